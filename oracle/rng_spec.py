@@ -1,0 +1,90 @@
+"""RNG specification of the build (TEST INFRASTRUCTURE -- never imported by the product).
+
+The reference draws decks from the process-global stdlib MT19937
+(`random.shuffle(self.deck)`, reference pokerl/game.py:424) and random-agent
+actions from numpy's global legacy RNG (pokerl/agents/random.py:12-16,
+examples/random_game.py:8).  Neither is reproducible per table, so "identical
+RNG seeds" is defined by THIS counter-based spec instead:
+
+  Philox4x32-10 (Salmon et al., Random123 constants), key = (seed_lo, seed_hi).
+
+  deck of a table's `hand_serial`-th setup_hand() call (0-based, never reset):
+      counter = (table_id, hand_serial, STREAM_DECK, block), block = 0,1,...
+      r[4*block + j] = j-th output word of that block
+      d = canonical deck (reference pokerl/cards.py:74-77: value[i] = ((i%4)<<4)|(i//4))
+      for i in 0..50:  j = i + ((r[i] * (52 - i)) >> 32);  swap(d[i], d[j])
+      (only d[0 : 5+2N] is ever read by the game: game.py:278,388-389,394-395,
+       so device code stops after i = 4+2N; the prefix is identical.)
+
+  random-agent action of a table's `step_serial`-th Game.step() (0-based, never reset):
+      counter = (table_id, step_serial, STREAM_ACTION, 0);  r = output word 0
+      n = popcount(valid_mask);  k = (r * n) >> 32;  action = k-th set bit (ascending)
+
+Pure-Python ints here (small cases only); the C restatement lives in pokerl_oracle.c.
+"""
+
+M0 = 0xD2511F53
+M1 = 0xCD9E8D57
+W0 = 0x9E3779B9
+W1 = 0xBB67AE85
+MASK32 = 0xFFFFFFFF
+
+STREAM_DECK = 0x4445434B    # 'DECK'
+STREAM_ACTION = 0x41435431  # 'ACT1'
+
+DEFAULT_SEED = 0x706F6B65726C  # 'pokerl'
+
+POLICY_RANDOM = 0
+POLICY_ALLIN = 1
+
+
+def philox4x32_10(ctr, key):
+    """One Philox4x32-10 block. ctr: 4 u32, key: 2 u32 -> 4 u32."""
+    c0, c1, c2, c3 = ctr
+    k0, k1 = key
+    for _ in range(10):
+        p0 = M0 * c0
+        p1 = M1 * c2
+        hi0, lo0 = p0 >> 32, p0 & MASK32
+        hi1, lo1 = p1 >> 32, p1 & MASK32
+        c0, c1, c2, c3 = (hi1 ^ c1 ^ k0) & MASK32, lo1, (hi0 ^ c3 ^ k1) & MASK32, lo0
+        k0 = (k0 + W0) & MASK32
+        k1 = (k1 + W1) & MASK32
+    return c0, c1, c2, c3
+
+
+def seed_key(seed):
+    return seed & MASK32, (seed >> 32) & MASK32
+
+
+def canonical_deck_values():
+    """Card.value of the reference's create_default_deck(), in order (cards.py:77)."""
+    return [((i % 4) << 4) | (i // 4) for i in range(52)]
+
+
+def deck_permutation(seed, table_id, hand_serial, nsteps=51):
+    """Index permutation p such that deck[i] = canonical[p[i]]."""
+    key = seed_key(seed)
+    d = list(range(52))
+    r = []
+    for i in range(nsteps):
+        if i % 4 == 0:
+            r.extend(philox4x32_10((table_id & MASK32, hand_serial & MASK32, STREAM_DECK, i // 4), key))
+        j = i + ((r[i] * (52 - i)) >> 32)
+        d[i], d[j] = d[j], d[i]
+    return d
+
+
+def pick_action(seed, table_id, step_serial, valid_mask_bits, policy=POLICY_RANDOM):
+    """Action of the synthetic agents. valid_mask_bits: bit a set iff action a valid."""
+    if policy == POLICY_ALLIN:
+        return 6
+    r = philox4x32_10((table_id & MASK32, step_serial & MASK32, STREAM_ACTION, 0), seed_key(seed))[0]
+    n = bin(valid_mask_bits).count("1")
+    k = (r * n) >> 32
+    for a in range(7):
+        if (valid_mask_bits >> a) & 1:
+            if k == 0:
+                return a
+            k -= 1
+    raise AssertionError("empty valid mask")

@@ -1,0 +1,429 @@
+#!/usr/bin/env python3
+"""Golden-vector generator: runs the REAL reference (imported read-only from
+/root/reference) under the build's RNG spec and writes small fixtures next to
+this script.  Runs only in the build container -- /root/reference does not
+exist on the GPU box, and nothing in tests/, bench.py or the package reads it.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [--only NAME]
+
+What is injected (reference untouched on disk):
+  * pokerl.game.random  -> object whose .shuffle(deck) installs the Philox deck
+    of oracle/rng_spec.py for (seed, table_id, hand_serial)     [game.py:1,424]
+  * pokerl.game.eval_hand -> recording wrapper (captures showdown rankings)  [game.py:489]
+  * agents -> oracle/rng_spec.pick_action(seed, table_id, step_serial, mask)
+Everything else (Game, judger, cards, envs) is the reference's own code.
+"""
+import argparse
+import hashlib
+import json
+import os
+import sys
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference")
+
+import numpy as np  # noqa: E402
+
+import pokerl.game as G  # noqa: E402
+from pokerl.cards import Card  # noqa: E402
+from pokerl.envs import PokerGameEnv  # noqa: E402
+from pokerl.enums import PlayerState  # noqa: E402
+from pokerl import judger as J  # noqa: E402
+
+from oracle import rng_spec as R  # noqa: E402
+
+SNAP_FIELDS = ("active", "turn", "dealer", "sb", "bb", "hand", "states", "credits", "bets",
+               "pending", "payoffs", "min_raise", "cards", "srank", "skick", "valid",
+               "hand_serial", "step_serial")
+
+
+# --------------------------------------------------------------------------- injection
+class _DeckInjector:
+    def __init__(self):
+        self.by_deck = {}
+
+    def shuffle(self, deck):
+        t = self.by_deck[id(deck)]
+        perm = R.deck_permutation(t.seed, t.table_id, t.hand_serial)
+        deck[:] = [t.canon[i] for i in perm]
+        t.hand_serial += 1
+
+
+_injector = _DeckInjector()
+G.random = _injector
+
+_eval_sink = []
+_real_eval = G.eval_hand
+
+
+def _recording_eval(hand):
+    out = _real_eval(hand)
+    _eval_sink.append(out)
+    return out
+
+
+G.eval_hand = _recording_eval
+
+
+class Table:
+    """One reference Game plus the per-table serials of the RNG spec."""
+
+    def __init__(self, seed, table_id, n, game=None, **cfg):
+        self.seed, self.table_id, self.n = seed, table_id, n
+        self.hand_serial = 0
+        self.step_serial = 0
+        self.game = game if game is not None else G.Game(num_players=n, **cfg)
+        self.canon = list(self.game.deck)
+        _injector.by_deck[id(self.game.deck)] = self
+        self.srank = np.full(n, 10, np.uint8)
+        self.skick = np.zeros(n, np.uint32)
+        real_step = self.game.step
+
+        def counted_step(action):
+            del _eval_sink[:]
+            out = real_step(action)
+            self.step_serial += 1  # only reached when the action was valid
+            self._absorb_showdowns()
+            return out
+
+        self.game.step = counted_step
+
+    def _absorb_showdowns(self):
+        # every showdown evaluates exactly num_players hands in seat order (game.py:488-489)
+        assert len(_eval_sink) % self.n == 0
+        if _eval_sink:
+            last = _eval_sink[-self.n:]
+            for p, (rank, kick) in enumerate(last):
+                self.srank[p] = rank
+                self.skick[p] = J.get_kickers_value(kick)
+        del _eval_sink[:]
+
+    def mask_bits(self):
+        onehot, _ = self.game.get_valid_actions()
+        return sum(1 << a for a in range(7) if onehot[a])
+
+    def pick(self, policy):
+        return R.pick_action(self.seed, self.table_id, self.step_serial, self.mask_bits(), policy)
+
+    def snapshot(self):
+        g = self.game
+        ncards = 5 + 2 * self.n
+        return dict(
+            active=g.active_player, turn=g.turn, dealer=g.dealer_idx, sb=g.small_blind_idx,
+            bb=g.big_blind_idx, hand=g.hand, states=g.player_states.copy(),
+            credits=g.credits.copy(), bets=g.bets.copy(), pending=g.pending_bets.copy(),
+            payoffs=g.payoffs.copy(), min_raise=float(g.minimum_raise_value),
+            cards=np.array([c.value for c in g.deck[:ncards]], np.uint8),
+            srank=self.srank.copy(), skick=self.skick.copy(), valid=self.mask_bits(),
+            hand_serial=self.hand_serial, step_serial=self.step_serial)
+
+
+_DT = dict(active=np.uint8, turn=np.uint8, dealer=np.uint8, sb=np.uint8, bb=np.uint8,
+           hand=np.int32, states=np.uint8, credits=np.float64, bets=np.float64,
+           pending=np.float64, payoffs=np.float64, min_raise=np.float64, cards=np.uint8,
+           srank=np.uint8, skick=np.uint32, valid=np.uint8, hand_serial=np.uint32,
+           step_serial=np.uint32)
+
+
+def _stack(snaps, prefix):
+    return {prefix + k: np.array([s[k] for s in snaps], dtype=_DT[k]) for k in SNAP_FIELDS}
+
+
+def snap_digest(snaps_by_table):
+    """sha256 over one lockstep snapshot of all tables (fixed field order, C order)."""
+    h = hashlib.sha256()
+    for k in SNAP_FIELDS:
+        h.update(np.ascontiguousarray(np.array([s[k] for s in snaps_by_table], dtype=_DT[k])).tobytes())
+    return h.hexdigest()
+
+
+# --------------------------------------------------------------------------- Game trajectories
+def game_trajectory(n, policy, seed, tables, steps, table_id_base=0, cfg=None, full=True, digest_every=0):
+    cfg = cfg or dict(start_credits=100, big_blind=2, small_blind=1)
+    ts = [Table(seed, table_id_base + i, n, **cfg) for i in range(tables)]
+    for t in ts:
+        t.game.reset()
+    init = [t.snapshot() for t in ts]
+    out = {}
+    meta = dict(kind="game", n=n, policy=policy, seed=seed, tables=tables, steps=steps,
+                table_id_base=table_id_base, cfg=cfg)
+    actions = np.zeros((steps, tables), np.int8)
+    flags = np.zeros((steps, tables), np.uint8)
+    post, resets, reset_idx, digests = [], [], [], []
+    for s in range(steps):
+        row = []
+        for i, t in enumerate(ts):
+            a = t.pick(policy)
+            over, hand, turn = t.game.step(int(a))
+            actions[s, i] = a
+            flags[s, i] = int(bool(over)) | int(bool(hand)) << 1 | int(bool(turn)) << 2
+            row.append(t.snapshot())
+        if full:
+            post.append(row)
+        if digest_every and (s + 1) % digest_every == 0:
+            digests.append(snap_digest(row))
+        for i, t in enumerate(ts):  # auto-reset finished games, as bench/rollout do
+            if flags[s, i] & 1:
+                t.game.reset()
+                if full:
+                    resets.append(t.snapshot())
+                    reset_idx.append((s, i))
+    out["actions"], out["flags"] = actions, flags
+    out.update(_stack(init, "init_"))
+    if full:
+        flat = [sn for row in post for sn in row]
+        st = _stack(flat, "post_")
+        for k, v in st.items():
+            out[k] = v.reshape((steps, tables) + v.shape[1:])
+        if resets:
+            out.update(_stack(resets, "reset_"))
+        out["reset_idx"] = np.array(reset_idx, np.int32).reshape(-1, 2)
+    if digest_every:
+        meta["digest_every"] = digest_every
+        meta["digests"] = digests
+    out["meta"] = np.array(json.dumps(meta))
+    return out
+
+
+# --------------------------------------------------------------------------- PokerGameEnv trajectories
+def env_trajectory(n, policy, opp_policy, seed, tables, steps, table_id_base=0, cfg=None):
+    cfg = cfg or dict(start_credits=100, big_blind=2, small_blind=1)
+    envs, ts = [], []
+    for i in range(tables):
+        holder = {}
+
+        def agent(state, holder=holder):
+            return holder["t"].pick(opp_policy)
+
+        env = PokerGameEnv([agent] * (n - 1), num_players=n, **cfg)
+        t = Table(seed, table_id_base + i, n, game=env.game)
+        holder["t"] = t
+        envs.append(env)
+        ts.append(t)
+    for env in envs:
+        env.reset()
+    init = [t.snapshot() for t in ts]
+    actions = np.zeros((steps, tables), np.int8)
+    reward = np.zeros((steps, tables), np.float64)
+    done = np.zeros((steps, tables), np.uint8)
+    hand = np.zeros((steps, tables), np.uint8)
+    post, resets, reset_idx = [], [], []
+    for s in range(steps):
+        row = []
+        for i, (env, t) in enumerate(zip(envs, ts)):
+            a = t.pick(policy)
+            _, r, d, h = env.step(int(a))
+            actions[s, i], reward[s, i], done[s, i], hand[s, i] = a, r, bool(d), bool(h)
+            row.append(t.snapshot())
+        post.append(row)
+        for i, (env, t) in enumerate(zip(envs, ts)):
+            if done[s, i]:
+                env.reset()
+                resets.append(t.snapshot())
+                reset_idx.append((s, i))
+    out = dict(actions=actions, reward=reward, done=done, hand_over=hand)
+    out.update(_stack(init, "init_"))
+    flat = [sn for row in post for sn in row]
+    for k, v in _stack(flat, "post_").items():
+        out[k] = v.reshape((steps, tables) + v.shape[1:])
+    if resets:
+        out.update(_stack(resets, "reset_"))
+    out["reset_idx"] = np.array(reset_idx, np.int32).reshape(-1, 2)
+    meta = dict(kind="env", n=n, policy=policy, opp_policy=opp_policy, seed=seed, tables=tables,
+                steps=steps, table_id_base=table_id_base, cfg=cfg)
+    out["meta"] = np.array(json.dumps(meta))
+    return out
+
+
+# --------------------------------------------------------------------------- judger vectors
+# Inputs of the reference's own known-answer tests (tests/pokerl/test_judger.py:14-78 and
+# :83-117), as data.  Expected outputs are produced by running the reference below.
+KAT_EVAL = [
+    "2C 3C 4C 5C 6C 7C 8C", "1D 2D 3D 4D 5D 6C 7C", "1D 2D 3D 4D 8D 6C 7C", "1D 3D 5H 7H 7S 9S JS",
+    "1D 3D 5H 8H 7S 9S 1S", "1D 1C 5H 6H 6H TS TS", "KD QC JH TH 9H 9S 9D", "KD QC JH TH 9H 5S 9D",
+    "KD QC JH TH 9H 5S 7D", "8D 9C 7H 6H 9H 5S 7D", "2H 3C 4H 5H 6H 7H 8D", "8D 8C 8H 5H 5S 5D 3D",
+    "8D 8C 8H 5H 5S 4D 3D", "1D 1C 1H 5H 5S 5D 5C", "1D 1C 1H 1S KS KD KC", "2D 3D 4D 5D 7D 6C KC",
+    "2D 3C 4D 5D 8D JC KC", "2D 2C 3D 3D JD JC KC", "2D 2C 3D 3D JD JC JC", "2D 2C 3D 3D 3D JC JC",
+    "KC QC JC TC 9C AD 4D", "9D 8C 4D 5D 6D JD KC",
+]
+KAT_EVAL_EXPECT = [  # (HandRanking, kickers) asserted at test_judger.py:15-78
+    (1, [7]), (1, [4]), (4, [13, 7, 3, 2, 1]), (8, [6, 13, 10, 8]), (8, [13, 8, 7, 6]), (7, [13, 9, 5]),
+    (5, [12]), (5, [12]), (5, [12]), (5, [8]), (4, [6, 5, 4, 3, 1]), (3, [7, 4]), (3, [7, 4]),
+    (2, [4, 13]), (2, [13, 12]), (4, [6, 4, 3, 2, 1]), (9, [12, 10, 7, 4, 3]), (7, [10, 2, 12]),
+    (3, [10, 2]), (3, [2, 10]), (1, [12]), (4, [10, 8, 5, 4, 3]),
+]
+KAT_COMPARE = [
+    (["1D 1C 1H 5H 6H 1S KS", "1D 1C 1H 5H 6H QS JS"], [1, 0]),
+    (["1D 1C 1H 5H 6H 1S KS", "1D 1C 1H 5H 6H QH JH"], [1, 0]),
+    (["1D 1C 1H 2H 3H 1S KS", "1D 1C 1H 2H 3H 4H 5H"], [0, 1]),
+    (["1D 3C 5H 7H 9H KS JS", "1D 3C 5H 7H 9H QS TS"], [1, 0]),
+    (["1D 3C 5H 7H 9H KS JS", "1D 3C 5H 7H 9H QS TS"], [1, 0]),
+    (["1D 3C 5H 7H 9H KS JS", "1D 3C 5H 7H 9H 3S TS"], [0, 1]),
+    (["1D 3C 5H 7H 9H 1S 9D", "1D 3C 5H 7H 9H 7S 7S", "1D 3C 5H 7H 9H 9S 9S"], [0, 0, 1]),
+]
+# Quirk hands of SURVEY.md Appendix A.1 (straight-flush reset, wheel if/elif, ...)
+QUIRK_EVAL = [
+    "KC QC JC TC 9C 2C 3D", "KC 9C 8C 7C 6C 5C 2D", "AC KC QC 5D 4D 3D 2D", "AS KC QC 5D 4D 3D 2D",
+    "AD 5D 4D 3D 2D KC QC", "AC 2D 3H 4S 5C 6D 9H", "AC 2D 3H 4S 5C KD 9H", "7C 7D 7H 4S 4C 4D 2H",
+    "7C 7D 9H 9S 4C 4D 2H", "7C 7D 9H 9S 4C 4D KH", "AC AD AH AS 2C 2D 2H", "2C 3C 4C 5C 7C 8C 9C",
+]
+
+
+def cards_from(s):
+    return [Card(x) for x in s.split()]
+
+
+def pack_eval(out):
+    rank, kick = out
+    return int(rank), int(J.get_kickers_value(kick)), len(kick)
+
+
+def judger_vectors(seed=1234):
+    rng = np.random.default_rng(seed)
+    kat = []
+    for s, exp in zip(KAT_EVAL, KAT_EVAL_EXPECT):
+        out = J.eval_hand(cards_from(s))
+        assert (out[0], list(out[1])) == (exp[0], exp[1]), (s, out, exp)
+        kat.append(dict(cards=s, values=[c.value for c in cards_from(s)], rank=int(out[0]),
+                        kickers=[int(k) for k in out[1]]))
+    quirks = []
+    for s in QUIRK_EVAL:
+        out = J.eval_hand(cards_from(s))
+        quirks.append(dict(cards=s, values=[c.value for c in cards_from(s)], rank=int(out[0]),
+                           kickers=[int(k) for k in out[1]]))
+    cmp_kat = []
+    for hands, exp in KAT_COMPARE:
+        out = J.compare_hands([cards_from(h) for h in hands])
+        assert out[0] == exp
+        cmp_kat.append(dict(hands=hands, values=[[c.value for c in cards_from(h)] for h in hands],
+                            onehot=out[0], winners=out[1],
+                            rankings=[[int(r), [int(k) for k in ks]] for r, ks in out[2]]))
+    canon = R.canonical_deck_values()
+
+    def batch(m, ncards, distinct):
+        cards = np.full((m, 7), 0xFF, np.uint8)
+        rank = np.zeros(m, np.uint8)
+        kick = np.zeros(m, np.uint32)
+        nk = np.zeros(m, np.uint8)
+        for i in range(m):
+            idx = rng.choice(52, ncards, replace=not distinct) if ncards else []
+            vals = [canon[j] for j in idx]
+            cards[i, :ncards] = vals
+            rank[i], kick[i], nk[i] = pack_eval(J.eval_hand([Card(int(v)) for v in vals]))
+        return cards, rank, kick, nk
+
+    arrays = {}
+    parts = [batch(20000, 7, True), batch(4000, 7, False)]
+    for nc in range(0, 7):
+        parts.append(batch(1500, nc, True))
+        if nc >= 2:
+            parts.append(batch(500, nc, False))
+    ncards = np.concatenate([np.full(len(p[0]), (p[0][0] != 0xFF).sum() if len(p[0]) else 0, np.uint8)
+                             for p in parts])
+    arrays["eval_cards"] = np.concatenate([p[0] for p in parts])
+    arrays["eval_ncards"] = (arrays["eval_cards"] != 0xFF).sum(axis=1).astype(np.uint8)
+    del ncards
+    arrays["eval_rank"] = np.concatenate([p[1] for p in parts])
+    arrays["eval_kick"] = np.concatenate([p[2] for p in parts])
+    arrays["eval_nkick"] = np.concatenate([p[3] for p in parts])
+
+    # compare_rankings on random ranking lists (incl. NONE entries and exact ties), judger.py:111-158
+    m = 6000
+    cr_n = np.zeros(m, np.uint8)
+    cr_rank = np.full((m, 10), 10, np.uint8)
+    cr_kick = np.zeros((m, 10), np.uint32)
+    cr_onehot = np.zeros((m, 10), np.uint8)
+    for i in range(m):
+        n = int(rng.integers(1, 11))
+        cr_n[i] = n
+        board = [Card(int(canon[j])) for j in rng.choice(52, 5, replace=False)] if i % 2 else None
+        rankings = []
+        for p in range(n):
+            if rng.random() < 0.25:
+                rankings.append((10, []))
+                continue
+            if board is not None:  # shared board -> frequent equal ranks / exact ties
+                hole = [Card(int(canon[j])) for j in rng.choice(52, 2, replace=False)]
+                rankings.append(J.eval_hand(board + hole))
+            else:
+                rankings.append(J.eval_hand([Card(int(canon[j])) for j in rng.choice(52, 7, replace=False)]))
+        onehot, winners = J.compare_rankings(rankings)
+        for p, (r, k) in enumerate(rankings):
+            cr_rank[i, p] = r
+            cr_kick[i, p] = J.get_kickers_value(k)
+        cr_onehot[i, :n] = onehot
+    arrays.update(cr_n=cr_n, cr_rank=cr_rank, cr_kick=cr_kick, cr_onehot=cr_onehot)
+    return dict(kat=kat, quirks=quirks, compare_kat=cmp_kat), arrays
+
+
+# --------------------------------------------------------------------------- main
+SEED = R.DEFAULT_SEED
+GAME_SETS = {
+    # name: (n, policy, seed, tables, steps, table_id_base, cfg)
+    "game_n2_random": (2, R.POLICY_RANDOM, SEED, 8, 256, 0, None),
+    "game_n6_random": (6, R.POLICY_RANDOM, SEED, 8, 256, 0, None),
+    "game_n9_random": (9, R.POLICY_RANDOM, SEED, 6, 200, 0, None),
+    "game_n6_allin": (6, R.POLICY_ALLIN, SEED, 6, 128, 0, None),
+    "game_n9_allin": (9, R.POLICY_ALLIN, SEED, 6, 128, 0, None),
+    "game_n4_example_cfg": (4, R.POLICY_RANDOM, SEED ^ 0x5555, 6, 200, 1000,
+                            dict(start_credits=1000, big_blind=40, small_blind=20)),  # examples/random_game.py:9
+    "game_n3_percredits": (3, R.POLICY_RANDOM, 7, 6, 200, 77,
+                           dict(start_credits=[30, 100, 5], big_blind=4, small_blind=2)),
+    "game_n10_random": (10, R.POLICY_RANDOM, 99, 4, 150, 5, None),
+}
+DIGEST_SETS = {
+    # long runs pinned by sha256 digests only (every 100 steps)
+    "digest_n2_random": (2, R.POLICY_RANDOM, SEED, 64, 2000, 0, None),
+    "digest_n6_random": (6, R.POLICY_RANDOM, SEED, 64, 2000, 0, None),
+    "digest_n9_random": (9, R.POLICY_RANDOM, SEED, 32, 1500, 0, None),
+    "digest_n9_allin": (9, R.POLICY_ALLIN, SEED, 32, 1000, 0, None),
+    "digest_n6_shard1": (6, R.POLICY_RANDOM, SEED, 32, 1000, 65536, None),  # table_id_base of rank 1 at C4
+}
+ENV_SETS = {
+    "env_n4_random": (4, R.POLICY_RANDOM, R.POLICY_RANDOM, SEED, 8, 200, 0, None),
+    "env_n6_random": (6, R.POLICY_RANDOM, R.POLICY_RANDOM, SEED, 6, 200, 0, None),
+    "env_n6_vs_allin": (6, R.POLICY_RANDOM, R.POLICY_ALLIN, SEED, 6, 150, 0, None),
+    "env_n2_random": (2, R.POLICY_RANDOM, R.POLICY_RANDOM, SEED, 8, 200, 0, None),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    args = ap.parse_args()
+
+    def want(name):
+        return args.only is None or args.only == name
+
+    if want("judger"):
+        js, arrays = judger_vectors()
+        with open(os.path.join(HERE, "judger_kat.json"), "w") as f:
+            json.dump(js, f, indent=1)
+        np.savez_compressed(os.path.join(HERE, "judger_vectors.npz"), **arrays)
+        print("judger: %d eval vectors, %d compare vectors" % (len(arrays["eval_rank"]), len(arrays["cr_n"])))
+    for name, (n, pol, seed, tables, steps, base, cfg) in GAME_SETS.items():
+        if want(name):
+            out = game_trajectory(n, pol, seed, tables, steps, base, cfg)
+            np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+            print(name, "resets:", len(out["reset_idx"]), "hands:", int(out["post_hand_serial"].max()))
+    for name, (n, pol, seed, tables, steps, base, cfg) in DIGEST_SETS.items():
+        if want(name):
+            out = game_trajectory(n, pol, seed, tables, steps, base, cfg, full=False, digest_every=100)
+            meta = json.loads(str(out["meta"]))
+            meta["flags_sha256"] = hashlib.sha256(out["flags"].tobytes()).hexdigest()
+            meta["actions_sha256"] = hashlib.sha256(out["actions"].tobytes()).hexdigest()
+            with open(os.path.join(HERE, name + ".json"), "w") as f:
+                json.dump(meta, f, indent=1)
+            print(name, "digests:", len(meta["digests"]))
+    for name, (n, pol, opp, seed, tables, steps, base, cfg) in ENV_SETS.items():
+        if want(name):
+            out = env_trajectory(n, pol, opp, seed, tables, steps, base, cfg)
+            np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+            print(name, "episodes:", int(out["done"].sum()))
+
+
+if __name__ == "__main__":
+    main()

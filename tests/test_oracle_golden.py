@@ -1,0 +1,110 @@
+"""CPU oracle (oracle/pokerl_oracle.c) pinned against vectors captured from the imported reference."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import golden_util as GU
+from oracle import loader as O
+from oracle import rng_spec as R
+
+
+def make_oracle(meta):
+    cfg = meta["cfg"]
+    return O.OracleGame(meta["tables"], meta["n"], cfg["start_credits"], cfg["big_blind"], cfg["small_blind"],
+                        seed=meta["seed"], table_id_base=meta["table_id_base"])
+
+
+def test_philox_known_answers():
+    # Random123 kat_vectors: philox4x32 10 rounds
+    L = O.lib()
+    out = np.zeros(4, np.uint32)
+    for ctr, key, exp in [
+        ((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+        ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+        ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+         (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1)),
+    ]:
+        L.orc_philox4x32_10(np.array(ctr, np.uint32), np.array(key, np.uint32), out)
+        assert tuple(int(x) for x in out) == exp
+        assert R.philox4x32_10(ctr, key) == exp
+
+
+def test_deck_spec_c_vs_python():
+    L = O.lib()
+    canon = R.canonical_deck_values()
+    out = np.zeros(52, np.uint8)
+    for seed, tid, hs in [(R.DEFAULT_SEED, 0, 0), (R.DEFAULT_SEED, 65535, 17), (1, 524287, 4000000000), (2**63 + 5, 3, 9)]:
+        L.orc_deck(seed, tid, hs, out)
+        perm = R.deck_permutation(seed, tid, hs)
+        assert sorted(perm) == list(range(52))
+        assert [canon[i] for i in perm] == out.tolist()
+        # the prefix the device computes (5+2N swaps) equals the full shuffle's prefix
+        for n in (2, 6, 9):
+            k = 5 + 2 * n
+            assert R.deck_permutation(seed, tid, hs, nsteps=k)[:k] == perm[:k]
+
+
+def test_np_sum_order_matches_numpy():
+    L = O.lib()
+    rng = np.random.default_rng(5)
+    for n in range(1, 17):
+        for _ in range(400):
+            a = rng.random(n) * rng.choice([1.0, 1e3, 1e-3, 1e7], n)
+            assert L.orc_np_sum(a, n) == np.sum(a)
+
+
+def test_judger_known_answers_of_reference_tests():
+    with open(os.path.join(GU.GOLDEN, "judger_kat.json")) as f:
+        kat = json.load(f)
+    for group in ("kat", "quirks"):
+        for case in kat[group]:
+            cards = np.array(case["values"], np.uint8)
+            rank, kick, nk = O.eval_hands(cards.reshape(1, 7))
+            exp_kick = 0
+            for k in case["kickers"]:
+                exp_kick = (exp_kick << 4) | k
+            assert (int(rank[0]), int(kick[0]), int(nk[0])) == (case["rank"], exp_kick, len(case["kickers"])), case
+    for case in kat["compare_kat"]:
+        vals = np.array(case["values"], np.uint8)
+        rank, kick, _ = O.eval_hands(vals)
+        assert O.compare_rankings(rank, kick).tolist() == case["onehot"]
+
+
+def test_judger_vectors():
+    z = np.load(os.path.join(GU.GOLDEN, "judger_vectors.npz"))
+    rank, kick, nk = O.eval_hands(z["eval_cards"], z["eval_ncards"])
+    assert np.array_equal(rank, z["eval_rank"])
+    assert np.array_equal(kick, z["eval_kick"])
+    assert np.array_equal(nk, z["eval_nkick"])
+    for i in range(len(z["cr_n"])):
+        n = int(z["cr_n"][i])
+        got = O.compare_rankings(z["cr_rank"][i, :n], z["cr_kick"][i, :n])
+        assert np.array_equal(got, z["cr_onehot"][i, :n]), i
+
+
+@pytest.mark.parametrize("name", GU.GAME_SETS)
+def test_game_trajectories(name):
+    GU.replay_game(make_oracle, name)
+
+
+@pytest.mark.parametrize("name", GU.DIGEST_SETS)
+def test_game_digests(name):
+    GU.replay_digest(make_oracle, name)
+
+
+@pytest.mark.parametrize("name", GU.ENV_SETS)
+def test_env_trajectories(name):
+    GU.replay_env(make_oracle, name)
+
+
+def test_invalid_action_leaves_state_untouched():
+    g = O.OracleGame(4, 3)
+    g.reset()
+    before = g.snapshot()
+    flags, err = g.step(np.array([1, 7, -1, 1], np.int32))  # CHECK invalid preflop (high_bet=2); 7/-1 out of range
+    assert err.tolist() == [O.ERR_INVALID_ACTION] * 4
+    after = g.snapshot()
+    for k in GU.SNAP_FIELDS:
+        assert GU.bits_equal(before[k], after[k])
