@@ -1,0 +1,162 @@
+/* pokerl_hip.h -- C ABI of libpokerl_hip.so: the MI355X (gfx950) vectorised No-Limit Hold'em hot path.
+ *
+ * The reference (sneppy/pokerl) is pure Python and has no plugin/FFI layer; its boundary for this
+ * path is the Python object API.  Each entry point below names the reference interface it replaces
+ * (paths relative to the reference root).  T = num_tables, N = num_players.
+ *
+ * Conventions
+ *   - every pointer is a HOST pointer owned by the caller unless the name ends in `_d` (device pointer,
+ *     caller-owned, on the handle's device);  the library owns all table state behind the opaque handle;
+ *   - arrays are table-major: [T][N] for per-seat data, [T] for per-table data;
+ *   - return value: PK_OK (0) or a negative PK_E_* code; pk_last_error() gives text; the library never aborts;
+ *   - per-table error bits (PK_TERR_*) are reported separately from the call's return code;
+ *   - a handle is bound to one device and one HIP stream and is not thread-safe; different handles may be
+ *     driven from different threads/processes (one process per GPU is the intended deployment);
+ *   - RNG is counter-based per handle: Philox4x32-10 keyed by `seed`, indexed by the GLOBAL table id
+ *     (table_id_base + t), so results do not depend on how tables are sharded over GPUs.
+ *
+ * All money arithmetic is IEEE binary64 in the reference's operation order (no FMA contraction), so
+ * valid_actions / payoffs / credits / flags / hand ranks are bit-identical to the CPU reference.
+ */
+#ifndef POKERL_HIP_H
+#define POKERL_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PK_ABI_VERSION 1
+#define PK_MIN_PLAYERS 2
+#define PK_MAX_PLAYERS 10
+#define PK_NUM_MOVES 7 /* pokerl/enums.py:104-114 PokerMoves */
+
+/* return codes */
+#define PK_OK 0
+#define PK_E_INVALID_ARG (-1)
+#define PK_E_NO_DEVICE (-2)
+#define PK_E_HIP (-3)
+#define PK_E_OOM (-4)
+#define PK_E_TABLE (-5) /* at least one table reported a PK_TERR_* bit; call completed for all other tables */
+
+/* per-table error bits */
+#define PK_TERR_INVALID_ACTION 1 /* Game.step ValueError, pokerl/game.py:649-651: that table is left untouched */
+#define PK_TERR_NO_WINNER 2      /* Game.end_hand AssertionError, pokerl/game.py:473: state partially mutated as in the reference */
+#define PK_TERR_HAND_CAP 4       /* more than PK_HAND_CAP hands rolled inside one step (reference would keep looping) */
+#define PK_HAND_CAP 64
+
+/* step flags (bit set) = the tuple Game.step returns, pokerl/game.py:634-641 */
+#define PK_FLAG_GAME_OVER 1
+#define PK_FLAG_HAND_OVER 2
+#define PK_FLAG_TURN_OVER 4
+
+/* in-kernel agents (synthetic workload; RandomAgent semantics of pokerl/agents/random.py:12-16) */
+#define PK_POLICY_RANDOM 0 /* uniform over the valid mask */
+#define PK_POLICY_ALLIN 1  /* always PokerMoves.ALL_IN */
+
+/* f64 [T][N] fields of pk_get_f64 = Game attributes, pokerl/game.py:260-264 */
+#define PK_F_CREDITS 0
+#define PK_F_BETS 1
+#define PK_F_PENDING_BETS 2
+#define PK_F_PAYOFFS 3
+
+/* int32 [T] fields of pk_get_i32 = Game attributes, pokerl/game.py:251-258 */
+#define PK_I_ACTIVE_PLAYER 0
+#define PK_I_TURN 1
+#define PK_I_DEALER_IDX 2
+#define PK_I_SMALL_BLIND_IDX 3
+#define PK_I_BIG_BLIND_IDX 4
+#define PK_I_HAND 5
+#define PK_I_HAND_SERIAL 6 /* RNG spec: setup_hand() calls so far */
+#define PK_I_STEP_SERIAL 7 /* RNG spec: completed Game.step() calls so far */
+
+/* rollout counters */
+#define PK_C_STEPS 0
+#define PK_C_HANDS 1
+#define PK_C_EVALS 2 /* 7-card eval_hand calls made by showdowns, pokerl/game.py:489 */
+#define PK_C_GAMES 3
+#define PK_NUM_COUNTERS 4
+
+typedef struct pk_handle pk_handle;
+
+int pk_abi_version(void);
+/* Number of visible HIP devices (0 if none / no driver). */
+int pk_device_count(void);
+const char *pk_last_error(const pk_handle *h); /* h may be NULL: last create/standalone error of this thread */
+
+/* Game(**config), pokerl/game.py:242-264.  start_credits: N doubles or NULL (then start_credit_scalar is
+ * broadcast, the `isinstance(self.start_credits, int)` branch of game.py:408).  `dealer` is kept for API parity;
+ * Game.reset() overwrites it (game.py:403).  Tables start un-reset (credits 0), as in the reference. */
+int pk_create(pk_handle **out, int device, int num_tables, int num_players, const double *start_credits,
+              double start_credit_scalar, double big_blind, double small_blind, int dealer, uint64_t seed,
+              uint32_t table_id_base);
+int pk_destroy(pk_handle *h);
+int pk_num_tables(const pk_handle *h);
+int pk_num_players(const pk_handle *h);
+
+/* Game.reset(dealer=...), pokerl/game.py:397-412, on tables with mask[t] != 0 (mask NULL = all tables). */
+int pk_reset(pk_handle *h, const uint8_t *mask, int dealer);
+
+/* Game.step(action), pokerl/game.py:621-700, one action per table.
+ * flags[T] (PK_FLAG_*), terr[T] (PK_TERR_*, may be NULL).  Returns PK_E_TABLE if any terr != 0. */
+int pk_step(pk_handle *h, const int32_t *actions, uint8_t *flags, uint8_t *terr);
+/* Same, device-resident I/O (inputs already in HBM; asynchronous on the handle's stream). */
+int pk_step_d(pk_handle *h, const int32_t *actions_d, uint8_t *flags_d, uint8_t *terr_d);
+
+/* Game.get_valid_actions() of the active player, pokerl/game.py:339-383: out[T][7] one-hot bytes. */
+int pk_get_valid_actions(pk_handle *h, uint8_t *out);
+
+/* State reads (Game attributes). */
+int pk_get_f64(pk_handle *h, int field, double *out /* [T][N] */);
+int pk_get_min_raise(pk_handle *h, double *out /* [T] minimum_raise_value */);
+int pk_get_player_states(pk_handle *h, uint8_t *out /* [T][N] PlayerState, pokerl/enums.py:130-136 */);
+int pk_get_i32(pk_handle *h, int field, int32_t *out /* [T] */);
+/* deck[0 : 5+2N] as Card.value bytes ((suit<<4)|rank0, pokerl/cards.py:28-62): community = [0:5], hole(p) = [5+2p : 7+2p]
+ * (pokerl/game.py:385-395). out[T][5+2N]. */
+int pk_get_cards(pk_handle *h, uint8_t *out);
+/* Rankings of the last showdown of each table (pokerl/game.py:488-489): rank[T][N] HandRanking (10 = NONE for
+ * seats not shown down), kick[T][N] = judger.get_kickers_value(kickers) (pokerl/judger.py:101-109). */
+int pk_get_hand_ranks(pk_handle *h, uint8_t *rank, uint32_t *kick);
+
+/* pokerl.judger.eval_hand (pokerl/judger.py:7-99) on M hands.  cards[M][7] Card.value bytes (unused slots ignored),
+ * ncards[M] in 0..7 (NULL = all 7).  rank[M], kick[M] (packed kickers, judger.py:101-109), nkick[M] (may be NULL).
+ * Multiset semantics: duplicate cards are legal, as in the reference's own tests. */
+int pk_eval_hands(int device, const uint8_t *cards, const uint8_t *ncards, size_t m, uint8_t *rank, uint32_t *kick,
+                  uint8_t *nkick);
+/* pokerl.judger.compare_rankings (pokerl/judger.py:111-158) on M lists of n rankings: rank[M][n], kick[M][n] ->
+ * onehot[M][n].  Includes the reference's line-148 behaviour. */
+int pk_compare_rankings(int device, const uint8_t *rank, const uint32_t *kick, int n, size_t m, uint8_t *onehot);
+
+/* Actions the in-kernel agent `policy` would take now (one per table) -- lets a host loop reproduce rollouts. */
+int pk_pick_actions(pk_handle *h, int policy, int32_t *actions);
+
+/* Throughput path: K lockstep Game.step()s per table with in-kernel agents; finished games are reset
+ * (Game.reset()) when auto_reset != 0.  fused != 0: ONE launch, table state held in registers for all K steps;
+ * fused == 0: K launches, state round-trips HBM every step.  counters[PK_NUM_COUNTERS] are ADDED to (may be NULL).
+ * Asynchronous unless counters != NULL. */
+int pk_rollout(pk_handle *h, int k_steps, int policy, int auto_reset, int fused, uint64_t *counters);
+
+/* PokerGameEnv.reset() / .step(action) (pokerl/envs/game_env.py:20-29, :31-53): seat 0 is the controlled seat,
+ * the other seats play `opp_policy` in-kernel.  reward[T] f64, done[T], hand[T] bytes. */
+int pk_env_reset(pk_handle *h, const uint8_t *mask, int opp_policy);
+int pk_env_step(pk_handle *h, const int32_t *actions, int opp_policy, double *reward, uint8_t *done, uint8_t *hand,
+                uint8_t *terr);
+
+/* Dense observation of Game.StateView(active player) (pokerl/game.py:117-131), one row of PK_OBS_DIM(N) doubles
+ * per table: [player, turn, minimum_raise_value, valid_actions[7], player_cards[2], community_cards[5] (-1 where
+ * not yet visible: game.py:278), credits[N], bets[N], pending_bets[N]]. */
+#define PK_OBS_DIM(n) (3 + 7 + 2 + 5 + 3 * (n))
+int pk_get_obs(pk_handle *h, double *out /* [T][PK_OBS_DIM(N)] */);
+
+/* Stream control / timing helpers (no torch types: plain HIP underneath). */
+int pk_sync(pk_handle *h);
+/* Runs `reps` back-to-back fused rollouts of k_steps each and returns the average device time of one launch in
+ * milliseconds, measured with HIP events on the handle's stream (used by bench.py's roofline leg). */
+int pk_time_rollout(pk_handle *h, int k_steps, int policy, int auto_reset, int fused, int reps, double *ms_per_launch,
+                    uint64_t *counters);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

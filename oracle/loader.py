@@ -62,6 +62,9 @@ def lib():
     L.orc_compare_rankings.restype = C.c_int
     L.orc_philox4x32_10.argtypes = [_u32p, _u32p, _u32p]
     L.orc_deck.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, _u8p]
+    L.orc_eval7_digest.argtypes = [C.c_int, C.c_int, _u64p, _u64p]
+    L.orc_eval7_prefix.argtypes = [C.c_int, C.c_int, _u32p]
+    L.orc_eval7_prefix.restype = C.c_size_t
     L.orc_np_sum.argtypes = [_f64p, C.c_int]
     L.orc_np_sum.restype = C.c_double
     _lib = L
@@ -182,3 +185,10 @@ def compare_rankings(rank, kick):
     onehot = np.zeros(len(rank), np.uint8)
     lib().orc_compare_rankings(rank, kick, len(rank), onehot)
     return onehot
+
+
+def eval7_digest(first_lo=0, first_hi=52):
+    per_first = np.zeros(52, np.uint64)
+    counts = np.zeros(11, np.uint64)
+    lib().orc_eval7_digest(int(first_lo), int(first_hi), per_first, counts)
+    return per_first, counts

@@ -56,25 +56,35 @@ void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
 }
 
 void orc_deck(uint64_t seed, uint32_t table_id, uint32_t hand_serial, uint8_t out[52]) {
-    uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)}, r[52];
-    for (int b = 0; b < 13; ++b) {
-        uint32_t ctr[4] = {table_id, hand_serial, STREAM_DECK, (uint32_t)b};
-        orc_philox4x32_10(ctr, key, r + 4 * b);
-    }
-    for (int i = 0; i < 52; ++i) out[i] = (uint8_t)(((i % 4) << 4) | (i / 4)); /* cards.py:77 */
-    for (int i = 0; i < 51; ++i) {
-        int j = i + (int)(((uint64_t)r[i] * (uint64_t)(52 - i)) >> 32);
-        uint8_t tmp = out[i]; out[i] = out[j]; out[j] = tmp;
+    uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    uint8_t remaining[52];
+    int nrem = 52;
+    uint64_t words[2] = {0, 0}, x = 0;
+    for (int i = 0; i < 52; ++i) remaining[i] = (uint8_t)(((i % 4) << 4) | (i / 4)); /* cards.py:77 */
+    for (int i = 0; i < 52; ++i) {
+        if (i % 18 == 0) {
+            uint32_t ctr[4] = {table_id, hand_serial, STREAM_DECK, (uint32_t)(i / 18)}, w[4];
+            orc_philox4x32_10(ctr, key, w);
+            words[0] = (uint64_t)w[0] | ((uint64_t)w[1] << 32);
+            words[1] = (uint64_t)w[2] | ((uint64_t)w[3] << 32);
+        }
+        if (i % 9 == 0) x = words[(i / 9) % 2];
+        unsigned __int128 p = (unsigned __int128)x * (unsigned)(52 - i);
+        int c = (int)(p >> 64);
+        x = (uint64_t)p;
+        out[i] = remaining[c];
+        for (int k = c; k + 1 < nrem; ++k) remaining[k] = remaining[k + 1];
+        --nrem;
     }
 }
 
 static int pick_action(uint64_t seed, const table_t *t, int policy, unsigned mask) {
     if (policy == 1) return MV_ALL_IN;
     uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)}, o[4];
-    uint32_t ctr[4] = {t->table_id, t->step_serial, STREAM_ACTION, 0};
+    uint32_t ctr[4] = {t->table_id, t->step_serial >> 2, STREAM_ACTION, 0};
     orc_philox4x32_10(ctr, key, o);
     int n = __builtin_popcount(mask);
-    int k = (int)(((uint64_t)o[0] * (uint64_t)n) >> 32);
+    int k = (int)(((uint64_t)o[t->step_serial & 3] * (uint64_t)n) >> 32);
     for (int a = 0; a < MV_NUM; ++a)
         if ((mask >> a) & 1) { if (k == 0) return a; --k; }
     return -1;
@@ -570,4 +580,54 @@ void orc_get_cards(const orc_game *g, uint8_t *out) {
 }
 void orc_get_showdown(const orc_game *g, uint8_t *rank, uint32_t *kick) {
     for (int i = 0; i < g->T; ++i) { memcpy(rank + (size_t)i * g->N, g->t[i].srank, g->N); memcpy(kick + (size_t)i * g->N, g->t[i].skick, sizeof(uint32_t) * g->N); }
+}
+
+/* ------------------------------------------------------------------ exhaustive evaluator digest */
+static inline uint64_t mix64(uint64_t z) {
+    z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 27; z *= 0x94D049BB133111EBull; z ^= z >> 31;
+    return z;
+}
+static inline uint8_t canon(int c) { return (uint8_t)(((c % 4) << 4) | (c / 4)); }
+
+void orc_eval7_digest(int first_lo, int first_hi, uint64_t *per_first, uint64_t *counts) {
+    /* binomials for the lexicographic rank of the first hand with first card a */
+    static uint64_t C[53][8];
+    for (int n = 0; n <= 52; ++n) for (int k = 0; k <= 7; ++k) C[n][k] = k == 0 ? 1 : (n == 0 ? 0 : C[n - 1][k - 1] + C[n - 1][k]);
+    uint64_t idx = 0;
+    for (int x = 0; x < first_lo; ++x) idx += C[51 - x][6];
+    uint8_t h[7];
+    for (int a = first_lo; a < first_hi && a <= 45; ++a) {
+        uint64_t acc = 0;
+        h[0] = canon(a);
+        for (int b = a + 1; b < 52; ++b) { h[1] = canon(b);
+        for (int c = b + 1; c < 52; ++c) { h[2] = canon(c);
+        for (int d = c + 1; d < 52; ++d) { h[3] = canon(d);
+        for (int e = d + 1; e < 52; ++e) { h[4] = canon(e);
+        for (int f = e + 1; f < 52; ++f) { h[5] = canon(f);
+        for (int g = f + 1; g < 52; ++g) { h[6] = canon(g);
+            ranking_t r;
+            eval_hand(h, 7, &r);
+            uint64_t v = ((uint64_t)r.rank << 20) | kickers_value(&r);
+            acc += mix64(v ^ (idx * 0x9E3779B97F4A7C15ull));
+            counts[r.rank] += 1;
+            ++idx;
+        }}}}}}
+        per_first[a] += acc;
+    }
+}
+
+size_t orc_eval7_prefix(int a, int b, uint32_t *out) {
+    size_t k = 0;
+    uint8_t h[7];
+    h[0] = canon(a); h[1] = canon(b);
+    for (int c = b + 1; c < 52; ++c) { h[2] = canon(c);
+    for (int d = c + 1; d < 52; ++d) { h[3] = canon(d);
+    for (int e = d + 1; e < 52; ++e) { h[4] = canon(e);
+    for (int f = e + 1; f < 52; ++f) { h[5] = canon(f);
+    for (int g = f + 1; g < 52; ++g) { h[6] = canon(g);
+        ranking_t r;
+        eval_hand(h, 7, &r);
+        out[k++] = ((uint32_t)r.rank << 20) | kickers_value(&r);
+    }}}}}
+    return k;
 }

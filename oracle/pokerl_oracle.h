@@ -70,6 +70,12 @@ void orc_eval_hands(const uint8_t *cards, const uint8_t *ncards, size_t m, uint8
 /* judger.compare_rankings on one list. judger.py:111-158. Returns number of winners. */
 int orc_compare_rankings(const uint8_t *rank, const uint32_t *kick, int n, uint8_t *onehot);
 
+/* Exhaustive 7-card digest (definition: tests/golden/make_eval_digest.py): all C(52,7) hands whose FIRST (lowest)
+ * canonical index is in [first_lo, first_hi).  per_first[52] partial digests (mod 2^64), counts[11] per category. */
+void orc_eval7_digest(int first_lo, int first_hi, uint64_t *per_first, uint64_t *counts);
+/* v = rank<<20|kick for the hands of one (a,b) prefix in lexicographic order; returns how many were written. */
+size_t orc_eval7_prefix(int a, int b, uint32_t *out);
+
 /* Spec helpers exposed for tests */
 void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 void orc_deck(uint64_t seed, uint32_t table_id, uint32_t hand_serial, uint8_t out[52]);

@@ -9,15 +9,18 @@ RNG seeds" is defined by THIS counter-based spec instead:
   Philox4x32-10 (Salmon et al., Random123 constants), key = (seed_lo, seed_hi).
 
   deck of a table's `hand_serial`-th setup_hand() call (0-based, never reset):
-      counter = (table_id, hand_serial, STREAM_DECK, block), block = 0,1,...
-      r[4*block + j] = j-th output word of that block
-      d = canonical deck (reference pokerl/cards.py:74-77: value[i] = ((i%4)<<4)|(i//4))
-      for i in 0..50:  j = i + ((r[i] * (52 - i)) >> 32);  swap(d[i], d[j])
-      (only d[0 : 5+2N] is ever read by the game: game.py:278,388-389,394-395,
-       so device code stops after i = 4+2N; the prefix is identical.)
+      block b = philox(counter = (table_id, hand_serial, STREAM_DECK, b)) -> words w0..w3
+      64-bit words X[2b] = w0 | w1<<32,  X[2b+1] = w2 | w3<<32
+      draw i (i = 0,1,...) takes x = X[i // 9] when i % 9 == 0, then
+          p = x * (52 - i)  (128-bit);  c_i = p >> 64;  x = p mod 2^64     (chained multiply-high,
+          9 bounded draws per 64-bit word; relative bias <= 52!/43!/2^64 = 7.3e-5)
+      card i of the deck = the c_i-th (0-based) not-yet-dealt card of the canonical deck
+      (reference pokerl/cards.py:74-77: value[k] = ((k%4)<<4)|(k//4)); cards never dealt keep canonical order.
+      Only deck[0 : 5+2N] is ever read by the game (game.py:278,388-389,394-395), so device code
+      stops after draw 4+2N; draw i depends on nothing but (seed, table_id, hand_serial, i).
 
   random-agent action of a table's `step_serial`-th Game.step() (0-based, never reset):
-      counter = (table_id, step_serial, STREAM_ACTION, 0);  r = output word 0
+      r = word (step_serial & 3) of philox(counter = (table_id, step_serial >> 2, STREAM_ACTION, 0))
       n = popcount(valid_mask);  k = (r * n) >> 32;  action = k-th set bit (ascending)
 
 Pure-Python ints here (small cases only); the C restatement lives in pokerl_oracle.c.
@@ -62,24 +65,36 @@ def canonical_deck_values():
     return [((i % 4) << 4) | (i // 4) for i in range(52)]
 
 
-def deck_permutation(seed, table_id, hand_serial, nsteps=51):
-    """Index permutation p such that deck[i] = canonical[p[i]]."""
+def deck_draws(seed, table_id, hand_serial, ndraws=52):
+    """The bounded draws c_i in [0, 52-i)."""
     key = seed_key(seed)
-    d = list(range(52))
-    r = []
-    for i in range(nsteps):
-        if i % 4 == 0:
-            r.extend(philox4x32_10((table_id & MASK32, hand_serial & MASK32, STREAM_DECK, i // 4), key))
-        j = i + ((r[i] * (52 - i)) >> 32)
-        d[i], d[j] = d[j], d[i]
-    return d
+    c = []
+    x = 0
+    words = []
+    for i in range(ndraws):
+        if i % 18 == 0:
+            w = philox4x32_10((table_id & MASK32, hand_serial & MASK32, STREAM_DECK, i // 18), key)
+            words = [w[0] | (w[1] << 32), w[2] | (w[3] << 32)]
+        if i % 9 == 0:
+            x = words[(i // 9) % 2]
+        p = x * (52 - i)
+        c.append(p >> 64)
+        x = p & 0xFFFFFFFFFFFFFFFF
+    return c
+
+
+def deck_permutation(seed, table_id, hand_serial, ndraws=52):
+    """Index permutation p such that deck[i] = canonical[p[i]]."""
+    remaining = list(range(52))
+    perm = [remaining.pop(c) for c in deck_draws(seed, table_id, hand_serial, ndraws)]
+    return perm + remaining
 
 
 def pick_action(seed, table_id, step_serial, valid_mask_bits, policy=POLICY_RANDOM):
     """Action of the synthetic agents. valid_mask_bits: bit a set iff action a valid."""
     if policy == POLICY_ALLIN:
         return 6
-    r = philox4x32_10((table_id & MASK32, step_serial & MASK32, STREAM_ACTION, 0), seed_key(seed))[0]
+    r = philox4x32_10((table_id & MASK32, (step_serial >> 2) & MASK32, STREAM_ACTION, 0), seed_key(seed))[step_serial & 3]
     n = bin(valid_mask_bits).count("1")
     k = (r * n) >> 32
     for a in range(7):

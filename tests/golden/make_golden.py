@@ -141,7 +141,11 @@ def snap_digest(snaps_by_table):
 
 
 # --------------------------------------------------------------------------- Game trajectories
-def game_trajectory(n, policy, seed, tables, steps, table_id_base=0, cfg=None, full=True, digest_every=0):
+def game_trajectory(n, policy, seed, tables, steps, table_id_base=0, cfg=None, full=True, digest_every=0,
+                    auto_reset=True):
+    """auto_reset=False: finished games are NOT reset (the lone survivor keeps being stepped, which the
+    reference allows); a survivor's FOLD then trips `assert num_potential_winners > 0` (game.py:473):
+    recorded as err=2 with the partially mutated state, after which that table is reset."""
     cfg = cfg or dict(start_credits=100, big_blind=2, small_blind=1)
     ts = [Table(seed, table_id_base + i, n, **cfg) for i in range(tables)]
     for t in ts:
@@ -149,29 +153,34 @@ def game_trajectory(n, policy, seed, tables, steps, table_id_base=0, cfg=None, f
     init = [t.snapshot() for t in ts]
     out = {}
     meta = dict(kind="game", n=n, policy=policy, seed=seed, tables=tables, steps=steps,
-                table_id_base=table_id_base, cfg=cfg)
+                table_id_base=table_id_base, cfg=cfg, auto_reset=auto_reset)
     actions = np.zeros((steps, tables), np.int8)
     flags = np.zeros((steps, tables), np.uint8)
+    errs = np.zeros((steps, tables), np.uint8)
     post, resets, reset_idx, digests = [], [], [], []
     for s in range(steps):
         row = []
         for i, t in enumerate(ts):
             a = t.pick(policy)
-            over, hand, turn = t.game.step(int(a))
             actions[s, i] = a
-            flags[s, i] = int(bool(over)) | int(bool(hand)) << 1 | int(bool(turn)) << 2
+            try:
+                over, hand, turn = t.game.step(int(a))
+                flags[s, i] = int(bool(over)) | int(bool(hand)) << 1 | int(bool(turn)) << 2
+            except AssertionError:
+                assert not auto_reset
+                errs[s, i] = 2
             row.append(t.snapshot())
         if full:
             post.append(row)
         if digest_every and (s + 1) % digest_every == 0:
             digests.append(snap_digest(row))
         for i, t in enumerate(ts):  # auto-reset finished games, as bench/rollout do
-            if flags[s, i] & 1:
+            if (flags[s, i] & 1 and auto_reset) or errs[s, i]:
                 t.game.reset()
                 if full:
                     resets.append(t.snapshot())
                     reset_idx.append((s, i))
-    out["actions"], out["flags"] = actions, flags
+    out["actions"], out["flags"], out["errs"] = actions, flags, errs
     out.update(_stack(init, "init_"))
     if full:
         flat = [sn for row in post for sn in row]
@@ -374,6 +383,10 @@ GAME_SETS = {
                            dict(start_credits=[30, 100, 5], big_blind=4, small_blind=2)),
     "game_n10_random": (10, R.POLICY_RANDOM, 99, 4, 150, 5, None),
 }
+NORESET_SETS = {
+    "game_n2_noreset": (2, R.POLICY_RANDOM, 11, 6, 150, 0, None),
+    "game_n3_noreset": (3, R.POLICY_RANDOM, 12, 6, 200, 0, dict(start_credits=20, big_blind=2, small_blind=1)),
+}
 DIGEST_SETS = {
     # long runs pinned by sha256 digests only (every 100 steps)
     "digest_n2_random": (2, R.POLICY_RANDOM, SEED, 64, 2000, 0, None),
@@ -409,6 +422,11 @@ def main():
             out = game_trajectory(n, pol, seed, tables, steps, base, cfg)
             np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
             print(name, "resets:", len(out["reset_idx"]), "hands:", int(out["post_hand_serial"].max()))
+    for name, (n, pol, seed, tables, steps, base, cfg) in NORESET_SETS.items():
+        if want(name):
+            out = game_trajectory(n, pol, seed, tables, steps, base, cfg, auto_reset=False)
+            np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+            print(name, "assertion errors:", int((out["errs"] != 0).sum()), "game-over steps:", int((out["flags"] & 1).sum()))
     for name, (n, pol, seed, tables, steps, base, cfg) in DIGEST_SETS.items():
         if want(name):
             out = game_trajectory(n, pol, seed, tables, steps, base, cfg, full=False, digest_every=100)

@@ -69,10 +69,12 @@ def replay_game(make_backend, name):
         picked = b.pick_actions(meta["policy"])
         assert np.array_equal(picked, acts), "%s step %d: agent actions differ %s vs %s" % (name, s, picked, acts)
         flags, err = b.step(acts)
-        assert not err.any(), "%s step %d: err %s" % (name, s, err)
-        assert np.array_equal(flags, z["flags"][s]), "%s step %d: flags %s vs %s" % (name, s, flags, z["flags"][s])
+        assert np.array_equal(err, z["errs"][s]), "%s step %d: err %s vs %s" % (name, s, err, z["errs"][s])
+        ok = err == 0
+        assert np.array_equal(flags[ok], z["flags"][s][ok]), "%s step %d: flags %s vs %s" % (name, s, flags, z["flags"][s])
         assert_snap(b.snapshot(), gold_snap(z, "post_", s), "%s step %d" % (name, s))
-        over = (flags & 1).astype(np.uint8)
+        over = ((flags & 1) if meta.get("auto_reset", True) else np.zeros_like(flags)).astype(np.uint8)
+        over[err != 0] = 1
         if over.any():
             b.reset(mask=over)
             snap = b.snapshot()
@@ -146,6 +148,6 @@ def replay_env(make_backend, name):
 
 
 GAME_SETS = ["game_n2_random", "game_n6_random", "game_n9_random", "game_n6_allin", "game_n9_allin",
-             "game_n4_example_cfg", "game_n3_percredits", "game_n10_random"]
+             "game_n4_example_cfg", "game_n3_percredits", "game_n10_random", "game_n2_noreset", "game_n3_noreset"]
 DIGEST_SETS = ["digest_n2_random", "digest_n6_random", "digest_n9_random", "digest_n9_allin", "digest_n6_shard1"]
 ENV_SETS = ["env_n4_random", "env_n6_random", "env_n6_vs_allin", "env_n2_random"]

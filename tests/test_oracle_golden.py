@@ -40,10 +40,10 @@ def test_deck_spec_c_vs_python():
         perm = R.deck_permutation(seed, tid, hs)
         assert sorted(perm) == list(range(52))
         assert [canon[i] for i in perm] == out.tolist()
-        # the prefix the device computes (5+2N swaps) equals the full shuffle's prefix
+        # the prefix the device computes (5+2N draws) equals the full deck's prefix
         for n in (2, 6, 9):
             k = 5 + 2 * n
-            assert R.deck_permutation(seed, tid, hs, nsteps=k)[:k] == perm[:k]
+            assert R.deck_permutation(seed, tid, hs, ndraws=k)[:k] == perm[:k]
 
 
 def test_np_sum_order_matches_numpy():
@@ -108,3 +108,23 @@ def test_invalid_action_leaves_state_untouched():
     after = g.snapshot()
     for k in GU.SNAP_FIELDS:
         assert GU.bits_equal(before[k], after[k])
+
+
+def test_eval7_exhaustive_digest_vs_reference():
+    """All C(52,7) hands: the C oracle reproduces the digest computed from the imported reference
+    (tests/golden/eval7_digest.json, made by tests/golden/make_eval_digest.py)."""
+    from concurrent.futures import ThreadPoolExecutor
+    gold = GU.load_json("eval7_digest")
+    O.lib()
+    chunks = [(0, 2), (2, 4), (4, 7), (7, 11), (11, 16), (16, 24), (24, 52)]
+    with ThreadPoolExecutor(len(chunks)) as ex:  # ctypes releases the GIL
+        parts = list(ex.map(lambda c: O.eval7_digest(*c), chunks))
+    per_first = np.zeros(52, np.uint64)
+    counts = np.zeros(11, np.uint64)
+    for pf, c in parts:
+        per_first += pf
+        counts += c
+    assert int(counts.sum()) == gold["hands"]
+    assert counts.tolist() == gold["category_counts"]
+    assert ["%016x" % int(x) for x in per_first] == gold["per_first_card"]
+    assert "%016x" % (int(per_first.astype(object).sum()) % (1 << 64)) == gold["digest"]
