@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the hot path: env-steps/s (+ showdown hand-evals/s) of random-agent 6-max NLHE,
+65 536 tables per MI355X (BASELINE.json configs[2]; N GPUs = configs[3] weak scaling, 65 536 tables per GPU).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one lockstep pass of the hot path over the whole batch: one Game.step() on every table (T env-steps).
+Table state is resident in HBM before the timed region starts; agents run in-kernel (Philox), finished games
+auto-reset.  Rank 0 prints ONE JSON line.  torch is used only for torch.distributed (barrier / max / sum across the
+one-process-per-GPU ranks); the product path itself is plain HIP behind a ctypes C ABI.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md: 8.0 TB/s)
+
+
+def b_step(n):
+    """Algorithmic bytes per env-step: read + write the table state once, plus action in and
+    mask/flags out: 2*(35N+21)+16 -> 478 B at N=6."""
+    return 2 * (35 * n + 21) + 16
+
+
+class DistContext:
+    """One process per GPU.  Barrier, MAX of the timed seconds over ranks, SUM of the units all ranks processed."""
+
+    def __init__(self, backend=None):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.dist = None
+        self.device = None
+        if self.world > 1:
+            import torch
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if backend is None:
+                backend = "nccl" if torch.cuda.is_available() else "gloo"
+            if backend == "nccl":
+                torch.cuda.set_device(self.local_rank)
+                self.device = torch.device("cuda", self.local_rank)
+                dist.init_process_group("nccl", device_id=self.device)   # "nccl" is RCCL on ROCm
+            else:
+                dist.init_process_group("gloo")
+            self.dist = dist
+            self.torch = torch
+
+    def barrier(self):
+        if self.dist is not None:
+            if self.device is not None:
+                t = self.torch.zeros(1, device=self.device)
+                self.dist.all_reduce(t)
+                self.torch.cuda.synchronize()
+            else:
+                self.dist.barrier()
+
+    def aggregate(self, local_units, local_seconds):
+        """(sum of units over ranks, max of seconds over ranks)."""
+        if self.dist is None:
+            return local_units, local_seconds
+        torch, dist = self.torch, self.dist
+        dev = self.device if self.device is not None else "cpu"
+        u = torch.tensor([float(local_units)], dtype=torch.float64, device=dev)
+        s = torch.tensor([float(local_seconds)], dtype=torch.float64, device=dev)
+        dist.all_reduce(u, op=dist.ReduceOp.SUM)
+        dist.all_reduce(s, op=dist.ReduceOp.MAX)
+        return int(round(u.item())), s.item()
+
+    def sum_list(self, values):
+        if self.dist is None:
+            return list(values)
+        torch, dist = self.torch, self.dist
+        dev = self.device if self.device is not None else "cpu"
+        v = torch.tensor([float(x) for x in values], dtype=torch.float64, device=dev)
+        dist.all_reduce(v, op=dist.ReduceOp.SUM)
+        return [int(round(x)) for x in v.tolist()]
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.destroy_process_group()
+
+
+def shard(total_tables, ctx):
+    from pokerl_amd import shard_tables
+    return shard_tables(total_tables, ctx.rank, ctx.world)
+
+
+def cpu_baseline(n_players, policy, budget_s=12.0):
+    """The scalar C oracle (bit-exact restatement of the reference) timed on ONE host core on a bounded sample of the
+    same workload.  Reported beside the GPU number; it is not the target (the roofline fraction is)."""
+    import numpy as np
+    from oracle import loader as O
+    tables, chunk = 2048, 50
+    g = O.OracleGame(tables, n_players)
+    g.reset()
+    g.rollout(chunk, policy, True)  # warm
+    steps = 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        c, _ = g.rollout(chunk, policy, True)
+        steps += int(c[0])
+    dt = time.perf_counter() - t0
+    return dict(value=steps / dt, unit="env-steps/s", cores=1, kind="port",
+                sample="%d tables x %d lockstep steps, random agents, N=%d, oracle/pokerl_oracle.c single thread"
+                       % (tables, steps // tables, n_players))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4096)
+    ap.add_argument("--warmup", type=int, default=512)
+    ap.add_argument("--tables", type=int, default=65536, help="tables per GPU (weak scaling)")
+    ap.add_argument("--players", type=int, default=6)
+    ap.add_argument("--policy", choices=["random", "allin"], default="random")
+    ap.add_argument("--chunk", type=int, default=512, help="steps per fused launch")
+    ap.add_argument("--unfused", action="store_true", help="one launch per step (state round-trips HBM every step)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    ctx = DistContext()
+    if ctx.world != max(1, args.gpus) and ctx.rank == 0:
+        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, ctx.world), file=sys.stderr)
+    import pokerl_amd
+    policy = 0 if args.policy == "random" else 1
+    total_tables = args.tables * ctx.world
+    n_local, base = shard(total_tables, ctx)
+    game = pokerl_amd.VecGame(n_local, num_players=args.players, device=ctx.local_rank, table_id_base=base)
+    game.reset()
+    fused = not args.unfused
+
+    def run(steps):
+        done = 0
+        while done < steps:
+            k = min(args.chunk, steps - done)
+            game.rollout(k, policy, True, fused, counters=False)
+            done += k
+
+    run(args.warmup)
+    game.rollout(0, policy, True, fused, counters=True)  # drain + zero the device counters
+    ctx.barrier(); game.sync()
+    t0 = time.perf_counter()
+    run(args.steps)
+    game.sync(); ctx.barrier()
+    dt = time.perf_counter() - t0
+    c = game.rollout(0, policy, True, fused, counters=True)
+    assert c["steps"] == n_local * args.steps, (c, n_local, args.steps)
+    total_steps, seconds = ctx.aggregate(c["steps"], dt)
+    hands, evals, games = ctx.sum_list([c["hands"], c["evals"], c["games"]])
+
+    # roofline leg (rank 0): HIP events on the handle's own stream around back-to-back launches of the dominant kernel
+    kern_steps = min(args.chunk, max(1, args.steps)) if fused else 1
+    reps = max(1, min(8, args.steps // max(1, kern_steps)))
+    ms_launch, _ = game.time_rollout(kern_steps * (1 if fused else reps), policy, True, fused, reps if fused else 1)
+    ctx.barrier()
+    if ctx.rank == 0:
+        alg_bytes = b_step(args.players) * n_local * kern_steps
+        achieved = alg_bytes / (ms_launch * 1e-3) / 1e9
+        out = {
+            "metric": "env-steps/sec (whole node) + showdown hand-evals/sec, 65 536 tables 6-max",
+            "value": total_steps / seconds, "unit": "env-steps/s", "n_gpus": ctx.world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": seconds / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%d tables/GPU x %d GPU(s), num_players=%d, %s agents in-kernel (Philox4x32-10), "
+                                   "start_credits=100 blinds 1/2, auto-reset; BASELINE configs[%d]"
+                                   % (args.tables, ctx.world, args.players, args.policy, 2 if ctx.world == 1 else 3),
+                       "tables_per_gpu": args.tables, "num_players": args.players, "policy": args.policy,
+                       "kernel": "k_rollout (fused, %d steps/launch)" % kern_steps if fused else "k_rollout (1 step/launch)",
+                       "parallelism": "env-parallel, %d shard(s), no collective on the step path" % ctx.world},
+            "hand_evals_per_s": evals / seconds, "hands_per_s": hands / seconds, "games_per_s": games / seconds,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel_ms": ms_launch, "algorithmic_bytes_per_launch": alg_bytes,
+                         "note": "algorithmic bytes = (2*(35N+21)+16) B/env-step x tables x steps per launch (SURVEY 8d)"},
+        }
+        if not args.no_cpu_baseline and ctx.world == 1:
+            out["cpu_baseline"] = cpu_baseline(args.players, policy)
+        print(json.dumps(out))
+    game.close()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,12 @@
+"""pokerl_amd -- MI355X-native vectorised No-Limit Hold'em hot path (drop-in for sneppy/pokerl's
+Game.step/reset, judger and PokerGameEnv.step over thousands of tables).  HIP kernels behind a ctypes C ABI."""
+from .enums import CardRank, CardSuit, HandRanking, PlayerState, PokerMoves, Policy
+from .game import VecGame
+from .envs import VecPokerGameEnv
+from .judger import compare_hands, compare_rankings, eval_hand, eval_hands
+from .sharding import shard_tables
+from ._lib import PokerlHipError, device_count
+
+__all__ = ['VecGame', 'VecPokerGameEnv', 'eval_hand', 'eval_hands', 'compare_rankings', 'compare_hands',
+           'shard_tables', 'HandRanking', 'PokerMoves', 'PlayerState', 'CardRank', 'CardSuit', 'Policy',
+           'PokerlHipError', 'device_count']

@@ -1,0 +1,95 @@
+"""ctypes binding of libpokerl_hip.so (C ABI: include/pokerl_hip.h).  There is NO CPU fallback: if the HIP library is
+missing or no MI355X is visible, calls raise."""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libpokerl_hip.so")
+
+PK_OK, PK_E_INVALID_ARG, PK_E_NO_DEVICE, PK_E_HIP, PK_E_OOM, PK_E_TABLE = 0, -1, -2, -3, -4, -5
+TERR_INVALID_ACTION, TERR_NO_WINNER, TERR_HAND_CAP = 1, 2, 4
+FLAG_GAME_OVER, FLAG_HAND_OVER, FLAG_TURN_OVER = 1, 2, 4
+F_CREDITS, F_BETS, F_PENDING_BETS, F_PAYOFFS = 0, 1, 2, 3
+(I_ACTIVE_PLAYER, I_TURN, I_DEALER_IDX, I_SMALL_BLIND_IDX, I_BIG_BLIND_IDX, I_HAND, I_HAND_SERIAL,
+ I_STEP_SERIAL) = range(8)
+NUM_COUNTERS = 4
+MIN_PLAYERS, MAX_PLAYERS = 2, 10
+
+# every symbol include/pokerl_hip.h declares (tests check the library exports each one)
+SYMBOLS = ["pk_abi_version", "pk_device_count", "pk_last_error", "pk_create", "pk_destroy", "pk_num_tables",
+           "pk_num_players", "pk_reset", "pk_step", "pk_step_d", "pk_get_valid_actions", "pk_get_f64",
+           "pk_get_min_raise", "pk_get_player_states", "pk_get_i32", "pk_get_cards", "pk_get_hand_ranks",
+           "pk_eval_hands", "pk_compare_rankings", "pk_eval7_prefix", "pk_pick_actions", "pk_rollout",
+           "pk_env_reset", "pk_env_step", "pk_get_obs", "pk_sync", "pk_time_rollout"]
+
+
+class PokerlHipError(RuntimeError):
+    pass
+
+
+_lib = None
+_vp = C.c_void_p
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PokerlHipError(
+            "%s not found: build it with `python -m pokerl_amd.build` (hipcc, gfx950). "
+            "pokerl_amd has no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    L.pk_abi_version.restype = C.c_int
+    L.pk_device_count.restype = C.c_int
+    L.pk_last_error.restype = C.c_char_p
+    L.pk_last_error.argtypes = [_vp]
+    L.pk_create.argtypes = [C.POINTER(_vp), C.c_int, C.c_int, C.c_int, _vp, C.c_double, C.c_double, C.c_double,
+                            C.c_int, C.c_uint64, C.c_uint32]
+    L.pk_destroy.argtypes = [_vp]
+    L.pk_num_tables.argtypes = [_vp]
+    L.pk_num_players.argtypes = [_vp]
+    L.pk_reset.argtypes = [_vp, _vp, C.c_int]
+    L.pk_step.argtypes = [_vp, _vp, _vp, _vp]
+    L.pk_step_d.argtypes = [_vp, _vp, _vp, _vp]
+    L.pk_get_valid_actions.argtypes = [_vp, _vp]
+    L.pk_get_f64.argtypes = [_vp, C.c_int, _vp]
+    L.pk_get_min_raise.argtypes = [_vp, _vp]
+    L.pk_get_player_states.argtypes = [_vp, _vp]
+    L.pk_get_i32.argtypes = [_vp, C.c_int, _vp]
+    L.pk_get_cards.argtypes = [_vp, _vp]
+    L.pk_get_hand_ranks.argtypes = [_vp, _vp, _vp]
+    L.pk_eval_hands.argtypes = [C.c_int, _vp, _vp, C.c_size_t, _vp, _vp, _vp]
+    L.pk_compare_rankings.argtypes = [C.c_int, _vp, _vp, C.c_int, C.c_size_t, _vp]
+    L.pk_eval7_prefix.argtypes = [C.c_int, C.c_int, C.c_int, _vp, C.POINTER(C.c_size_t)]
+    L.pk_pick_actions.argtypes = [_vp, C.c_int, _vp]
+    L.pk_rollout.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]
+    L.pk_env_reset.argtypes = [_vp, _vp, C.c_int]
+    L.pk_env_step.argtypes = [_vp, _vp, C.c_int, _vp, _vp, _vp, _vp]
+    L.pk_get_obs.argtypes = [_vp, _vp]
+    L.pk_sync.argtypes = [_vp]
+    L.pk_time_rollout.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), _vp]
+    for name in SYMBOLS:
+        if name != "pk_last_error":
+            getattr(L, name).restype = C.c_int
+    if L.pk_abi_version() != 1:
+        raise PokerlHipError("libpokerl_hip.so ABI version mismatch")
+    _lib = L
+    return L
+
+
+def ptr(a):
+    return None if a is None else a.ctypes.data_as(_vp)
+
+
+def check(rc, handle=None, allow_table_errors=False):
+    if rc == PK_OK or (allow_table_errors and rc == PK_E_TABLE):
+        return rc
+    msg = lib().pk_last_error(handle)
+    raise PokerlHipError("libpokerl_hip: error %d: %s" % (rc, msg.decode() if msg else "?"))
+
+
+def device_count():
+    return lib().pk_device_count()

@@ -1,0 +1,43 @@
+"""Builds libpokerl_hip.so (hand-written HIP, gfx950 only) in-tree with hipcc.  No torch, no JIT cache."""
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libpokerl_hip.so")
+SOURCES = ["pk_api.hip"]
+HEADERS = [os.path.join(CSRC, "pk_device.hpp"), os.path.join(os.path.dirname(HERE), "include", "pokerl_hip.h")]
+# -ffp-contract=off: numpy never fuses multiply-add, so neither may we (bit-exact f64 money).
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared",
+         "-fgpu-rdc=0" if False else "-Wall", "-Wno-unused-function"]
+
+
+def hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: libpokerl_hip.so cannot be built")
+    return exe
+
+
+def stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_lib(force=False, verbose=False):
+    if not force and not stale():
+        return LIB
+    cmd = [hipcc()] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    import sys
+    build_lib(force="--force" in sys.argv, verbose=True)

@@ -1,0 +1,784 @@
+// pk_api.hip -- kernels + C ABI (include/pokerl_hip.h) of libpokerl_hip.so.  gfx950 only; plain HIP runtime,
+// no torch types.  Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -shared -fPIC (see pokerl_amd/build.py).
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "pk_device.hpp"
+
+using namespace pk;
+
+// ================================================================================================ kernels
+// One table per lane.  Grid = ceil(T / block); block is a multiple of 64 (one or more whole wavefronts).
+
+__device__ __forceinline__ void wave_add_counters(const State &S, uint32_t steps, uint32_t hands, uint32_t evals, uint32_t games) {
+    // 64-wide butterfly reduction in registers, one atomic per wave and counter.
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        steps += __shfl_down(steps, off, 64); hands += __shfl_down(hands, off, 64);
+        evals += __shfl_down(evals, off, 64); games += __shfl_down(games, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (steps) atomicAdd(&S.counters[PK_C_STEPS], (unsigned long long)steps);
+        if (hands) atomicAdd(&S.counters[PK_C_HANDS], (unsigned long long)hands);
+        if (evals) atomicAdd(&S.counters[PK_C_EVALS], (unsigned long long)evals);
+        if (games) atomicAdd(&S.counters[PK_C_GAMES], (unsigned long long)games);
+    }
+}
+
+template <int N>
+__global__ void k_reset(State S, const uint8_t *mask, int dealer) {  // Game.reset, game.py:397-412
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= S.T) return;
+    if (mask && !mask[t]) return;
+    Table<N> tb;
+    tb.load(S, t);
+    tb.reset(S, S.table_id_base + (uint32_t)t, dealer);
+    tb.store(S, t);
+    double hb;
+    S.valid[t] = (uint8_t)tb.valid_mask(hb);
+    S.terr[t] = 0;
+}
+
+template <int N>
+__global__ void k_step(State S, const int32_t *actions, uint8_t *flags, uint8_t *terr) {  // Game.step, game.py:621-700
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= S.T) return;
+    Table<N> tb;
+    tb.load(S, t);
+    double high_bet;
+    uint32_t mask = tb.valid_mask(high_bet);                                       // :648
+    int action = actions[t];
+    if (action < 0 || action >= PK_NUM_MOVES || !((mask >> action) & 1)) {         // :649-651: no mutation
+        flags[t] = 0;
+        S.terr[t] = PK_TERR_INVALID_ACTION;
+        if (terr) terr[t] = PK_TERR_INVALID_ACTION;
+        return;
+    }
+    uint32_t fl = tb.step(S, t, S.table_id_base + (uint32_t)t, action, high_bet);
+    tb.store(S, t);
+    flags[t] = (uint8_t)fl;
+    S.valid[t] = (uint8_t)tb.valid_mask(high_bet);
+    S.terr[t] = (uint8_t)tb.terr;
+    if (terr) terr[t] = (uint8_t)tb.terr;
+}
+
+template <int N>
+__global__ void k_pick(State S, int policy, int32_t *actions) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= S.T) return;
+    actions[t] = pick_action(S, S.table_id_base + (uint32_t)t, S.step_serial[t], S.valid[t], policy);
+}
+
+// K lockstep steps, in-kernel agents, table state in registers for the whole launch (K == 1: the unfused form).
+template <int N>
+__global__ void k_rollout(State S, int K, int policy, int auto_reset) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t steps = 0, games = 0, hands = 0, evals = 0;
+    if (t < S.T) {
+        const uint32_t table_id = S.table_id_base + (uint32_t)t;
+        Table<N> tb;
+        tb.load(S, t);
+        const uint32_t hs0 = tb.hand_serial;
+        double high_bet;
+        uint32_t mask = tb.valid_mask(high_bet);
+        for (int k = 0; k < K; ++k) {
+            int action = pick_action(S, table_id, tb.step_serial, mask, policy);
+            tb.hands_this_step = 0;
+            uint32_t fl = tb.step(S, t, table_id, action, high_bet);
+            if (tb.terr) break;  // table keeps its (reference-identical) state; reported through terr
+            ++steps;
+            if (fl & PK_FLAG_GAME_OVER) {
+                ++games;
+                if (auto_reset) tb.reset(S, table_id, 0);
+            }
+            mask = tb.valid_mask(high_bet);
+        }
+        tb.store(S, t);
+        S.valid[t] = (uint8_t)mask;
+        S.terr[t] = (uint8_t)tb.terr;
+        hands = tb.hand_serial - hs0; evals = tb.evals;
+    }
+    wave_add_counters(S, steps, hands, evals, games);  // every lane of the wave takes part in the shuffles
+}
+
+// PokerGameEnv.reset, envs/game_env.py:20-29
+template <int N>
+__global__ void k_env_reset(State S, const uint8_t *mask, int opp_policy) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= S.T) return;
+    if (mask && !mask[t]) return;
+    const uint32_t table_id = S.table_id_base + (uint32_t)t;
+    Table<N> tb;
+    tb.load(S, t);
+    tb.reset(S, table_id, 0);                                                      // :23
+    double high_bet;
+    uint32_t vm = tb.valid_mask(high_bet);
+    while (tb.active != 0) {                                                       // :24
+        int action = pick_action(S, table_id, tb.step_serial, vm, opp_policy);     // :25
+        tb.hands_this_step = 0;
+        uint32_t fl = tb.step(S, t, table_id, action, high_bet);                   // :26
+        if (tb.terr) break;
+        if (fl & PK_FLAG_GAME_OVER) tb.reset(S, table_id, 0);                      // :27
+        vm = tb.valid_mask(high_bet);
+    }
+    tb.store(S, t);
+    S.valid[t] = (uint8_t)tb.valid_mask(high_bet);
+    S.terr[t] = (uint8_t)tb.terr;
+}
+
+// PokerGameEnv.step, envs/game_env.py:31-53
+template <int N>
+__global__ void k_env_step(State S, const int32_t *actions, int opp_policy, double *reward, uint8_t *done_out, uint8_t *hand_out, uint8_t *terr) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= S.T) return;
+    const uint32_t table_id = S.table_id_base + (uint32_t)t;
+    Table<N> tb;
+    tb.load(S, t);
+    double high_bet;
+    uint32_t vm = tb.valid_mask(high_bet);
+    int action = actions[t];
+    if (action < 0 || action >= PK_NUM_MOVES || !((vm >> action) & 1)) {
+        reward[t] = 0.0; done_out[t] = 0; hand_out[t] = 0;
+        S.terr[t] = PK_TERR_INVALID_ACTION; terr[t] = PK_TERR_INVALID_ACTION;
+        return;
+    }
+    double rew = 0.0;                                                              // :34
+    uint32_t fl = tb.step(S, t, table_id, action, high_bet);                       // :35
+    bool done = fl & PK_FLAG_GAME_OVER, hand = fl & PK_FLAG_HAND_OVER;
+    if (!tb.terr) {
+        if (done || ((tb.st_broken >> 0) & 1)) {                                   // :37-39
+            rew = tb.payoffs[0]; done = true; hand = true;
+        } else {
+            vm = tb.valid_mask(high_bet);
+            while (!hand && tb.active != 0) {                                      // :41-44
+                int a = pick_action(S, table_id, tb.step_serial, vm, opp_policy);
+                tb.hands_this_step = 0;
+                fl = tb.step(S, t, table_id, a, high_bet);
+                if (tb.terr) break;
+                done = fl & PK_FLAG_GAME_OVER; hand = fl & PK_FLAG_HAND_OVER;
+                vm = tb.valid_mask(high_bet);
+            }
+            if (hand) rew = tb.payoffs[0];                                         // :47
+            while (!tb.terr && !done && tb.active != 0) {                          // :49-52
+                int a = pick_action(S, table_id, tb.step_serial, vm, opp_policy);
+                tb.hands_this_step = 0;
+                fl = tb.step(S, t, table_id, a, high_bet);
+                if (tb.terr) break;
+                done = fl & PK_FLAG_GAME_OVER;
+                vm = tb.valid_mask(high_bet);
+            }
+        }
+    }
+    tb.store(S, t);
+    reward[t] = rew; done_out[t] = done; hand_out[t] = hand;                       // :53
+    S.valid[t] = (uint8_t)tb.valid_mask(high_bet);
+    S.terr[t] = (uint8_t)tb.terr; terr[t] = (uint8_t)tb.terr;
+}
+
+// ---- exports: device-side conversion from the SoA/bitmask layout to the reference's table-major arrays
+__global__ void k_export_f64(const double *src, int T, int N, double *out) {  // [N][T] -> [T][N]
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T * N) return;
+    int t = i / N, p = i - t * N;
+    out[i] = src[(size_t)p * T + t];
+}
+__global__ void k_export_states(const uint64_t *ss, int T, int N, uint8_t *out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T * N) return;
+    int t = i / N, p = i - t * N;
+    uint64_t s = ss[t];
+    uint8_t st = PS_FOLDED;
+    if ((s >> p) & 1) st = PS_ACTIVE;
+    if ((s >> (16 + p)) & 1) st = PS_CALLED;
+    if ((s >> (32 + p)) & 1) st = PS_ALL_IN;
+    if ((s >> (48 + p)) & 1) st = PS_BROKEN;
+    out[i] = st;
+}
+__global__ void k_export_i32(State S, int field, int32_t *out) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= S.T) return;
+    uint32_t cur = S.cursors[t];
+    int32_t v = 0;
+    switch (field) {
+        case PK_I_ACTIVE_PLAYER: v = cur & 0xf; break;
+        case PK_I_TURN: v = (cur >> 16) & 0xf; break;
+        case PK_I_DEALER_IDX: v = (cur >> 4) & 0xf; break;
+        case PK_I_SMALL_BLIND_IDX: v = (cur >> 8) & 0xf; break;
+        case PK_I_BIG_BLIND_IDX: v = (cur >> 12) & 0xf; break;
+        case PK_I_HAND: v = S.hand[t]; break;
+        case PK_I_HAND_SERIAL: v = (int32_t)S.hand_serial[t]; break;
+        case PK_I_STEP_SERIAL: v = (int32_t)S.step_serial[t]; break;
+    }
+    out[t] = v;
+}
+__global__ void k_export_cards(const uint32_t *cards, int T, int K, uint8_t *out) {  // [W][T] words -> [T][K] bytes
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T * K) return;
+    int t = i / K, c = i - t * K;
+    out[i] = (uint8_t)(cards[(size_t)(c >> 2) * T + t] >> (8 * (c & 3)));
+}
+__global__ void k_export_show(const uint32_t *show, int T, int N, uint8_t *rank, uint32_t *kick) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T * N) return;
+    int t = i / N, p = i - t * N;
+    uint32_t v = show[(size_t)p * T + t];
+    rank[i] = (uint8_t)(v >> 20);
+    kick[i] = v & 0xFFFFF;
+}
+__global__ void k_export_valid(const uint8_t *valid, int T, uint8_t *out) {  // bitmask -> one-hot [T][7]
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T * PK_NUM_MOVES) return;
+    int t = i / PK_NUM_MOVES, a = i - t * PK_NUM_MOVES;
+    out[i] = (valid[t] >> a) & 1;
+}
+// Game.StateView(active player), game.py:117-131, as one dense f64 row per table (layout: pokerl_hip.h PK_OBS_DIM).
+__global__ void k_obs(State S, int N, double *out) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= S.T) return;
+    const int T = S.T, D = PK_OBS_DIM(N);
+    double *o = out + (size_t)t * D;
+    uint32_t cur = S.cursors[t];
+    int active = cur & 0xf, turn = (cur >> 16) & 0xf;
+    auto card = [&](int c) { return (double)((S.cards[(size_t)(c >> 2) * T + t] >> (8 * (c & 3))) & 0xff); };
+    o[0] = active; o[1] = turn; o[2] = S.min_raise[t];
+    for (int a = 0; a < PK_NUM_MOVES; ++a) o[3 + a] = (S.valid[t] >> a) & 1;
+    o[10] = card(5 + 2 * active); o[11] = card(6 + 2 * active);                    // game.py:385-389
+    for (int c = 0; c < 5; ++c) o[12 + c] = (turn != 0 && c < turn + 2) ? card(c) : -1.0;  // game.py:278
+    for (int p = 0; p < N; ++p) {
+        o[17 + p] = S.credits[(size_t)p * T + t];
+        o[17 + N + p] = S.bets[(size_t)p * T + t];
+        o[17 + 2 * N + p] = S.pending[(size_t)p * T + t];
+    }
+}
+
+// pokerl.judger.eval_hand batched: one hand per lane, cards[M][7] bytes
+__global__ void k_eval_hands(const uint8_t *cards, const uint8_t *ncards, size_t m, uint8_t *rank, uint32_t *kick, uint8_t *nkick) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    uint32_t c[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) c[j] = cards[i * 7 + j];
+    int n = ncards ? ncards[i] : 7;
+    n = n < 0 ? 0 : (n > 7 ? 7 : n);
+    int nk;
+    uint32_t v = eval_hand(c, n, nk);
+    rank[i] = (uint8_t)(v >> 20);
+    kick[i] = v & 0xFFFFF;
+    if (nkick) nkick[i] = (uint8_t)nk;
+}
+// pokerl.judger.compare_rankings batched: one list of n rankings per lane (judger.py:111-158)
+__global__ void k_compare(const uint8_t *rank, const uint32_t *kick, int n, size_t m, uint8_t *onehot) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    uint32_t best_rank = HR_NONE, best_kicker = 0, win = 0;
+    for (int p = 0; p < n; ++p) {
+        uint32_t r = rank[i * n + p], k = kick[i * n + p];
+        if (r < best_rank) { best_rank = r; best_kicker = k; win = 1u << p; }
+        else if (r == best_rank) {
+            if (k > best_kicker) win = 1u << p;  // line 148: best_kicker is not raised
+            else if (k == best_kicker) win |= 1u << p;
+        }
+    }
+    for (int p = 0; p < n; ++p) onehot[i * n + p] = (win >> p) & 1;
+}
+// Exhaustive 7-card sweep used by tests (digest definition: tests/golden/make_eval_digest.py): all hands with prefix
+// (a, b); hand index within the prefix -> combination of 5 from the cards above b is decoded per lane.
+__global__ void k_eval7_prefix(int a, int b, uint32_t count, uint32_t *out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    // unrank i among 5-subsets of {b+1..51} in lexicographic order
+    int n = 51 - b;  // pool size
+    int sel5[5];
+    uint32_t r = i;
+    int start = 0;
+    for (int k = 5; k >= 1; --k) {
+        for (int x = start;; ++x) {
+            // C(n - x - 1, k - 1) hands start with element x
+            uint32_t cnt = 1;
+            int top = n - x - 1;
+            if (top < k - 1) cnt = 0;
+            else for (int j = 0; j < k - 1; ++j) cnt = cnt * (uint32_t)(top - j) / (uint32_t)(j + 1);
+            if (r < cnt) { sel5[5 - k] = x; start = x + 1; break; }
+            r -= cnt;
+        }
+    }
+    auto canon = [](int c) { return (uint32_t)(((c % 4) << 4) | (c / 4)); };
+    uint32_t h[7] = {canon(a), canon(b), canon(b + 1 + sel5[0]), canon(b + 1 + sel5[1]), canon(b + 1 + sel5[2]),
+                     canon(b + 1 + sel5[3]), canon(b + 1 + sel5[4])};
+    int nk;
+    out[i] = eval_hand(h, 7, nk);
+}
+
+// ================================================================================================ host side
+static thread_local std::string g_err;
+
+struct pk_handle {
+    int device = 0, T = 0, N = 0, Tpad = 0, block = 64, dealer = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    State S{};
+    void *arena = nullptr;
+    // staging (device)
+    int32_t *d_actions = nullptr;
+    uint8_t *d_flags = nullptr, *d_terr = nullptr, *d_mask = nullptr, *d_done = nullptr, *d_handf = nullptr;
+    double *d_reward = nullptr;
+    void *d_export = nullptr;
+    size_t export_bytes = 0;
+    std::string err;
+    int fail(int code, const char *what, hipError_t e = hipSuccess) {
+        err = what;
+        if (e != hipSuccess) { err += ": "; err += hipGetErrorString(e); }
+        g_err = err;
+        return code;
+    }
+};
+
+#define HIPCHK(h, call)                                            \
+    do {                                                           \
+        hipError_t e_ = (call);                                    \
+        if (e_ != hipSuccess) return (h)->fail(PK_E_HIP, #call, e_); \
+    } while (0)
+
+#define DISPATCH_N(h, KERNEL, grid, ...)                                                                         \
+    do {                                                                                                         \
+        dim3 g_((grid)), b_((h)->block);                                                                         \
+        switch ((h)->N) {                                                                                        \
+            case 2: hipLaunchKernelGGL(KERNEL<2>, g_, b_, 0, (h)->stream, __VA_ARGS__); break;                   \
+            case 3: hipLaunchKernelGGL(KERNEL<3>, g_, b_, 0, (h)->stream, __VA_ARGS__); break;                   \
+            case 4: hipLaunchKernelGGL(KERNEL<4>, g_, b_, 0, (h)->stream, __VA_ARGS__); break;                   \
+            case 5: hipLaunchKernelGGL(KERNEL<5>, g_, b_, 0, (h)->stream, __VA_ARGS__); break;                   \
+            case 6: hipLaunchKernelGGL(KERNEL<6>, g_, b_, 0, (h)->stream, __VA_ARGS__); break;                   \
+            case 7: hipLaunchKernelGGL(KERNEL<7>, g_, b_, 0, (h)->stream, __VA_ARGS__); break;                   \
+            case 8: hipLaunchKernelGGL(KERNEL<8>, g_, b_, 0, (h)->stream, __VA_ARGS__); break;                   \
+            case 9: hipLaunchKernelGGL(KERNEL<9>, g_, b_, 0, (h)->stream, __VA_ARGS__); break;                   \
+            case 10: hipLaunchKernelGGL(KERNEL<10>, g_, b_, 0, (h)->stream, __VA_ARGS__); break;                 \
+        }                                                                                                        \
+    } while (0)
+
+static inline int table_grid(const pk_handle *h) { return (h->T + h->block - 1) / h->block; }
+static inline int flat_grid(size_t n) { return (int)((n + 255) / 256); }
+
+template <typename F>
+static int export_to_host(pk_handle *h, void *out, size_t bytes, F launch) {
+    HIPCHK(h, hipSetDevice(h->device));
+    if (bytes > h->export_bytes) return h->fail(PK_E_INVALID_ARG, "export buffer too small");
+    launch();
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(out, h->d_export, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return PK_OK;
+}
+
+extern "C" {
+
+int pk_abi_version(void) { return PK_ABI_VERSION; }
+
+int pk_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char *pk_last_error(const pk_handle *h) { return h ? h->err.c_str() : g_err.c_str(); }
+
+int pk_create(pk_handle **out, int device, int num_tables, int num_players, const double *start_credits,
+              double start_credit_scalar, double big_blind, double small_blind, int dealer, uint64_t seed,
+              uint32_t table_id_base) {
+    if (!out) { g_err = "pk_create: out is NULL"; return PK_E_INVALID_ARG; }
+    *out = nullptr;
+    if (num_tables < 1 || num_players < PK_MIN_PLAYERS || num_players > PK_MAX_PLAYERS) {
+        g_err = "pk_create: need num_tables >= 1 and 2 <= num_players <= 10";
+        return PK_E_INVALID_ARG;
+    }
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        g_err = std::string("pk_create: no HIP device available (") + (e != hipSuccess ? hipGetErrorString(e) : "0 devices") +
+                "); this library has no CPU fallback";
+        return PK_E_NO_DEVICE;
+    }
+    if (device < 0 || device >= ndev) { g_err = "pk_create: device index out of range"; return PK_E_INVALID_ARG; }
+    pk_handle *h = new pk_handle();
+    h->device = device; h->T = num_tables; h->N = num_players; h->dealer = dealer;
+    const char *bs = getenv("PK_BLOCK");
+    if (bs) { int b = atoi(bs); if (b == 64 || b == 128 || b == 256 || b == 512) h->block = b; }
+    auto bail = [&](int code) { g_err = h->err; pk_destroy(h); return code; };
+    if (hipSetDevice(device) != hipSuccess) return bail(h->fail(PK_E_HIP, "hipSetDevice"));
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return bail(h->fail(PK_E_HIP, "hipStreamCreate"));
+    if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) return bail(h->fail(PK_E_HIP, "hipEventCreate"));
+
+    const size_t T = (size_t)num_tables, N = (size_t)num_players;
+    const size_t K = 5 + 2 * N, W = (K + 3) / 4;
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    size_t obs = (size_t)PK_OBS_DIM(N) * 8;
+    h->export_bytes = al(T * (obs > N * 8 ? obs : N * 8));
+    size_t total = 4 * al(T * N * 8) + al(T * 8) + al(T * 8) + 4 * al(T * 4) + al(W * T * 4) + al(N * T * 4) + 2 * al(T) +
+                   al(PK_NUM_COUNTERS * 8) + al(T * 4) + 5 * al(T) + al(T * 8) + h->export_bytes;
+    e = hipMalloc(&h->arena, total);
+    if (e != hipSuccess) return bail(h->fail(PK_E_OOM, "hipMalloc(table state)", e));
+    if (hipMemsetAsync(h->arena, 0, total, h->stream) != hipSuccess) return bail(h->fail(PK_E_HIP, "hipMemset"));
+    char *p = (char *)h->arena;
+    auto take = [&](size_t bytes) { void *r = p; p += al(bytes); return r; };
+    State &S = h->S;
+    S.credits = (double *)take(T * N * 8); S.bets = (double *)take(T * N * 8);
+    S.pending = (double *)take(T * N * 8); S.payoffs = (double *)take(T * N * 8);
+    S.min_raise = (double *)take(T * 8);
+    S.seat_states = (uint64_t *)take(T * 8);
+    S.cursors = (uint32_t *)take(T * 4); S.hand = (int32_t *)take(T * 4);
+    S.hand_serial = (uint32_t *)take(T * 4); S.step_serial = (uint32_t *)take(T * 4);
+    S.cards = (uint32_t *)take(W * T * 4);
+    S.show = (uint32_t *)take(N * T * 4);
+    S.valid = (uint8_t *)take(T); S.terr = (uint8_t *)take(T);
+    S.counters = (unsigned long long *)take(PK_NUM_COUNTERS * 8);
+    h->d_actions = (int32_t *)take(T * 4);
+    h->d_flags = (uint8_t *)take(T); h->d_terr = (uint8_t *)take(T); h->d_mask = (uint8_t *)take(T);
+    h->d_done = (uint8_t *)take(T); h->d_handf = (uint8_t *)take(T);
+    h->d_reward = (double *)take(T * 8);
+    h->d_export = take(h->export_bytes);
+    for (int i = 0; i < PK_MAX_PLAYERS; ++i)
+        S.start_credits[i] = i < num_players ? (start_credits ? start_credits[i] : start_credit_scalar) : 0.0;
+    S.big_blind = big_blind; S.small_blind = small_blind;
+    S.key0 = (uint32_t)seed; S.key1 = (uint32_t)(seed >> 32);
+    S.table_id_base = table_id_base; S.T = num_tables;
+
+    // Game.__init__ (game.py:242-264): every seat ACTIVE, dealer cursor = config dealer, credits 0, ranks NONE.
+    {
+        std::vector<uint64_t> ss(T, (uint64_t)((1u << num_players) - 1));
+        int d = ((dealer % num_players) + num_players) % num_players;
+        std::vector<uint32_t> cur(T, (uint32_t)d << 4);
+        std::vector<uint32_t> show(N * T, NONE_V);
+        std::vector<uint8_t> valid(T, 0x7f);  // all credits/pending 0: FOLD, CHECK, ALL_IN valid; literal value set below
+        // literal get_valid_actions on the zero state: raises invalid (0 > 0 false), CHECK valid (high_bet == 0),
+        // CALL invalid (0 < 0 false) -> FOLD|CHECK|ALL_IN
+        for (auto &v : valid) v = (1u << MV_FOLD) | (1u << MV_CHECK) | (1u << MV_ALL_IN);
+        if (hipMemcpyAsync(S.seat_states, ss.data(), T * 8, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+            hipMemcpyAsync(S.cursors, cur.data(), T * 4, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+            hipMemcpyAsync(S.show, show.data(), N * T * 4, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+            hipMemcpyAsync(S.valid, valid.data(), T, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+            hipStreamSynchronize(h->stream) != hipSuccess)
+            return bail(h->fail(PK_E_HIP, "initial state upload"));
+    }
+    *out = h;
+    return PK_OK;
+}
+
+int pk_destroy(pk_handle *h) {
+    if (!h) return PK_OK;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->arena) (void)hipFree(h->arena);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return PK_OK;
+}
+
+int pk_num_tables(const pk_handle *h) { return h ? h->T : PK_E_INVALID_ARG; }
+int pk_num_players(const pk_handle *h) { return h ? h->N : PK_E_INVALID_ARG; }
+
+static int upload_mask(pk_handle *h, const uint8_t *mask, const uint8_t **dmask) {
+    *dmask = nullptr;
+    if (mask) {
+        HIPCHK(h, hipMemcpyAsync(h->d_mask, mask, (size_t)h->T, hipMemcpyHostToDevice, h->stream));
+        *dmask = h->d_mask;
+    }
+    return PK_OK;
+}
+
+int pk_reset(pk_handle *h, const uint8_t *mask, int dealer) {
+    if (!h) return PK_E_INVALID_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    const uint8_t *dmask;
+    int rc = upload_mask(h, mask, &dmask);
+    if (rc) return rc;
+    int d = ((dealer % h->N) + h->N) % h->N;
+    DISPATCH_N(h, k_reset, table_grid(h), h->S, dmask, d);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return PK_OK;
+}
+
+int pk_step_d(pk_handle *h, const int32_t *actions_d, uint8_t *flags_d, uint8_t *terr_d) {
+    if (!h || !actions_d || !flags_d) return h ? h->fail(PK_E_INVALID_ARG, "pk_step_d: NULL buffer") : PK_E_INVALID_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    DISPATCH_N(h, k_step, table_grid(h), h->S, actions_d, flags_d, terr_d);
+    HIPCHK(h, hipGetLastError());
+    return PK_OK;
+}
+
+static int any_terr(const uint8_t *terr, int T) {
+    for (int i = 0; i < T; ++i) if (terr[i]) return 1;
+    return 0;
+}
+
+int pk_step(pk_handle *h, const int32_t *actions, uint8_t *flags, uint8_t *terr) {
+    if (!h || !actions || !flags) return h ? h->fail(PK_E_INVALID_ARG, "pk_step: NULL buffer") : PK_E_INVALID_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t T = (size_t)h->T;
+    HIPCHK(h, hipMemcpyAsync(h->d_actions, actions, T * 4, hipMemcpyHostToDevice, h->stream));
+    int rc = pk_step_d(h, h->d_actions, h->d_flags, h->d_terr);
+    if (rc) return rc;
+    std::vector<uint8_t> te(T);
+    HIPCHK(h, hipMemcpyAsync(flags, h->d_flags, T, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(te.data(), h->d_terr, T, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (terr) memcpy(terr, te.data(), T);
+    if (any_terr(te.data(), h->T)) return h->fail(PK_E_TABLE, "pk_step: per-table error(s), see terr");
+    return PK_OK;
+}
+
+int pk_get_valid_actions(pk_handle *h, uint8_t *out) {
+    if (!h || !out) return PK_E_INVALID_ARG;
+    size_t n = (size_t)h->T * PK_NUM_MOVES;
+    return export_to_host(h, out, n, [&] {
+        hipLaunchKernelGGL(k_export_valid, dim3(flat_grid(n)), dim3(256), 0, h->stream, h->S.valid, h->T, (uint8_t *)h->d_export);
+    });
+}
+
+int pk_get_f64(pk_handle *h, int field, double *out) {
+    if (!h || !out || field < 0 || field > 3) return h ? h->fail(PK_E_INVALID_ARG, "pk_get_f64: bad field") : PK_E_INVALID_ARG;
+    const double *src = field == PK_F_CREDITS ? h->S.credits : field == PK_F_BETS ? h->S.bets : field == PK_F_PENDING_BETS ? h->S.pending : h->S.payoffs;
+    size_t n = (size_t)h->T * h->N;
+    return export_to_host(h, out, n * 8, [&] {
+        hipLaunchKernelGGL(k_export_f64, dim3(flat_grid(n)), dim3(256), 0, h->stream, src, h->T, h->N, (double *)h->d_export);
+    });
+}
+
+int pk_get_min_raise(pk_handle *h, double *out) {
+    if (!h || !out) return PK_E_INVALID_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemcpyAsync(out, h->S.min_raise, (size_t)h->T * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return PK_OK;
+}
+
+int pk_get_player_states(pk_handle *h, uint8_t *out) {
+    if (!h || !out) return PK_E_INVALID_ARG;
+    size_t n = (size_t)h->T * h->N;
+    return export_to_host(h, out, n, [&] {
+        hipLaunchKernelGGL(k_export_states, dim3(flat_grid(n)), dim3(256), 0, h->stream, h->S.seat_states, h->T, h->N, (uint8_t *)h->d_export);
+    });
+}
+
+int pk_get_i32(pk_handle *h, int field, int32_t *out) {
+    if (!h || !out || field < 0 || field > PK_I_STEP_SERIAL) return h ? h->fail(PK_E_INVALID_ARG, "pk_get_i32: bad field") : PK_E_INVALID_ARG;
+    return export_to_host(h, out, (size_t)h->T * 4, [&] {
+        hipLaunchKernelGGL(k_export_i32, dim3(flat_grid(h->T)), dim3(256), 0, h->stream, h->S, field, (int32_t *)h->d_export);
+    });
+}
+
+int pk_get_cards(pk_handle *h, uint8_t *out) {
+    if (!h || !out) return PK_E_INVALID_ARG;
+    int K = 5 + 2 * h->N;
+    size_t n = (size_t)h->T * K;
+    return export_to_host(h, out, n, [&] {
+        hipLaunchKernelGGL(k_export_cards, dim3(flat_grid(n)), dim3(256), 0, h->stream, h->S.cards, h->T, K, (uint8_t *)h->d_export);
+    });
+}
+
+int pk_get_hand_ranks(pk_handle *h, uint8_t *rank, uint32_t *kick) {
+    if (!h || !rank || !kick) return PK_E_INVALID_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    size_t n = (size_t)h->T * h->N;
+    uint32_t *dk = (uint32_t *)h->d_export;
+    uint8_t *dr = (uint8_t *)h->d_export + n * 4;
+    if (n * 5 > h->export_bytes) return h->fail(PK_E_INVALID_ARG, "export buffer too small");
+    hipLaunchKernelGGL(k_export_show, dim3(flat_grid(n)), dim3(256), 0, h->stream, h->S.show, h->T, h->N, dr, dk);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(kick, dk, n * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(rank, dr, n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return PK_OK;
+}
+
+int pk_get_obs(pk_handle *h, double *out) {
+    if (!h || !out) return PK_E_INVALID_ARG;
+    size_t bytes = (size_t)h->T * PK_OBS_DIM(h->N) * 8;
+    return export_to_host(h, out, bytes, [&] {
+        hipLaunchKernelGGL(k_obs, dim3(flat_grid(h->T)), dim3(256), 0, h->stream, h->S, h->N, (double *)h->d_export);
+    });
+}
+
+int pk_pick_actions(pk_handle *h, int policy, int32_t *actions) {
+    if (!h || !actions || policy < 0 || policy > 1) return h ? h->fail(PK_E_INVALID_ARG, "pk_pick_actions: bad argument") : PK_E_INVALID_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    DISPATCH_N(h, k_pick, table_grid(h), h->S, policy, h->d_actions);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(actions, h->d_actions, (size_t)h->T * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return PK_OK;
+}
+
+static int launch_rollout(pk_handle *h, int k_steps, int policy, int auto_reset, int fused) {
+    if (fused) {
+        DISPATCH_N(h, k_rollout, table_grid(h), h->S, k_steps, policy, auto_reset);
+    } else {
+        for (int k = 0; k < k_steps; ++k) DISPATCH_N(h, k_rollout, table_grid(h), h->S, 1, policy, auto_reset);
+    }
+    HIPCHK(h, hipGetLastError());
+    return PK_OK;
+}
+
+static int fetch_counters(pk_handle *h, uint64_t *counters) {
+    unsigned long long c[PK_NUM_COUNTERS];
+    HIPCHK(h, hipMemcpyAsync(c, h->S.counters, sizeof(c), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->S.counters, 0, sizeof(c), h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (int i = 0; i < PK_NUM_COUNTERS; ++i) counters[i] += c[i];
+    return PK_OK;
+}
+
+int pk_rollout(pk_handle *h, int k_steps, int policy, int auto_reset, int fused, uint64_t *counters) {
+    if (!h || k_steps < 0 || policy < 0 || policy > 1) return h ? h->fail(PK_E_INVALID_ARG, "pk_rollout: bad argument") : PK_E_INVALID_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = launch_rollout(h, k_steps, policy, auto_reset, fused);
+    if (rc) return rc;
+    if (counters) return fetch_counters(h, counters);
+    return PK_OK;
+}
+
+int pk_time_rollout(pk_handle *h, int k_steps, int policy, int auto_reset, int fused, int reps, double *ms_per_launch,
+                    uint64_t *counters) {
+    if (!h || !ms_per_launch || reps < 1) return h ? h->fail(PK_E_INVALID_ARG, "pk_time_rollout: bad argument") : PK_E_INVALID_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+    for (int r = 0; r < reps; ++r) {
+        int rc = launch_rollout(h, k_steps, policy, auto_reset, fused);
+        if (rc) return rc;
+    }
+    HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+    HIPCHK(h, hipEventSynchronize(h->ev1));
+    float ms = 0.f;
+    HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    int launches = reps * (fused ? 1 : k_steps);
+    *ms_per_launch = launches ? (double)ms / launches : 0.0;
+    if (counters) return fetch_counters(h, counters);
+    return PK_OK;
+}
+
+int pk_env_reset(pk_handle *h, const uint8_t *mask, int opp_policy) {
+    if (!h || opp_policy < 0 || opp_policy > 1) return h ? h->fail(PK_E_INVALID_ARG, "pk_env_reset: bad argument") : PK_E_INVALID_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    const uint8_t *dmask;
+    int rc = upload_mask(h, mask, &dmask);
+    if (rc) return rc;
+    DISPATCH_N(h, k_env_reset, table_grid(h), h->S, dmask, opp_policy);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return PK_OK;
+}
+
+int pk_env_step(pk_handle *h, const int32_t *actions, int opp_policy, double *reward, uint8_t *done, uint8_t *hand,
+                uint8_t *terr) {
+    if (!h || !actions || !reward || !done || !hand || opp_policy < 0 || opp_policy > 1)
+        return h ? h->fail(PK_E_INVALID_ARG, "pk_env_step: bad argument") : PK_E_INVALID_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t T = (size_t)h->T;
+    HIPCHK(h, hipMemcpyAsync(h->d_actions, actions, T * 4, hipMemcpyHostToDevice, h->stream));
+    DISPATCH_N(h, k_env_step, table_grid(h), h->S, (const int32_t *)h->d_actions, opp_policy, h->d_reward, h->d_done, h->d_handf, h->d_terr);
+    HIPCHK(h, hipGetLastError());
+    std::vector<uint8_t> te(T);
+    HIPCHK(h, hipMemcpyAsync(reward, h->d_reward, T * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(done, h->d_done, T, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(hand, h->d_handf, T, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(te.data(), h->d_terr, T, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (terr) memcpy(terr, te.data(), T);
+    if (any_terr(te.data(), h->T)) return h->fail(PK_E_TABLE, "pk_env_step: per-table error(s), see terr");
+    return PK_OK;
+}
+
+int pk_sync(pk_handle *h) {
+    if (!h) return PK_E_INVALID_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return PK_OK;
+}
+
+// ---- standalone judger ops (no handle)
+struct tmp_handle { std::string err; int fail(int code, const char *what, hipError_t e) { err = what; err += ": "; err += hipGetErrorString(e); g_err = err; return code; } };
+
+static int check_device(int device) {
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) { g_err = "no HIP device available; this library has no CPU fallback"; return PK_E_NO_DEVICE; }
+    if (device < 0 || device >= ndev) { g_err = "device index out of range"; return PK_E_INVALID_ARG; }
+    if (hipSetDevice(device) != hipSuccess) { g_err = "hipSetDevice failed"; return PK_E_HIP; }
+    return PK_OK;
+}
+
+int pk_eval_hands(int device, const uint8_t *cards, const uint8_t *ncards, size_t m, uint8_t *rank, uint32_t *kick,
+                  uint8_t *nkick) {
+    if (!cards || !rank || !kick) { g_err = "pk_eval_hands: NULL buffer"; return PK_E_INVALID_ARG; }
+    int rc = check_device(device);
+    if (rc) return rc;
+    if (m == 0) return PK_OK;
+    tmp_handle th, *h = &th;
+    uint8_t *d = nullptr;
+    size_t off_n = m * 7, off_r = off_n + m, off_nk = off_r + m, off_k = (off_nk + m + 3) & ~(size_t)3, total = off_k + m * 4;
+    HIPCHK(h, hipMalloc((void **)&d, total));
+    hipError_t e = hipMemcpy(d, cards, m * 7, hipMemcpyHostToDevice);
+    if (e == hipSuccess && ncards) e = hipMemcpy(d + off_n, ncards, m, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_eval_hands, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, 0, d, ncards ? d + off_n : nullptr, m,
+                           d + off_r, (uint32_t *)(d + off_k), d + off_nk);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(rank, d + off_r, m, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(kick, d + off_k, m * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && nkick) e = hipMemcpy(nkick, d + off_nk, m, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return th.fail(PK_E_HIP, "pk_eval_hands", e);
+    return PK_OK;
+}
+
+int pk_compare_rankings(int device, const uint8_t *rank, const uint32_t *kick, int n, size_t m, uint8_t *onehot) {
+    if (!rank || !kick || !onehot || n < 1 || n > 32) { g_err = "pk_compare_rankings: bad argument (1 <= n <= 32)"; return PK_E_INVALID_ARG; }
+    int rc = check_device(device);
+    if (rc) return rc;
+    if (m == 0) return PK_OK;
+    tmp_handle th, *h = &th;
+    size_t cnt = m * (size_t)n;
+    uint8_t *d = nullptr;
+    size_t off_r = cnt * 4, off_o = off_r + cnt, total = off_o + cnt;
+    HIPCHK(h, hipMalloc((void **)&d, total));
+    hipError_t e = hipMemcpy(d, kick, cnt * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d + off_r, rank, cnt, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_compare, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, 0, d + off_r, (const uint32_t *)d, n, m, d + off_o);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(onehot, d + off_o, cnt, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return th.fail(PK_E_HIP, "pk_compare_rankings", e);
+    return PK_OK;
+}
+
+// Test hook (declared in pokerl_hip.h as part of the judger surface): values rank<<20|kick of all 7-card hands whose
+// two lowest canonical indices are (a, b), lexicographic order.  out holds C(51-b, 5) words.
+int pk_eval7_prefix(int device, int a, int b, uint32_t *out, size_t *count_out) {
+    if (!out || a < 0 || b <= a || b > 51) { g_err = "pk_eval7_prefix: bad argument"; return PK_E_INVALID_ARG; }
+    int rc = check_device(device);
+    if (rc) return rc;
+    int n = 51 - b;
+    size_t count = n >= 5 ? (size_t)n * (n - 1) * (n - 2) * (n - 3) * (n - 4) / 120 : 0;
+    if (count_out) *count_out = count;
+    if (!count) return PK_OK;
+    tmp_handle th, *h = &th;
+    uint32_t *d = nullptr;
+    HIPCHK(h, hipMalloc((void **)&d, count * 4));
+    hipLaunchKernelGGL(k_eval7_prefix, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, 0, a, b, (uint32_t)count, d);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpy(out, d, count * 4, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return th.fail(PK_E_HIP, "pk_eval7_prefix", e);
+    return PK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,561 @@
+// pk_device.hpp -- gfx950 device code of the vectorised NLHE hot path: one table per lane, all per-table state in
+// VGPRs (compile-time-indexed arrays, seat states as bitmasks), money in IEEE binary64 in the reference's operation
+// order (translation unit is built with -ffp-contract=off).  Citations: paths relative to the reference root.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/pokerl_hip.h"
+
+namespace pk {
+
+// pokerl/enums.py:9-18, :104-114, :130-136
+enum : int { HR_SF = 1, HR_POKER = 2, HR_FULL = 3, HR_FLUSH = 4, HR_STRAIGHT = 5, HR_TRIS = 6, HR_TWO_PAIR = 7, HR_PAIR = 8, HR_HIGH = 9, HR_NONE = 10 };
+enum : int { MV_FOLD = 0, MV_CHECK = 1, MV_CALL = 2, MV_RAISE_ANY = 3, MV_ALL_IN = 6 };
+enum : int { PS_FOLDED = 0, PS_ACTIVE = 1, PS_CALLED = 2, PS_ALL_IN = 3, PS_BROKEN = 4 };
+constexpr uint32_t STREAM_DECK = 0x4445434Bu, STREAM_ACTION = 0x41435431u;
+constexpr uint32_t NONE_V = (uint32_t)HR_NONE << 20;  // ranking value (rank<<20 | kickers) of judger's (NONE, [])
+
+// ---------------------------------------------------------------------------------------------- HBM layout
+// Structure-of-arrays, seat-major: element (seat p, table t) of a per-seat array lives at [p*T + t], so the 64 lanes
+// of a wave (64 consecutive tables) touch 64 consecutive 8-byte (or 4-byte) words per load: fully coalesced.
+struct State {
+    double *credits, *bets, *pending, *payoffs;  // [N][T]   Game.credits/.bets/.pending_bets/.payoffs (game.py:260-264)
+    double *min_raise;                           // [T]      Game.minimum_raise_value (game.py:263)
+    uint64_t *seat_states;                       // [T]      ACTIVE | CALLED<<16 | ALL_IN<<32 | BROKEN<<48 seat bitmasks (FOLDED = in none)
+    uint32_t *cursors;                           // [T]      active | dealer<<4 | sb<<8 | bb<<12 | turn<<16 (game.py:251-258)
+    int32_t *hand;                               // [T]      Game.hand
+    uint32_t *hand_serial, *step_serial;         // [T]      RNG-spec counters
+    uint32_t *cards;                             // [W][T]   4 Card.value bytes per word, deck[0:5+2N] (game.py:385-395)
+    uint32_t *show;                              // [N][T]   last showdown: HandRanking<<20 | kickers value
+    uint8_t *valid;                              // [T]      valid-action bitmask of the active player (game.py:339-383)
+    uint8_t *terr;                               // [T]      PK_TERR_* of the last call
+    unsigned long long *counters;                // [PK_NUM_COUNTERS]
+    double start_credits[PK_MAX_PLAYERS];
+    double big_blind, small_blind;
+    uint32_t key0, key1, table_id_base;
+    int T;
+};
+
+// ---------------------------------------------------------------------------------------------- helpers
+template <int N>
+__device__ __forceinline__ double sel(const double (&a)[N], int i) {
+    double r = a[0];
+#pragma unroll
+    for (int p = 1; p < N; ++p) r = (i == p) ? a[p] : r;
+    return r;
+}
+template <int N>
+__device__ __forceinline__ void put(double (&a)[N], int i, double v) {
+#pragma unroll
+    for (int p = 0; p < N; ++p) a[p] = (i == p) ? v : a[p];
+}
+template <int N>
+__device__ __forceinline__ double vmax(const double (&a)[N]) {  // np.max
+    double m = a[0];
+#pragma unroll
+    for (int p = 1; p < N; ++p) m = (a[p] > m) ? a[p] : m;
+    return m;
+}
+// np.sum over contiguous f64[N] in numpy's association order: N<8 left to right;
+// 8<=N<16: ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) then the tail left to right.
+template <int N>
+__device__ __forceinline__ double np_sum(const double (&a)[N]) {
+    if constexpr (N < 8) {
+        double r = a[0];
+#pragma unroll
+        for (int p = 1; p < N; ++p) r = r + a[p];
+        return r;
+    } else {
+        static_assert(N < 16, "np_sum: second block of 8 not implemented");
+        double r = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+#pragma unroll
+        for (int p = 8; p < N; ++p) r = r + a[p];
+        return r;
+    }
+}
+
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// ---------------------------------------------------------------------------------------------- judger.eval_hand
+__device__ __forceinline__ void cex_desc(uint32_t &a, uint32_t &b) {  // compare-exchange, larger first
+    uint32_t hi = a > b ? a : b, lo = a > b ? b : a;
+    a = hi; b = lo;
+}
+__device__ __forceinline__ void sort7_desc(uint32_t (&k)[7]) {  // 16-comparator network (0/1-principle checked on host)
+    cex_desc(k[0], k[6]); cex_desc(k[2], k[3]); cex_desc(k[4], k[5]);
+    cex_desc(k[0], k[2]); cex_desc(k[1], k[4]); cex_desc(k[3], k[6]);
+    cex_desc(k[0], k[1]); cex_desc(k[2], k[5]); cex_desc(k[3], k[4]);
+    cex_desc(k[1], k[2]); cex_desc(k[4], k[6]);
+    cex_desc(k[2], k[3]); cex_desc(k[4], k[5]);
+    cex_desc(k[1], k[2]); cex_desc(k[3], k[4]); cex_desc(k[5], k[6]);
+}
+
+// General evaluator: 0..7 cards, multiset semantics, every quirk of pokerl/judger.py:7-99.
+// c[i] = Card.value ((suit<<4)|rank0, cards.py:28-62) for i < n.  Returns HandRanking<<20 | get_kickers_value(kickers)
+// (judger.py:101-109); nk = len(kickers).
+__device__ inline uint32_t eval_hand(const uint32_t (&c)[7], int n, int &nk) {
+    nk = 0;
+    if (n == 0) return NONE_V;                                                     // :30
+    uint32_t rk[7], sk[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        uint32_t r = c[i] & 0xf; r = r ? r : 13;                                   // cards.py:14
+        uint32_t s = (c[i] >> 4) & 3;                                              // cards.py:20
+        bool real = i < n;
+        rk[i] = real ? r : 0;                                                      // pads sort last (real keys >= 1)
+        sk[i] = real ? ((s << 4) | r) : 0;
+    }
+    if (n == 1) { nk = 1; return ((uint32_t)HR_HIGH << 20) | rk[0]; }             // :31
+    if (n == 2) {                                                                  // :32-35
+        if (rk[0] == rk[1]) { nk = 1; return ((uint32_t)HR_PAIR << 20) | rk[0]; }
+        uint32_t hi = rk[0] > rk[1] ? rk[0] : rk[1], lo = rk[0] > rk[1] ? rk[1] : rk[0];
+        nk = 2; return ((uint32_t)HR_HIGH << 20) | (hi << 4) | lo;
+    }
+    sort7_desc(rk);                                                                // :38 (ties: only .rank is read)
+    sort7_desc(sk);                                                                // :39 (keys of distinct cards differ; equal keys are identical)
+    uint32_t flush = 4, both = 4, kind = 0, straight = 0, flush_start = 0;         // :41-45
+    uint32_t two = 0, three = 0, four = 0, n2 = 0, n3 = 0, n4 = 0;                 // lists as nibbles, append order
+#pragma unroll
+    for (int idx = 0; idx < 7; ++idx) {                                            // :50
+        if (idx < n) {
+            uint32_t rr = rk[idx], sr = sk[idx] & 0xf, ss = sk[idx] >> 4;
+            if (ss == (flush & 0xf)) {                                             // :52
+                flush += 0x100;
+                if (sr + (both >> 8) == ((both >> 4) & 0xf)) both += 0x100;        // :56
+                else both = 0x100 | (sr << 4) | ss;                                // :57
+            } else if ((flush >> 8) < 5) { both = flush = 0x100 | (sr << 4) | ss; flush_start = idx; }  // :58
+            if (rr == (kind & 0xf)) kind += 0x10;                                  // :61
+            else {
+                uint32_t numakind = kind >> 4, kr = kind & 0xf;                    // :64-67
+                if (numakind == 2) { two |= kr << (4 * n2); ++n2; }
+                else if (numakind == 3) { three |= kr << (4 * n3); ++n3; }
+                else if (numakind == 4) { four |= kr << (4 * n4); ++n4; }
+                kind = 0x10 | rr;                                                  // :70
+                if (rr + (straight >> 4) == (straight & 0xf)) straight += 0x10;    // :71
+                else if ((straight >> 4) < 5) straight = 0x10 | rr;                // :72
+            }
+        }
+    }
+    {
+        uint32_t numakind = kind >> 4, kr = kind & 0xf;                            // :77-80
+        if (numakind == 2) { two |= kr << (4 * n2); ++n2; }
+        else if (numakind == 3) { three |= kr << (4 * n3); ++n3; }
+        else if (numakind == 4) { four |= kr << (4 * n4); ++n4; }
+    }
+    if ((both >> 8) == 4 && ((both >> 4) & 0xf) == 4) {                            // :83-85  (CardRank.FIVE == 4)
+        bool ace = false;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) ace = ace || (i < n && sk[i] == (((both & 0xf) << 4) | 13));
+        if (ace) { nk = 1; return ((uint32_t)HR_SF << 20) | 4; }
+    } else if ((straight >> 4) == 4 && (straight & 0xf) == 4) {                    // :86-88
+        if (rk[0] == 13) { nk = 1; return ((uint32_t)HR_STRAIGHT << 20) | 4; }     // any ace: it sorts first
+    }
+    auto others = [&](uint32_t ex0, uint32_t ex1, int count, uint32_t &kick, int &cnt) {
+        int k = 0;                                                                 // islice(... if c.rank != ex ..., count)
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            bool take = i < n && rk[i] != ex0 && rk[i] != ex1 && k < count;
+            kick = take ? ((kick << 4) | rk[i]) : kick;
+            k += take;
+        }
+        cnt += k;
+    };
+    uint32_t kick = 0;
+    if ((both >> 8) >= 5) { nk = 1; return ((uint32_t)HR_SF << 20) | ((both >> 4) & 0xf); }                 // :90
+    if (n4) { kick = four & 0xf; nk = 1; others(four & 0xf, 99, 1, kick, nk); return ((uint32_t)HR_POKER << 20) | kick; }  // :91
+    if (n3 > 1) { nk = 2; return ((uint32_t)HR_FULL << 20) | ((three & 0xf) << 4) | ((three >> 4) & 0xf); }  // :92
+    if (n3 && n2) { nk = 2; return ((uint32_t)HR_FULL << 20) | ((three & 0xf) << 4) | (two & 0xf); }          // :93
+    if ((flush >> 8) >= 5) {                                                                                  // :94
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            bool take = i < n && (uint32_t)i >= flush_start && (uint32_t)i < flush_start + 5;
+            kick = take ? ((kick << 4) | (sk[i] & 0xf)) : kick;
+            nk += take;
+        }
+        return ((uint32_t)HR_FLUSH << 20) | kick;
+    }
+    if ((straight >> 4) >= 5) { nk = 1; return ((uint32_t)HR_STRAIGHT << 20) | (straight & 0xf); }            // :95
+    if (n3) { kick = three & 0xf; nk = 1; others(three & 0xf, 99, 2, kick, nk); return ((uint32_t)HR_TRIS << 20) | kick; }  // :96
+    if (n2 > 1) {                                                                                             // :97
+        uint32_t t0 = two & 0xf, t1 = (two >> 4) & 0xf;
+        kick = (t0 << 4) | t1; nk = 2; others(t0, t1, 1, kick, nk);
+        return ((uint32_t)HR_TWO_PAIR << 20) | kick;
+    }
+    if (n2) { kick = two & 0xf; nk = 1; others(two & 0xf, 99, 3, kick, nk); return ((uint32_t)HR_PAIR << 20) | kick; }  // :98
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {                                                                             // :99
+        bool take = i < n;
+        kick = take ? ((kick << 4) | rk[i]) : kick;
+        nk += take;
+    }
+    return ((uint32_t)HR_HIGH << 20) | kick;
+}
+
+// judger.compare_rankings (judger.py:111-158) over values v[p] = rank<<20|kick; returns the winners bitmask.
+// Line 148 (`kicker = best_kicker`) never raises best_kicker: reproduced.
+template <int N>
+__device__ __forceinline__ uint32_t compare_rankings(const uint32_t (&v)[N], int &nw) {
+    uint32_t best_rank = HR_NONE, best_kicker = 0, win = 0;
+#pragma unroll
+    for (int p = 0; p < N; ++p) {
+        uint32_t rank = v[p] >> 20, kicker = v[p] & 0xFFFFF;
+        if (rank < best_rank) { best_rank = rank; best_kicker = kicker; win = 1u << p; }   // :140-144
+        else if (rank == best_rank) {
+            if (kicker > best_kicker) win = 1u << p;                                        // :146-149
+            else if (kicker == best_kicker) win |= 1u << p;                                 // :150-152
+        }
+    }
+    nw = __popc(win);
+    return win;
+}
+
+// ---------------------------------------------------------------------------------------------- the table
+template <int N>
+struct Table {
+    static constexpr int K = 5 + 2 * N;      // cards ever read (game.py:278,388-395)
+    static constexpr int W = (K + 3) / 4;    // packed words
+    static constexpr uint32_t FULL = (1u << N) - 1;
+    double credits[N], bets[N], pending[N], payoffs[N];
+    double min_raise;
+    uint32_t st_active, st_called, st_allin, st_broken;  // seat bitmasks; FOLDED = in none of them
+    int active, dealer, sb, bb, turn, hand;
+    uint32_t hand_serial, step_serial;
+    uint32_t cards[W];
+    uint32_t terr;
+    int hands_this_step;
+    uint32_t evals;  // showdown 7-card evals since load
+
+    __device__ __forceinline__ void load(const State &S, int t) {
+#pragma unroll
+        for (int p = 0; p < N; ++p) {
+            credits[p] = S.credits[(size_t)p * S.T + t]; bets[p] = S.bets[(size_t)p * S.T + t];
+            pending[p] = S.pending[(size_t)p * S.T + t]; payoffs[p] = S.payoffs[(size_t)p * S.T + t];
+        }
+        min_raise = S.min_raise[t];
+        uint64_t ss = S.seat_states[t];
+        st_active = (uint32_t)ss & 0xffff; st_called = (uint32_t)(ss >> 16) & 0xffff;
+        st_allin = (uint32_t)(ss >> 32) & 0xffff; st_broken = (uint32_t)(ss >> 48) & 0xffff;
+        uint32_t cur = S.cursors[t];
+        active = cur & 0xf; dealer = (cur >> 4) & 0xf; sb = (cur >> 8) & 0xf; bb = (cur >> 12) & 0xf; turn = (cur >> 16) & 0xf;
+        hand = S.hand[t];
+        hand_serial = S.hand_serial[t]; step_serial = S.step_serial[t];
+#pragma unroll
+        for (int w = 0; w < W; ++w) cards[w] = S.cards[(size_t)w * S.T + t];
+        terr = 0; hands_this_step = 0; evals = 0;
+    }
+    __device__ __forceinline__ void store(const State &S, int t) const {
+#pragma unroll
+        for (int p = 0; p < N; ++p) {
+            S.credits[(size_t)p * S.T + t] = credits[p]; S.bets[(size_t)p * S.T + t] = bets[p];
+            S.pending[(size_t)p * S.T + t] = pending[p]; S.payoffs[(size_t)p * S.T + t] = payoffs[p];
+        }
+        S.min_raise[t] = min_raise;
+        S.seat_states[t] = (uint64_t)st_active | ((uint64_t)st_called << 16) | ((uint64_t)st_allin << 32) | ((uint64_t)st_broken << 48);
+        S.cursors[t] = (uint32_t)active | ((uint32_t)dealer << 4) | ((uint32_t)sb << 8) | ((uint32_t)bb << 12) | ((uint32_t)turn << 16);
+        S.hand[t] = hand;
+        S.hand_serial[t] = hand_serial; S.step_serial[t] = step_serial;
+#pragma unroll
+        for (int w = 0; w < W; ++w) S.cards[(size_t)w * S.T + t] = cards[w];
+    }
+
+    __device__ __forceinline__ void set_state(int p, int st) {  // player_states[p] = st
+        uint32_t b = 1u << p;
+        st_active &= ~b; st_called &= ~b; st_allin &= ~b; st_broken &= ~b;
+        st_active |= (st == PS_ACTIVE) ? b : 0; st_called |= (st == PS_CALLED) ? b : 0;
+        st_allin |= (st == PS_ALL_IN) ? b : 0; st_broken |= (st == PS_BROKEN) ? b : 0;
+    }
+    __device__ __forceinline__ static uint32_t rotr(uint32_t m, int a) {  // bit k of result = bit (a+k)%N of m
+        return ((m >> a) | (m << (N - a))) & FULL;
+    }
+    // Game.get_first_playing, game.py:334-337 (idx in [0, N]; all-BROKEN -> idx % N)
+    __device__ __forceinline__ int first_playing(int idx) const {
+        int i = idx >= N ? idx - N : idx;
+        uint32_t nb = ~st_broken & FULL;
+        if (nb == 0) return i;
+        int r = i + (__ffs(rotr(nb, i)) - 1);
+        return r >= N ? r - N : r;
+    }
+    __device__ __forceinline__ bool game_over() const { return __popc(~st_broken & FULL) == 1; }  // game.py:317-320
+
+    // Game.get_valid_actions(active player) as a bitmask, game.py:339-383.  high_bet is returned for step().
+    __device__ __forceinline__ uint32_t valid_mask(double &high_bet) const {
+        high_bet = vmax<N>(pending);                                               // :365
+        double credit = sel<N>(credits, active);                                   // :366
+        uint32_t mask = (1u << MV_FOLD) | (1u << MV_ALL_IN);                       // :367
+        double d = credit - high_bet;
+        double rv0 = 0.1 * d, rv1 = 0.25 * d, rv2 = 0.5 * d;                       // :370
+        mask |= (rv0 > min_raise && (high_bet + rv0) < credit) ? (1u << 3) : 0;    // :371
+        mask |= (rv1 > min_raise && (high_bet + rv1) < credit) ? (1u << 4) : 0;
+        mask |= (rv2 > min_raise && (high_bet + rv2) < credit) ? (1u << 5) : 0;
+        mask |= (high_bet == 0.0) ? (1u << MV_CHECK) : 0;                          // :375
+        mask |= (high_bet < credit) ? (1u << MV_CALL) : 0;                         // :376
+        return mask;
+    }
+
+    // Deck of this hand (RNG spec: DESIGN.md, "RNG specification") -> cards[]; replaces random.shuffle(self.deck), game.py:424.
+    __device__ __forceinline__ void deal(const State &S, uint32_t table_id) {
+        uint32_t c[K];
+        constexpr int NB = (K + 17) / 18;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            uint32_t w[4];
+            philox4x32_10(table_id, hand_serial, STREAM_DECK, (uint32_t)b, S.key0, S.key1, w);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                uint32_t xlo = w[2 * h], xhi = w[2 * h + 1];
+#pragma unroll
+                for (int j = 0; j < 9; ++j) {
+                    const int i = b * 18 + h * 9 + j;
+                    if (i < K) {  // chained multiply-high: c_i = (x * (52-i)) >> 64, x = low 64 bits
+                        uint64_t t = (uint64_t)xlo * (uint32_t)(52 - i);
+                        uint64_t u = (uint64_t)xhi * (uint32_t)(52 - i) + (t >> 32);
+                        c[i] = (uint32_t)(u >> 32); xlo = (uint32_t)t; xhi = (uint32_t)u;
+                    }
+                }
+            }
+        }
+        hand_serial += 1;
+        // Lehmer decode ("c_i-th card not yet dealt") without arrays: packed bytes (bit 7 kept set), processed from the
+        // last draw to the first; for each earlier-processed (later-drawn) byte b: b += (b >= c_i).
+        uint32_t a[W];
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            uint32_t v = 0x80808080u;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (4 * w + j < K) v |= c[4 * w + j] << (8 * j);
+            a[w] = v;
+        }
+#pragma unroll
+        for (int i = K - 1; i >= 0; --i) {
+            uint32_t bc = c[i] | (c[i] << 8); bc |= bc << 16;
+#pragma unroll
+            for (int w = i / 4; w < W; ++w) {
+                uint32_t fl = (a[w] - bc) & 0x80808080u;
+                if (w == i / 4) {
+                    if ((i % 4) == 3) continue;
+                    fl &= 0x80808080u << (8 * ((i % 4) + 1));
+                }
+                a[w] += fl >> 7;
+            }
+        }
+#pragma unroll
+        for (int w = 0; w < W; ++w) {  // canonical index k -> Card.value ((k%4)<<4)|(k//4), cards.py:77
+            uint32_t idx = a[w] & 0x3f3f3f3fu;
+            cards[w] = ((idx & 0x03030303u) << 4) | ((idx >> 2) & 0x0f0f0f0fu);
+        }
+    }
+    __device__ __forceinline__ uint32_t card(int i) const { return (cards[i >> 2] >> (8 * (i & 3))) & 0xff; }  // compile-time i
+
+    // Game.setup_hand, game.py:414-451
+    __device__ __forceinline__ void setup_hand(const State &S, uint32_t table_id) {
+        hand += 1; turn = 0;                                                       // :417-418
+        st_active = ~st_broken & FULL; st_called = 0; st_allin = 0;                // :421
+        deal(S, table_id);                                                         // :424
+        dealer = first_playing(dealer + 1);                                        // :432
+        sb = first_playing(dealer + 1);                                            // :433
+        bb = first_playing(sb + 1);                                                // :434
+        active = first_playing(bb + 1);                                            // :435
+#pragma unroll
+        for (int p = 0; p < N; ++p) {                                              // :438-440 (fancy index: sb written last)
+            bets[p] = 0.0;
+            double v = (p == bb) ? S.big_blind : 0.0;
+            pending[p] = (p == sb) ? S.small_blind : v;
+        }
+        set_state(bb, PS_CALLED);                                                  // :441
+#pragma unroll
+        for (int p = 0; p < N; ++p) {
+            if (pending[p] > credits[p]) set_state(p, PS_ALL_IN);                  // :444
+            pending[p] = (credits[p] < pending[p]) ? credits[p] : pending[p];      // :445 np.minimum
+        }
+        min_raise = vmax<N>(pending);                                              // :446
+        hands_this_step += 1;
+    }
+
+    // Game.reset, game.py:397-412
+    __device__ __forceinline__ void reset(const State &S, uint32_t table_id, int dealer_cfg) {
+        dealer = dealer_cfg; hand = 0; active = 0;                                 // :403-407
+#pragma unroll
+        for (int p = 0; p < N; ++p) credits[p] = S.start_credits[p];               // :408
+        st_active = FULL; st_called = st_allin = st_broken = 0;                    // :409
+        setup_hand(S, table_id);                                                   // :412
+    }
+
+    // Game.end_hand, game.py:453-539.  `show` = S.show + t (seat stride T).
+    __device__ inline void end_hand(const State &S, int t, uint32_t table_id) {
+#pragma unroll
+        for (int p = 0; p < N; ++p) {                                              // :457-461, :468
+            bets[p] = bets[p] + pending[p]; credits[p] = credits[p] - pending[p];
+            pending[p] = 0.0; payoffs[p] = 0.0;
+        }
+        min_raise = 0.0;
+        uint32_t pw = (st_active | st_called | st_allin) & FULL;                   // :471 (not BROKEN, not FOLDED)
+        int npw = __popc(pw);                                                      // :472
+        if (npw <= 0) { terr |= PK_TERR_NO_WINNER; return; }                       // :473 assert
+        if (npw == 1) {                                                            // :475-480
+            int winner = __ffs(pw) - 1;
+            double pot = np_sum<N>(bets);
+#pragma unroll
+            for (int p = 0; p < N; ++p) {
+                payoffs[p] = (p == winner) ? pot : payoffs[p];
+                credits[p] = (p == winner) ? credits[p] + pot : credits[p];
+            }
+        } else {
+            double wb[N];                                                          // :485
+            uint32_t hv[N];
+            const uint32_t showdown = (st_called | st_allin) & FULL;               // :488, :496
+#pragma unroll
+            for (int p = 0; p < N; ++p) {
+                wb[p] = bets[p];
+                uint32_t v = NONE_V;
+                if ((showdown >> p) & 1) {                                         // :488-489, hand = deck[:5] + hole (:394-395)
+                    uint32_t h[7] = {card(0), card(1), card(2), card(3), card(4), card(5 + 2 * p), card(6 + 2 * p)};
+                    int nk;
+                    v = eval_hand(h, 7, nk);
+                    evals += 1;
+                }
+                hv[p] = v;
+                S.show[(size_t)p * S.T + t] = v;
+            }
+            uint32_t todo = showdown;                                              // :495-496 argsort(bets) filtered, stable
+            while (todo) {                                                         // :498
+                int player = 0; double best = 0.0; bool have = false;
+#pragma unroll
+                for (int p = 0; p < N; ++p) {                                      // next in ascending original-bet order
+                    bool cand = (todo >> p) & 1;
+                    bool better = cand && (!have || bets[p] < best);
+                    player = better ? p : player; best = better ? bets[p] : best; have = have || cand;
+                }
+                todo &= ~(1u << player);
+                bool any_pos = false;
+#pragma unroll
+                for (int p = 0; p < N; ++p) any_pos = any_pos || !(wb[p] <= 0.0);
+                if (!any_pos) break;                                               // :499
+                if (npw == 1) {                                                    // :500-505
+                    double s = np_sum<N>(wb);
+                    put<N>(payoffs, player, sel<N>(payoffs, player) + s);
+                    break;
+                }
+                double max_bet = sel<N>(wb, player), mb[N];                        // :508-509 np.clip(bets, 0, max_bet)
+#pragma unroll
+                for (int p = 0; p < N; ++p) { double x = wb[p]; x = (x < 0.0) ? 0.0 : x; x = (x > max_bet) ? max_bet : x; mb[p] = x; }
+                int nw;
+                uint32_t win = compare_rankings<N>(hv, nw);                        // :512
+                double s = np_sum<N>(mb);
+                if (nw == 1) {                                                     // :515
+#pragma unroll
+                    for (int p = 0; p < N; ++p) payoffs[p] = ((win >> p) & 1) ? payoffs[p] + s : payoffs[p];
+                } else {                                                           // :516  sum * onehot / sum(onehot)
+                    double k = (double)nw;
+#pragma unroll
+                    for (int p = 0; p < N; ++p) payoffs[p] = payoffs[p] + (s * (((win >> p) & 1) ? 1.0 : 0.0)) / k;
+                }
+#pragma unroll
+                for (int p = 0; p < N; ++p) {                                      // :522-523
+                    hv[p] = (p == player) ? NONE_V : hv[p];
+                    wb[p] = wb[p] - mb[p];
+                }
+                npw -= 1;                                                          // :525
+            }
+#pragma unroll
+            for (int p = 0; p < N; ++p) credits[p] = credits[p] + payoffs[p];      // :528
+        }
+#pragma unroll
+        for (int p = 0; p < N; ++p) {
+            payoffs[p] = payoffs[p] - bets[p];                                     // :531
+            if (credits[p] <= 0.0) set_state(p, PS_BROKEN);                        // :536
+        }
+        setup_hand(S, table_id);                                                   // :539
+    }
+
+    // Game.next_turn, game.py:541-576.  Returns PK_FLAG_* bits.
+    __device__ inline uint32_t next_turn(const State &S, int t, uint32_t table_id) {
+#pragma unroll
+        for (int p = 0; p < N; ++p) {                                              // :554-557
+            bets[p] = bets[p] + pending[p]; credits[p] = credits[p] - pending[p]; pending[p] = 0.0;
+        }
+        min_raise = 0.0;                                                           // :558
+        turn += 1;                                                                 // :561
+        if (turn == 4) {                                                           // :563-565
+            end_hand(S, t, table_id);
+            return (game_over() ? PK_FLAG_GAME_OVER : 0) | PK_FLAG_HAND_OVER | PK_FLAG_TURN_OVER;
+        }
+        if (__popc(st_called) > 1) { st_active |= st_called; st_called = 0; }      // :567-572
+        active = first_playing(dealer + 1);                                        // :575
+        return PK_FLAG_TURN_OVER;
+    }
+
+    // Game.next_player, game.py:578-619
+    __device__ inline uint32_t next_player(const State &S, int t, uint32_t table_id) {
+        uint32_t playing = (st_active | st_called | st_allin) & FULL;              // :598-599
+        if (__popc(playing) > 1) {
+            uint32_t done = 0;                                                     // :603
+            const int current = active;                                            // :604
+            active = (active + 1 == N) ? 0 : active + 1;                           // :605
+            for (;;) {                                                             // :607  while states[active] != ACTIVE
+                int d = current - active; d = d < 0 ? d + N : d;                   //       seats active..current (cyclic)
+                uint32_t window = rotr(st_active, active) & ((2u << d) - 1);
+                if (window) { int a = active + (__ffs(window) - 1); active = a >= N ? a - N : a; break; }
+                active = current;                                                  // :611 walked up to current_player
+                done = next_turn(S, t, table_id);                                  // :609
+                if (terr) break;
+                if (done & PK_FLAG_GAME_OVER) break;                               // :610
+                if (hands_this_step > PK_HAND_CAP) { terr |= PK_TERR_HAND_CAP; break; }
+            }
+            return done;                                                           // :615
+        }
+        end_hand(S, t, table_id);                                                  // :618
+        return (game_over() ? PK_FLAG_GAME_OVER : 0) | PK_FLAG_HAND_OVER;          // :619
+    }
+
+    // Game.step for an action already known to be valid (mask checked by the caller), game.py:656-699.
+    __device__ inline uint32_t step(const State &S, int t, uint32_t table_id, int action, double high_bet) {
+        const int a = active;
+        if (action == MV_FOLD) set_state(a, PS_FOLDED);                            // :656-657
+        else if (action == MV_CHECK) set_state(a, PS_CALLED);                      // :659-660
+        else {
+            double bet_value = (S.big_blind > high_bet) ? S.big_blind : high_bet;  // :665 max(high_bet, big_blind)
+            double credit = sel<N>(credits, a);                                    // :666
+            int st = PS_CALLED;                                                    // :667
+            if (action == MV_ALL_IN) { bet_value = credit; st = PS_ALL_IN; }       // :669-671
+            else if (action >= MV_RAISE_ANY) {                                     // :673-678
+                double f = action == 3 ? 0.1 : (action == 4 ? 0.25 : 0.5);
+                double future_credit = credit - bet_value;
+                double raise_value = future_credit * f;
+                bet_value = bet_value + raise_value;
+            }
+            if (bet_value > high_bet) {                                            // :680-687
+                st_active |= st_called; st_called = 0;
+                min_raise = bet_value - high_bet;
+            }
+            set_state(a, st);
+            put<N>(pending, a, bet_value);                                         // :696
+        }
+        uint32_t flags = next_player(S, t, table_id);                              // :699
+        if (!(terr & PK_TERR_NO_WINNER)) step_serial += 1;
+        return flags;
+    }
+};
+
+// Synthetic agents (RandomAgent semantics of pokerl/agents/random.py:12-16 under the RNG spec).
+__device__ __forceinline__ int pick_action(const State &S, uint32_t table_id, uint32_t step_serial, uint32_t mask, int policy) {
+    if (policy == PK_POLICY_ALLIN) return MV_ALL_IN;
+    uint32_t w[4];
+    philox4x32_10(table_id, step_serial >> 2, STREAM_ACTION, 0u, S.key0, S.key1, w);
+    uint32_t r = (step_serial & 2) ? ((step_serial & 1) ? w[3] : w[2]) : ((step_serial & 1) ? w[1] : w[0]);
+    uint32_t k = __umulhi(r, (uint32_t)__popc(mask));
+    uint32_t m = mask;
+    for (uint32_t i = 0; i < k; ++i) m &= m - 1;  // drop the k lowest set bits (k <= 6)
+    return __ffs(m) - 1;
+}
+
+}  // namespace pk

@@ -1,0 +1,234 @@
+"""VecGame: T independent reference `Game`s stepped in lockstep on one MI355X.
+
+Host-side mirror of the reference's pokerl/game.py `Game` API for the data-parallel hot path: same method and
+attribute names, same argument meaning and error behaviour, with a leading table axis on everything.  All game
+logic runs in hand-written HIP kernels behind the C ABI of include/pokerl_hip.h (ctypes; no torch, no CPU fallback).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+from .enums import PlayerState, PokerMoves
+
+DEFAULT_SEED = 0x706F6B65726C  # 'pokerl'
+
+
+class VecGame:
+    """`Game(**config)` (pokerl/game.py:242-264) for `num_tables` tables.
+
+    config: num_players=4, start_credits=100 (int or per-seat list/array), big_blind=2, small_blind=1, dealer=0 -- as
+    the reference -- plus num_tables, seed, device, table_id_base (global id of table 0: RNG streams are keyed by the
+    global table id, so a table's trajectory does not depend on which GPU/shard hosts it).
+    """
+
+    def __init__(self, num_tables=1, **config):
+        self.num_tables = int(num_tables)
+        self.num_players = int(config.get('num_players', 4))
+        self.start_credits = config.get('start_credits', 100)
+        self.big_blind = config.get('big_blind', 2)
+        self.small_blind = config.get('small_blind', 1)
+        self.dealer = int(config.get('dealer', 0))
+        self.seed = int(config.get('seed', DEFAULT_SEED))
+        self.device = int(config.get('device', 0))
+        self.table_id_base = int(config.get('table_id_base', 0))
+        if not (L.MIN_PLAYERS <= self.num_players <= L.MAX_PLAYERS):
+            raise ValueError('num_players must be in [%d, %d]' % (L.MIN_PLAYERS, L.MAX_PLAYERS))
+        self._lib = L.lib()
+        self._h = C.c_void_p()
+        if isinstance(self.start_credits, (int, float, np.integer, np.floating)):
+            sc, scalar = None, float(self.start_credits)
+        else:
+            sc = np.ascontiguousarray(self.start_credits, np.float64)
+            if sc.shape != (self.num_players,):
+                raise ValueError('start_credits must be a scalar or one value per player')
+            scalar = 0.0
+        rc = self._lib.pk_create(C.byref(self._h), self.device, self.num_tables, self.num_players, L.ptr(sc), scalar,
+                                 float(self.big_blind), float(self.small_blind), self.dealer, self.seed,
+                                 self.table_id_base)
+        if rc != L.PK_OK:
+            self._h = C.c_void_p()
+            L.check(rc)
+
+    def close(self):
+        if getattr(self, '_h', None) and self._h.value:
+            self._lib.pk_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ reset / step
+    def reset(self, mask=None, **config):
+        """`Game.reset(**config)` (game.py:397-412) on every table, or on tables where mask != 0.  Only `dealer` is
+        re-read from config (game.py:403)."""
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        if m is not None and m.shape != (self.num_tables,):
+            raise ValueError('mask must have shape (num_tables,)')
+        L.check(self._lib.pk_reset(self._h, L.ptr(m), int(config.get('dealer', 0))), self._h)
+
+    def _actions(self, actions):
+        a = np.asarray(actions)
+        if a.dtype.kind not in 'iu':          # game.py:646,700: only int actions are implemented
+            raise NotImplementedError
+        a = np.ascontiguousarray(np.broadcast_to(a, (self.num_tables,)), np.int32)
+        return a
+
+    def step(self, actions, strict=True):
+        """`Game.step(action)` (game.py:621-700), one action per table.
+
+        Returns (game_over, hand_over, turn_over) as bool arrays [T] -- the reference's tuple, vectorised.
+        strict=True mirrors the reference's error contract for the batch: if ANY action is invalid a ValueError
+        ('Player %d invalid move: `%s`', game.py:651) is raised before any table is mutated.  strict=False steps the
+        tables whose action is valid, leaves the others untouched and returns a 4th array of per-table error bits.
+        """
+        a = self._actions(actions)
+        if strict:
+            valid = self.get_valid_actions()[0]
+            ok = (a >= 0) & (a < PokerMoves.NUM_MOVES)
+            ok[ok] = valid[np.nonzero(ok)[0], a[ok]] != 0
+            if not ok.all():
+                t = int(np.argmin(ok))
+                name = PokerMoves.as_string[a[t]] if 0 <= a[t] < PokerMoves.NUM_MOVES else str(int(a[t]))
+                raise ValueError('Player %d invalid move: `%s` (table %d)' % (int(self.active_player[t]), name, t))
+        flags = np.zeros(self.num_tables, np.uint8)
+        terr = np.zeros(self.num_tables, np.uint8)
+        rc = self._lib.pk_step(self._h, L.ptr(a), L.ptr(flags), L.ptr(terr))
+        L.check(rc, self._h, allow_table_errors=True)
+        out = ((flags & L.FLAG_GAME_OVER) != 0, (flags & L.FLAG_HAND_OVER) != 0, (flags & L.FLAG_TURN_OVER) != 0)
+        if strict:
+            if (terr & L.TERR_NO_WINNER).any():   # game.py:473
+                raise AssertionError('Invalid state: no potential winner (table %d)' % int(np.argmax(terr & L.TERR_NO_WINNER)))
+            if terr.any():
+                raise L.PokerlHipError('table error bits %s' % np.unique(terr))
+            return out
+        return out + (terr,)
+
+    def get_valid_actions(self):
+        """`Game.get_valid_actions()` (game.py:339-383) of each table's active player: (onehot f64 [T,7], list of
+        index arrays)."""
+        out = np.zeros((self.num_tables, PokerMoves.NUM_MOVES), np.uint8)
+        L.check(self._lib.pk_get_valid_actions(self._h, L.ptr(out)), self._h)
+        onehot = out.astype(np.float64)
+        return onehot, (np.nonzero(row)[0] for row in out)
+
+    # ------------------------------------------------------------------ throughput / agents
+    def pick_actions(self, policy=0):
+        a = np.zeros(self.num_tables, np.int32)
+        L.check(self._lib.pk_pick_actions(self._h, int(policy), L.ptr(a)), self._h)
+        return a
+
+    def rollout(self, steps, policy=0, auto_reset=True, fused=True, counters=True):
+        """`steps` lockstep Game.step()s per table with in-kernel agents (examples/random_game.py:8-12 as a kernel).
+        Returns dict(steps, hands, evals, games) when counters=True (synchronises), else None (asynchronous)."""
+        c = np.zeros(L.NUM_COUNTERS, np.uint64) if counters else None
+        L.check(self._lib.pk_rollout(self._h, int(steps), int(policy), int(bool(auto_reset)), int(bool(fused)), L.ptr(c)),
+                self._h)
+        if c is not None:
+            return dict(steps=int(c[0]), hands=int(c[1]), evals=int(c[2]), games=int(c[3]))
+
+    def time_rollout(self, steps, policy=0, auto_reset=True, fused=True, reps=1):
+        """Average device milliseconds per kernel launch (HIP events on the handle's stream) + counters."""
+        ms = C.c_double(0.0)
+        c = np.zeros(L.NUM_COUNTERS, np.uint64)
+        L.check(self._lib.pk_time_rollout(self._h, int(steps), int(policy), int(bool(auto_reset)), int(bool(fused)),
+                                          int(reps), C.byref(ms), L.ptr(c)), self._h)
+        return ms.value, dict(steps=int(c[0]), hands=int(c[1]), evals=int(c[2]), games=int(c[3]))
+
+    def sync(self):
+        L.check(self._lib.pk_sync(self._h), self._h)
+
+    # ------------------------------------------------------------------ state reads (Game attributes)
+    def _f64(self, field):
+        out = np.zeros((self.num_tables, self.num_players), np.float64)
+        L.check(self._lib.pk_get_f64(self._h, field, L.ptr(out)), self._h)
+        return out
+
+    def _i32(self, field):
+        out = np.zeros(self.num_tables, np.int32)
+        L.check(self._lib.pk_get_i32(self._h, field, L.ptr(out)), self._h)
+        return out
+
+    credits = property(lambda self: self._f64(L.F_CREDITS))
+    bets = property(lambda self: self._f64(L.F_BETS))
+    pending_bets = property(lambda self: self._f64(L.F_PENDING_BETS))
+    payoffs = property(lambda self: self._f64(L.F_PAYOFFS))
+    active_player = property(lambda self: self._i32(L.I_ACTIVE_PLAYER))
+    turn = property(lambda self: self._i32(L.I_TURN))
+    dealer_idx = property(lambda self: self._i32(L.I_DEALER_IDX))
+    small_blind_idx = property(lambda self: self._i32(L.I_SMALL_BLIND_IDX))
+    big_blind_idx = property(lambda self: self._i32(L.I_BIG_BLIND_IDX))
+    hand = property(lambda self: self._i32(L.I_HAND))
+    hand_serial = property(lambda self: self._i32(L.I_HAND_SERIAL).view(np.uint32))
+    step_serial = property(lambda self: self._i32(L.I_STEP_SERIAL).view(np.uint32))
+
+    @property
+    def minimum_raise_value(self):
+        out = np.zeros(self.num_tables, np.float64)
+        L.check(self._lib.pk_get_min_raise(self._h, L.ptr(out)), self._h)
+        return out
+
+    @property
+    def player_states(self):
+        out = np.zeros((self.num_tables, self.num_players), np.uint8)
+        L.check(self._lib.pk_get_player_states(self._h, L.ptr(out)), self._h)
+        return out
+
+    @property
+    def deck(self):
+        """deck[:, 0:5+2N] as Card.value bytes -- the only part of the deck the game ever reads (game.py:278,385-395)."""
+        out = np.zeros((self.num_tables, 5 + 2 * self.num_players), np.uint8)
+        L.check(self._lib.pk_get_cards(self._h, L.ptr(out)), self._h)
+        return out
+
+    @property
+    def community_cards(self):
+        """[T,5] card values, -1 where not yet visible (game.py:266-278: [] at turn 0, deck[:turn+2] after)."""
+        cards = self.deck[:, :5].astype(np.int16)
+        turn = self.turn
+        visible = (turn[:, None] != 0) & (np.arange(5)[None, :] < (turn[:, None] + 2))
+        cards[~visible] = -1
+        return cards
+
+    def get_cards_of(self, player):
+        """game.py:385-389.  player: int or int array [T]."""
+        p = np.broadcast_to(np.asarray(player), (self.num_tables,))
+        d = self.deck
+        t = np.arange(self.num_tables)
+        return np.stack([d[t, 5 + 2 * p], d[t, 6 + 2 * p]], axis=1)
+
+    def get_hand_for(self, player):
+        """game.py:391-395: the 5 community cards + the player's 2 hole cards, [T,7]."""
+        return np.concatenate([self.deck[:, :5], self.get_cards_of(player)], axis=1)
+
+    @property
+    def hand_rankings(self):
+        """Rankings of each table's last showdown (game.py:488-489): (rank [T,N] HandRanking, kickers value [T,N])."""
+        rank = np.zeros((self.num_tables, self.num_players), np.uint8)
+        kick = np.zeros((self.num_tables, self.num_players), np.uint32)
+        L.check(self._lib.pk_get_hand_ranks(self._h, L.ptr(rank), L.ptr(kick)), self._h)
+        return rank, kick
+
+    @property
+    def pot(self):
+        return np.array([np.sum(b) for b in self.bets])  # game.py:281-284 (np.sum per table keeps numpy's order)
+
+    @property
+    def high_bet(self):
+        return np.max(self.pending_bets, axis=1)  # game.py:287-290
+
+    @property
+    def game_over(self):
+        return np.sum(self.player_states != PlayerState.BROKEN, axis=1) == 1  # game.py:317-320
+
+    @property
+    def observations(self):
+        """Dense `StateView(active player)` rows (game.py:117-131), f64 [T, PK_OBS_DIM(N)]; layout in pokerl_hip.h."""
+        out = np.zeros((self.num_tables, 17 + 3 * self.num_players), np.float64)
+        L.check(self._lib.pk_get_obs(self._h, L.ptr(out)), self._h)
+        return out
+
+    active_state = observations

@@ -1,0 +1,108 @@
+"""CPU-side tests (no GPU): the C-ABI library loads and exports every declared symbol, the host mirror's pure-host
+logic, sharding, and the distributed aggregation of bench.py under gloo with world_size 2."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    import ctypes
+    from pokerl_amd import _lib, build
+    build.build_lib()
+    header = open(os.path.join(ROOT, "include", "pokerl_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(pk_[a-z0-9_]+)\s*\(", header)))
+    assert declared == sorted(_lib.SYMBOLS)
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(L, name), name
+    assert _lib.lib().pk_abi_version() == 1
+
+
+def test_no_device_fails_loudly():
+    import pokerl_amd
+    if pokerl_amd.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(pokerl_amd.PokerlHipError, match="no CPU fallback"):
+        pokerl_amd.VecGame(4, num_players=3)
+    with pytest.raises(pokerl_amd.PokerlHipError):
+        pokerl_amd.eval_hand(["AD", "KD"])
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "pokerl_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src, os.path.join(dirpath, f)  # not imported, linked, loaded or even named
+
+
+def test_shard_tables():
+    from pokerl_amd import shard_tables
+    for total, world in [(524288, 8), (65536, 1), (10, 3), (7, 8)]:
+        parts = [shard_tables(total, r, world) for r in range(world)]
+        assert sum(n for n, _ in parts) == total
+        pos = 0
+        for n, base in parts:
+            assert base == pos
+            pos += n
+    assert shard_tables(524288, 3, 8) == (65536, 196608)
+    with pytest.raises(ValueError):
+        shard_tables(10, 3, 3)
+
+
+def test_card_helpers_match_reference_encoding():
+    from pokerl_amd import cards
+    # pokerl/cards.py: '1D' and 'AD' are both the ace of diamonds, value (2<<4)|0; rank property makes it 13
+    assert cards.card_value("AD") == cards.card_value("1D") == 0x20
+    assert cards.card_rank(0x20) == 13 and cards.card_suit(0x20) == 2 and cards.card_id(0x20) == 26
+    assert cards.card_value("KC") == 0x3c and cards.card_value((5, 1)) == 0x15 and cards.card_value((13, 0)) == 0
+    d = cards.default_deck_values()
+    assert d[:5].tolist() == [0x00, 0x10, 0x20, 0x30, 0x01] and len(set(d.tolist())) == 52
+    from oracle import rng_spec
+    assert d.tolist() == rng_spec.canonical_deck_values()
+
+
+def test_enums_match_golden_constants():
+    from pokerl_amd import HandRanking, PlayerState, PokerMoves
+    assert (HandRanking.STRAIGHT_FLUSH, HandRanking.HIGH, HandRanking.NONE) == (1, 9, 10)
+    assert (PokerMoves.FOLD, PokerMoves.CHECK, PokerMoves.CALL, PokerMoves.RAISE_TEN, PokerMoves.ALL_IN) == (0, 1, 2, 3, 6)
+    assert (PlayerState.FOLDED, PlayerState.ACTIVE, PlayerState.CALLED, PlayerState.ALL_IN, PlayerState.BROKEN) == (0, 1, 2, 3, 4)
+
+
+WORKER = r'''
+import os, sys, json
+sys.path.insert(0, %r)
+import bench
+rank = int(os.environ["RANK"]); world = int(os.environ["WORLD_SIZE"])
+ctx = bench.DistContext(backend="gloo")
+n, base = bench.shard(131072, ctx)
+# stand-in workload: rank r "runs" n*10 steps in (1 + r) seconds
+total_steps, seconds = ctx.aggregate(n * 10, 1.0 + rank)
+ctx.barrier()
+if rank == 0:
+    print(json.dumps(dict(n=n, base=base, total=total_steps, seconds=seconds, world=world)))
+ctx.close()
+'''
+
+
+def test_bench_aggregation_gloo_world2(tmp_path):
+    script = tmp_path / "w.py"
+    script.write_text(WORKER % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29531")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29531", str(script)],
+                         capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    import json
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    r = json.loads(line)
+    assert r["world"] == 2 and r["n"] == 65536 and r["base"] == 0
+    assert r["total"] == 131072 * 10          # units of ALL ranks
+    assert r["seconds"] == 2.0                # MAX over ranks
