@@ -128,9 +128,10 @@ int pk_eval_hands(int device, const uint8_t *cards, const uint8_t *ncards, size_
  * onehot[M][n].  Includes the reference's line-148 behaviour. */
 int pk_compare_rankings(int device, const uint8_t *rank, const uint32_t *kick, int n, size_t m, uint8_t *onehot);
 
-/* Exhaustive-check hook for the evaluator: v = HandRanking<<20 | kickers value of every 7-card hand whose two lowest
- * canonical deck indices (pokerl/cards.py:77 order) are (a, b), in lexicographic order; out holds C(51-b, 5) words. */
-int pk_eval7_prefix(int device, int a, int b, uint32_t *out, size_t *count_out);
+/* Exhaustive-check hook for the evaluators: v = HandRanking<<20 | kickers value of every 7-card hand whose two lowest
+ * canonical deck indices (pokerl/cards.py:77 order) are (a, b), in lexicographic order; out holds C(51-b, 5) words.
+ * fast != 0: the 7-distinct-card evaluator the showdown kernels use; fast == 0: the general one behind pk_eval_hands. */
+int pk_eval7_prefix(int device, int a, int b, int fast, uint32_t *out, size_t *count_out);
 
 /* Actions the in-kernel agent `policy` would take now (one per table) -- lets a host loop reproduce rollouts. */
 int pk_pick_actions(pk_handle *h, int policy, int32_t *actions);

@@ -498,7 +498,10 @@ int orc_rollout(orc_game *g, int K, int policy, int auto_reset, uint64_t *counte
             int a = pick_action(g->seed, t, policy, valid_actions(g, t, t->active_player));
             int e = step_table(g, t, a, &fl);
             any |= e;
-            if (e) break;
+            if (e) { /* hand cap (reference would never return): with auto_reset it counts as a finished game */
+                if (!(auto_reset && e == ORC_ERR_HAND_CAP)) break;
+                t->err = 0; fl = 1;
+            }
             ++steps;
             if (fl & 1) { ++games; if (auto_reset) reset_table(g, t, 0); }
         }

@@ -45,6 +45,7 @@ void orc_valid_actions(const orc_game *g, uint8_t *mask);
 void orc_pick_actions(const orc_game *g, int policy, int32_t *actions);
 
 /* K lockstep steps with in-library agents; auto_reset != 0 resets finished games (dealer 0).
+* A table that hits ORC_ERR_HAND_CAP is treated as a finished game when auto_reset != 0 (return value still has the bit).
  * counters[0] += steps, [1] += hands dealt (setup_hand calls), [2] += showdown 7-card evals, [3] += games finished */
 int orc_rollout(orc_game *g, int K, int policy, int auto_reset, uint64_t *counters);
 

@@ -63,7 +63,7 @@ def lib():
     L.pk_get_hand_ranks.argtypes = [_vp, _vp, _vp]
     L.pk_eval_hands.argtypes = [C.c_int, _vp, _vp, C.c_size_t, _vp, _vp, _vp]
     L.pk_compare_rankings.argtypes = [C.c_int, _vp, _vp, C.c_int, C.c_size_t, _vp]
-    L.pk_eval7_prefix.argtypes = [C.c_int, C.c_int, C.c_int, _vp, C.POINTER(C.c_size_t)]
+    L.pk_eval7_prefix.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.POINTER(C.c_size_t)]
     L.pk_pick_actions.argtypes = [_vp, C.c_int, _vp]
     L.pk_rollout.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]
     L.pk_env_reset.argtypes = [_vp, _vp, C.c_int]

@@ -13,7 +13,10 @@
 using namespace pk;
 
 // ================================================================================================ kernels
-// One table per lane.  Grid = ceil(T / block); block is a multiple of 64 (one or more whole wavefronts).
+// One table per lane, one wavefront per workgroup.  At the headline size (65 536 tables) that is exactly one wave per
+// SIMD (256 CUs x 4), so occupancy cannot hide anything and the register budget is the whole 512-entry file:
+// __launch_bounds__(64) lets the compiler keep a table's full state in VGPRs instead of spilling to scratch.
+#define PK_TABLE_BLOCK 64
 
 __device__ __forceinline__ void wave_add_counters(const State &S, uint32_t steps, uint32_t hands, uint32_t evals, uint32_t games) {
     // 64-wide butterfly reduction in registers, one atomic per wave and counter.
@@ -31,13 +34,14 @@ __device__ __forceinline__ void wave_add_counters(const State &S, uint32_t steps
 }
 
 template <int N>
-__global__ void k_reset(State S, const uint8_t *mask, int dealer) {  // Game.reset, game.py:397-412
+__global__ void __launch_bounds__(PK_TABLE_BLOCK) k_reset(State S, const uint8_t *mask, int dealer) {  // Game.reset, game.py:397-412
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= S.T) return;
     if (mask && !mask[t]) return;
     Table<N> tb;
     tb.load(S, t);
-    tb.reset(S, S.table_id_base + (uint32_t)t, dealer);
+    tb.reset_state(S, dealer);
+    tb.deal(S, S.table_id_base + (uint32_t)t);
     tb.store(S, t);
     double hb;
     S.valid[t] = (uint8_t)tb.valid_mask(hb);
@@ -45,138 +49,159 @@ __global__ void k_reset(State S, const uint8_t *mask, int dealer) {  // Game.res
 }
 
 template <int N>
-__global__ void k_step(State S, const int32_t *actions, uint8_t *flags, uint8_t *terr) {  // Game.step, game.py:621-700
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= S.T) return;
+__global__ void __launch_bounds__(PK_TABLE_BLOCK) k_step(State S, const int32_t *actions, uint8_t *flags, uint8_t *terr) {  // Game.step, game.py:621-700
+    __shared__ Lds<N> lds;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = t < S.T;
+    const uint32_t table_id = S.table_id_base + (uint32_t)t;
     Table<N> tb;
-    tb.load(S, t);
+    if (live) tb.load(S, t); else tb.blank();
     double high_bet;
     uint32_t mask = tb.valid_mask(high_bet);                                       // :648
-    int action = actions[t];
-    if (action < 0 || action >= PK_NUM_MOVES || !((mask >> action) & 1)) {         // :649-651: no mutation
+    const int action = live ? actions[t] : -1;
+    const bool ok = live && action >= 0 && action < PK_NUM_MOVES && ((mask >> action) & 1);
+    if (ok) tb.begin_step(S, action, high_bet);
+    tb.run(S, t, table_id, lds, false);
+    if (!live) return;
+    if (!ok) {                                                                     // :649-651: no mutation
         flags[t] = 0;
         S.terr[t] = PK_TERR_INVALID_ACTION;
         if (terr) terr[t] = PK_TERR_INVALID_ACTION;
         return;
     }
-    uint32_t fl = tb.step(S, t, S.table_id_base + (uint32_t)t, action, high_bet);
     tb.store(S, t);
-    flags[t] = (uint8_t)fl;
+    flags[t] = (uint8_t)tb.flags;
     S.valid[t] = (uint8_t)tb.valid_mask(high_bet);
     S.terr[t] = (uint8_t)tb.terr;
     if (terr) terr[t] = (uint8_t)tb.terr;
 }
 
 template <int N>
-__global__ void k_pick(State S, int policy, int32_t *actions) {
+__global__ void __launch_bounds__(PK_TABLE_BLOCK) k_pick(State S, int policy, int32_t *actions) {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= S.T) return;
-    actions[t] = pick_action(S, S.table_id_base + (uint32_t)t, S.step_serial[t], S.valid[t], policy);
+    ActionRng rng;
+    actions[t] = pick_action(S, rng, S.table_id_base + (uint32_t)t, S.step_serial[t], S.valid[t], policy);
 }
 
 // K lockstep steps, in-kernel agents, table state in registers for the whole launch (K == 1: the unfused form).
 template <int N>
-__global__ void k_rollout(State S, int K, int policy, int auto_reset) {
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t steps = 0, games = 0, hands = 0, evals = 0;
-    if (t < S.T) {
-        const uint32_t table_id = S.table_id_base + (uint32_t)t;
-        Table<N> tb;
-        tb.load(S, t);
-        const uint32_t hs0 = tb.hand_serial;
-        double high_bet;
-        uint32_t mask = tb.valid_mask(high_bet);
-        for (int k = 0; k < K; ++k) {
-            int action = pick_action(S, table_id, tb.step_serial, mask, policy);
-            tb.hands_this_step = 0;
-            uint32_t fl = tb.step(S, t, table_id, action, high_bet);
-            if (tb.terr) break;  // table keeps its (reference-identical) state; reported through terr
-            ++steps;
-            if (fl & PK_FLAG_GAME_OVER) {
-                ++games;
-                if (auto_reset) tb.reset(S, table_id, 0);
-            }
-            mask = tb.valid_mask(high_bet);
+__global__ void __launch_bounds__(PK_TABLE_BLOCK) k_rollout(State S, int K, int policy, int auto_reset) {
+    __shared__ Lds<N> lds;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = t < S.T;
+    const uint32_t table_id = S.table_id_base + (uint32_t)t;
+    Table<N> tb;
+    if (live) tb.load(S, t); else tb.blank();
+    const uint32_t hs0 = tb.hand_serial;
+    uint32_t steps = 0;
+    bool alive = live;
+    ActionRng rng;
+    double high_bet;
+    uint32_t mask = tb.valid_mask(high_bet);
+    for (int k = 0; k < K; ++k) {
+        if (alive) tb.begin_step(S, pick_action(S, rng, table_id, tb.step_serial, mask, policy), high_bet);
+        tb.run(S, t, table_id, lds, auto_reset != 0);
+        if (alive) {
+            if (tb.terr) alive = false;  // table keeps its (reference-identical) state; reported through terr
+            else ++steps;
         }
+        mask = tb.valid_mask(high_bet);
+    }
+    if (live) {
         tb.store(S, t);
         S.valid[t] = (uint8_t)mask;
-        S.terr[t] = (uint8_t)tb.terr;
-        hands = tb.hand_serial - hs0; evals = tb.evals;
+        S.terr[t] = (uint8_t)(tb.terr | tb.seen);
     }
-    wave_add_counters(S, steps, hands, evals, games);  // every lane of the wave takes part in the shuffles
+    wave_add_counters(S, steps, tb.hand_serial - hs0, tb.evals, tb.games);  // every lane takes part in the shuffles
 }
 
 // PokerGameEnv.reset, envs/game_env.py:20-29
 template <int N>
-__global__ void k_env_reset(State S, const uint8_t *mask, int opp_policy) {
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= S.T) return;
-    if (mask && !mask[t]) return;
+__global__ void __launch_bounds__(PK_TABLE_BLOCK) k_env_reset(State S, const uint8_t *mask, int opp_policy) {
+    __shared__ Lds<N> lds;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = t < S.T && (!mask || mask[t < S.T ? t : 0]);
     const uint32_t table_id = S.table_id_base + (uint32_t)t;
     Table<N> tb;
-    tb.load(S, t);
-    tb.reset(S, table_id, 0);                                                      // :23
+    if (live) { tb.load(S, t); tb.reset_state(S, 0); tb.deal(S, table_id); } else tb.blank();   // :23
+    ActionRng rng;
     double high_bet;
     uint32_t vm = tb.valid_mask(high_bet);
-    while (tb.active != 0) {                                                       // :24
-        int action = pick_action(S, table_id, tb.step_serial, vm, opp_policy);     // :25
-        tb.hands_this_step = 0;
-        uint32_t fl = tb.step(S, t, table_id, action, high_bet);                   // :26
-        if (tb.terr) break;
-        if (fl & PK_FLAG_GAME_OVER) tb.reset(S, table_id, 0);                      // :27
+    bool more = live && tb.active != 0;                                            // :24
+    while (__any(more)) {
+        if (more) tb.begin_step(S, pick_action(S, rng, table_id, tb.step_serial, vm, opp_policy), high_bet);  // :25-26
+        tb.run(S, t, table_id, lds, false);
+        if (more) {
+            if (tb.terr) more = false;
+            else {
+                if (tb.flags & PK_FLAG_GAME_OVER) { tb.reset_state(S, 0); tb.deal(S, table_id); }  // :27
+                more = tb.active != 0;
+            }
+        }
         vm = tb.valid_mask(high_bet);
     }
-    tb.store(S, t);
-    S.valid[t] = (uint8_t)tb.valid_mask(high_bet);
-    S.terr[t] = (uint8_t)tb.terr;
+    if (live) {
+        tb.store(S, t);
+        S.valid[t] = (uint8_t)vm;
+        S.terr[t] = (uint8_t)tb.terr;
+    }
 }
 
 // PokerGameEnv.step, envs/game_env.py:31-53
 template <int N>
-__global__ void k_env_step(State S, const int32_t *actions, int opp_policy, double *reward, uint8_t *done_out, uint8_t *hand_out, uint8_t *terr) {
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= S.T) return;
+__global__ void __launch_bounds__(PK_TABLE_BLOCK) k_env_step(State S, const int32_t *actions, int opp_policy, double *reward, uint8_t *done_out, uint8_t *hand_out, uint8_t *terr) {
+    __shared__ Lds<N> lds;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = t < S.T;
     const uint32_t table_id = S.table_id_base + (uint32_t)t;
     Table<N> tb;
-    tb.load(S, t);
+    if (live) tb.load(S, t); else tb.blank();
+    ActionRng rng;
     double high_bet;
     uint32_t vm = tb.valid_mask(high_bet);
-    int action = actions[t];
-    if (action < 0 || action >= PK_NUM_MOVES || !((vm >> action) & 1)) {
+    const int action = live ? actions[t] : -1;
+    const bool ok = live && action >= 0 && action < PK_NUM_MOVES && ((vm >> action) & 1);
+    double rew = 0.0;                                                              // :34
+    if (ok) tb.begin_step(S, action, high_bet);                                    // :35
+    tb.run(S, t, table_id, lds, false);
+    bool done = tb.flags & PK_FLAG_GAME_OVER, hand = tb.flags & PK_FLAG_HAND_OVER;
+    bool fin = !ok || tb.terr != 0;
+    if (!fin && (done || (tb.st_broken & 1))) { rew = tb.payoffs[0]; done = true; hand = true; fin = true; }  // :37-39
+    vm = tb.valid_mask(high_bet);
+    bool more = !fin && !hand && tb.active != 0;                                   // :41
+    while (__any(more)) {
+        if (more) tb.begin_step(S, pick_action(S, rng, table_id, tb.step_serial, vm, opp_policy), high_bet);  // :43-44
+        tb.run(S, t, table_id, lds, false);
+        if (more) {
+            if (tb.terr) { fin = true; more = false; }
+            else {
+                done = tb.flags & PK_FLAG_GAME_OVER; hand = tb.flags & PK_FLAG_HAND_OVER;
+                more = !hand && tb.active != 0;
+            }
+        }
+        vm = tb.valid_mask(high_bet);
+    }
+    if (!fin && hand) rew = tb.payoffs[0];                                         // :47
+    more = !fin && !done && tb.active != 0;                                        // :49
+    while (__any(more)) {
+        if (more) tb.begin_step(S, pick_action(S, rng, table_id, tb.step_serial, vm, opp_policy), high_bet);  // :51-52
+        tb.run(S, t, table_id, lds, false);
+        if (more) {
+            if (tb.terr) { fin = true; more = false; }
+            else { done = tb.flags & PK_FLAG_GAME_OVER; more = !done && tb.active != 0; }
+        }
+        vm = tb.valid_mask(high_bet);
+    }
+    if (!live) return;
+    if (!ok) {
         reward[t] = 0.0; done_out[t] = 0; hand_out[t] = 0;
         S.terr[t] = PK_TERR_INVALID_ACTION; terr[t] = PK_TERR_INVALID_ACTION;
         return;
     }
-    double rew = 0.0;                                                              // :34
-    uint32_t fl = tb.step(S, t, table_id, action, high_bet);                       // :35
-    bool done = fl & PK_FLAG_GAME_OVER, hand = fl & PK_FLAG_HAND_OVER;
-    if (!tb.terr) {
-        if (done || ((tb.st_broken >> 0) & 1)) {                                   // :37-39
-            rew = tb.payoffs[0]; done = true; hand = true;
-        } else {
-            vm = tb.valid_mask(high_bet);
-            while (!hand && tb.active != 0) {                                      // :41-44
-                int a = pick_action(S, table_id, tb.step_serial, vm, opp_policy);
-                tb.hands_this_step = 0;
-                fl = tb.step(S, t, table_id, a, high_bet);
-                if (tb.terr) break;
-                done = fl & PK_FLAG_GAME_OVER; hand = fl & PK_FLAG_HAND_OVER;
-                vm = tb.valid_mask(high_bet);
-            }
-            if (hand) rew = tb.payoffs[0];                                         // :47
-            while (!tb.terr && !done && tb.active != 0) {                          // :49-52
-                int a = pick_action(S, table_id, tb.step_serial, vm, opp_policy);
-                tb.hands_this_step = 0;
-                fl = tb.step(S, t, table_id, a, high_bet);
-                if (tb.terr) break;
-                done = fl & PK_FLAG_GAME_OVER;
-                vm = tb.valid_mask(high_bet);
-            }
-        }
-    }
     tb.store(S, t);
     reward[t] = rew; done_out[t] = done; hand_out[t] = hand;                       // :53
-    S.valid[t] = (uint8_t)tb.valid_mask(high_bet);
+    S.valid[t] = (uint8_t)vm;
     S.terr[t] = (uint8_t)tb.terr; terr[t] = (uint8_t)tb.terr;
 }
 
@@ -288,7 +313,7 @@ __global__ void k_compare(const uint8_t *rank, const uint32_t *kick, int n, size
 }
 // Exhaustive 7-card sweep used by tests (digest definition: tests/golden/make_eval_digest.py): all hands with prefix
 // (a, b); hand index within the prefix -> combination of 5 from the cards above b is decoded per lane.
-__global__ void k_eval7_prefix(int a, int b, uint32_t count, uint32_t *out) {
+__global__ void k_eval7_prefix(int a, int b, int fast, uint32_t count, uint32_t *out) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     // unrank i among 5-subsets of {b+1..51} in lexicographic order
@@ -311,7 +336,7 @@ __global__ void k_eval7_prefix(int a, int b, uint32_t count, uint32_t *out) {
     uint32_t h[7] = {canon(a), canon(b), canon(b + 1 + sel5[0]), canon(b + 1 + sel5[1]), canon(b + 1 + sel5[2]),
                      canon(b + 1 + sel5[3]), canon(b + 1 + sel5[4])};
     int nk;
-    out[i] = eval_hand(h, 7, nk);
+    out[i] = fast ? eval7_distinct(h) : eval_hand(h, 7, nk);  // in-game evaluator / general (multiset) evaluator
 }
 
 // ================================================================================================ host side
@@ -405,8 +430,7 @@ int pk_create(pk_handle **out, int device, int num_tables, int num_players, cons
     if (device < 0 || device >= ndev) { g_err = "pk_create: device index out of range"; return PK_E_INVALID_ARG; }
     pk_handle *h = new pk_handle();
     h->device = device; h->T = num_tables; h->N = num_players; h->dealer = dealer;
-    const char *bs = getenv("PK_BLOCK");
-    if (bs) { int b = atoi(bs); if (b == 64 || b == 128 || b == 256 || b == 512) h->block = b; }
+    h->block = PK_TABLE_BLOCK;
     auto bail = [&](int code) { g_err = h->err; pk_destroy(h); return code; };
     if (hipSetDevice(device) != hipSuccess) return bail(h->fail(PK_E_HIP, "hipSetDevice"));
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return bail(h->fail(PK_E_HIP, "hipStreamCreate"));
@@ -762,7 +786,7 @@ int pk_compare_rankings(int device, const uint8_t *rank, const uint32_t *kick, i
 
 // Test hook (declared in pokerl_hip.h as part of the judger surface): values rank<<20|kick of all 7-card hands whose
 // two lowest canonical indices are (a, b), lexicographic order.  out holds C(51-b, 5) words.
-int pk_eval7_prefix(int device, int a, int b, uint32_t *out, size_t *count_out) {
+int pk_eval7_prefix(int device, int a, int b, int fast, uint32_t *out, size_t *count_out) {
     if (!out || a < 0 || b <= a || b > 51) { g_err = "pk_eval7_prefix: bad argument"; return PK_E_INVALID_ARG; }
     int rc = check_device(device);
     if (rc) return rc;
@@ -773,7 +797,7 @@ int pk_eval7_prefix(int device, int a, int b, uint32_t *out, size_t *count_out) 
     tmp_handle th, *h = &th;
     uint32_t *d = nullptr;
     HIPCHK(h, hipMalloc((void **)&d, count * 4));
-    hipLaunchKernelGGL(k_eval7_prefix, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, 0, a, b, (uint32_t)count, d);
+    hipLaunchKernelGGL(k_eval7_prefix, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, 0, a, b, fast, (uint32_t)count, d);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpy(out, d, count * 4, hipMemcpyDeviceToHost);
     (void)hipFree(d);

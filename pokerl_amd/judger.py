@@ -71,14 +71,15 @@ def compare_hands(hands, device=0):
     return compare_rankings(rankings, device) + (rankings,)
 
 
-def eval7_prefix(a, b, device=0):
-    """Values rank<<20|kick of all 7-card hands whose two lowest canonical indices are (a, b) (exhaustive checks)."""
+def eval7_prefix(a, b, fast=True, device=0):
+    """Values rank<<20|kick of all 7-card hands whose two lowest canonical indices are (a, b) (exhaustive checks).
+    fast=True: the distinct-card evaluator used by the showdown kernels; False: the general evaluator."""
     import ctypes as C
     import math
     n = math.comb(51 - b, 5)
     out = np.zeros(max(n, 1), np.uint32)
     cnt = C.c_size_t(0)
-    L.check(L.lib().pk_eval7_prefix(int(device), int(a), int(b), L.ptr(out), C.byref(cnt)))
+    L.check(L.lib().pk_eval7_prefix(int(device), int(a), int(b), int(bool(fast)), L.ptr(out), C.byref(cnt)))
     return out[:cnt.value]
 
 

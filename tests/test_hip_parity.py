@@ -75,8 +75,10 @@ def test_golden_judger_vectors(HB):
         assert [[r, k] for r, k in out[2]] == case["rankings"]
 
 
-def test_eval7_exhaustive_digest(HB):
-    """All C(52,7) = 133 784 560 hands on the GPU against the digest computed from the imported reference."""
+@pytest.mark.parametrize("fast", [True, False], ids=["showdown_evaluator", "general_evaluator"])
+def test_eval7_exhaustive_digest(HB, fast):
+    """All C(52,7) = 133 784 560 hands on the GPU against the digest computed from the imported reference, for both
+    device evaluators (the bitmask one the showdown kernels use and the general multiset one of pk_eval_hands)."""
     from pokerl_amd import judger
     gold = GU.load_json("eval7_digest")
     GOLD = np.uint64(0x9E3779B97F4A7C15)
@@ -96,7 +98,7 @@ def test_eval7_exhaustive_digest(HB):
                 n = math.comb(51 - b, 5)
                 if n == 0:
                     continue
-                v = judger.eval7_prefix(a, b).astype(np.uint64)
+                v = judger.eval7_prefix(a, b, fast).astype(np.uint64)
                 assert len(v) == n
                 idx = np.arange(n, dtype=np.uint64) + np.uint64(idx0)
                 per_first[a] = (per_first[a] + int(np.sum(mix64(v ^ (idx * GOLD)), dtype=np.uint64))) % (1 << 64)
