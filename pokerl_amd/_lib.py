@@ -6,7 +6,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libpokerl_hip.so")
+LIB_PATH = os.environ.get("POKERL_HIP_LIB") or os.path.join(HERE, "libpokerl_hip.so")  # override: diagnostic builds
 
 PK_OK, PK_E_INVALID_ARG, PK_E_NO_DEVICE, PK_E_HIP, PK_E_OOM, PK_E_TABLE = 0, -1, -2, -3, -4, -5
 TERR_INVALID_ACTION, TERR_NO_WINNER, TERR_HAND_CAP = 1, 2, 4

@@ -28,6 +28,16 @@ def stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def build_prof_lib(verbose=False):
+    """Diagnostic build with s_memtime stamps around the step machine's blocks (tools/block_profile.py); not shipped."""
+    out = os.path.join(HERE, "libpokerl_hip_prof.so")
+    cmd = [hipcc()] + FLAGS + ["-DPK_PROFILE"] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", out]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return out
+
+
 def build_lib(force=False, verbose=False):
     if not force and not stale():
         return LIB
@@ -41,3 +51,5 @@ def build_lib(force=False, verbose=False):
 if __name__ == "__main__":
     import sys
     build_lib(force="--force" in sys.argv, verbose=True)
+    if "--prof" in sys.argv:
+        build_prof_lib(verbose=True)

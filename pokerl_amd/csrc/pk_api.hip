@@ -99,6 +99,7 @@ __global__ void __launch_bounds__(PK_TABLE_BLOCK) k_rollout(State S, int K, int 
     ActionRng rng;
     double high_bet;
     uint32_t mask = tb.valid_mask(high_bet);
+    PK_PROF(tb.prof.start();)
     for (int k = 0; k < K; ++k) {
         if (alive) tb.begin_step(S, pick_action(S, rng, table_id, tb.step_serial, mask, policy), high_bet);
         tb.run(S, t, table_id, lds, auto_reset != 0);
@@ -114,6 +115,7 @@ __global__ void __launch_bounds__(PK_TABLE_BLOCK) k_rollout(State S, int K, int 
         S.terr[t] = (uint8_t)(tb.terr | tb.seen);
     }
     wave_add_counters(S, steps, tb.hand_serial - hs0, tb.evals, tb.games);  // every lane takes part in the shuffles
+    PK_PROF(tb.prof.flush(S.prof);)
 }
 
 // PokerGameEnv.reset, envs/game_env.py:20-29
@@ -442,7 +444,7 @@ int pk_create(pk_handle **out, int device, int num_tables, int num_players, cons
     size_t obs = (size_t)PK_OBS_DIM(N) * 8;
     h->export_bytes = al(T * (obs > N * 8 ? obs : N * 8));
     size_t total = 4 * al(T * N * 8) + al(T * 8) + al(T * 8) + 4 * al(T * 4) + al(W * T * 4) + al(N * T * 4) + 2 * al(T) +
-                   al(PK_NUM_COUNTERS * 8) + al(T * 4) + 5 * al(T) + al(T * 8) + h->export_bytes;
+                   al(PK_NUM_COUNTERS * 8) + al(PF_SLOTS * 8) + al(T * 4) + 5 * al(T) + al(T * 8) + h->export_bytes;
     e = hipMalloc(&h->arena, total);
     if (e != hipSuccess) return bail(h->fail(PK_E_OOM, "hipMalloc(table state)", e));
     if (hipMemsetAsync(h->arena, 0, total, h->stream) != hipSuccess) return bail(h->fail(PK_E_HIP, "hipMemset"));
@@ -459,6 +461,7 @@ int pk_create(pk_handle **out, int device, int num_tables, int num_players, cons
     S.show = (uint32_t *)take(N * T * 4);
     S.valid = (uint8_t *)take(T); S.terr = (uint8_t *)take(T);
     S.counters = (unsigned long long *)take(PK_NUM_COUNTERS * 8);
+    S.prof = (unsigned long long *)take(PF_SLOTS * 8);
     h->d_actions = (int32_t *)take(T * 4);
     h->d_flags = (uint8_t *)take(T); h->d_terr = (uint8_t *)take(T); h->d_mask = (uint8_t *)take(T);
     h->d_done = (uint8_t *)take(T); h->d_handf = (uint8_t *)take(T);
@@ -717,6 +720,18 @@ int pk_env_step(pk_handle *h, const int32_t *actions, int opp_policy, double *re
     if (any_terr(te.data(), h->T)) return h->fail(PK_E_TABLE, "pk_env_step: per-table error(s), see terr");
     return PK_OK;
 }
+
+#ifdef PK_PROFILE
+// Diagnostic library only: read and clear the per-block cycle sums (slots: pk_device.hpp PF_*).
+int pk_prof_read(pk_handle *h, unsigned long long *out) {
+    if (!h || !out) return PK_E_INVALID_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemcpyAsync(out, h->S.prof, PF_SLOTS * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->S.prof, 0, PF_SLOTS * 8, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return PK_OK;
+}
+#endif
 
 int pk_sync(pk_handle *h) {
     if (!h) return PK_E_INVALID_ARG;

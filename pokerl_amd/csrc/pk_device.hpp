@@ -2,7 +2,9 @@
 // VGPRs (compile-time-indexed arrays, seat states as bitmasks), money in IEEE binary64 in the reference's operation
 // order (translation unit is built with -ffp-contract=off).  Citations: paths relative to the reference root.
 #pragma once
+#ifndef PK_HOST_SIM  // tools/host_sim (dev-only CPU build of this header) supplies shims instead
 #include <hip/hip_runtime.h>
+#endif
 #include <stdint.h>
 
 #include <type_traits>
@@ -34,6 +36,7 @@ struct State {
     uint8_t *valid;                              // [T]      valid-action bitmask of the active player (game.py:339-383)
     uint8_t *terr;                               // [T]      PK_TERR_* of the last call
     unsigned long long *counters;                // [PK_NUM_COUNTERS]
+    unsigned long long *prof;                    // [PF_SLOTS], diagnostic build only
     double start_credits[PK_MAX_PLAYERS];
     double big_blind, small_blind;
     uint32_t key0, key1, table_id_base;
@@ -210,18 +213,29 @@ __device__ inline uint32_t eval_hand(const uint32_t (&c)[7], int n, int &nk) {
 }
 
 // judger.compare_rankings (judger.py:111-158) over values v[p] = rank<<20|kick; returns the winners bitmask.
-// Line 148 (`kicker = best_kicker`) never raises best_kicker: reproduced.
+// The reference walks the list keeping best_rank / best_kicker / winners; its line 148 (`kicker = best_kicker`) never
+// raises best_kicker, so best_kicker stays the kicker k0 of the FIRST hand holding the best rank:
+//   a later hand with kicker > k0 replaces the winners list, one with kicker == k0 is appended.
+// Closed form: E = {best rank, kicker == k0}, G = {best rank, kicker > k0};  G empty -> E;  else the LAST seat g of G
+// plus the seats of E after g.
 template <int N>
 __device__ __forceinline__ uint32_t compare_rankings(const uint32_t (&v)[N], int &nw) {
-    uint32_t best_rank = HR_NONE, best_kicker = 0, win = 0;
+    uint32_t best_rank = HR_NONE;
+    PK_FOR(p, N) best_rank = min(best_rank, v[p] >> 20); PK_END                    // :140 (lower rank number wins)
+    uint32_t k0 = 0; bool have = false;                                            // initial best_kicker = 0 (:135)
     PK_FOR(p, N)
-        uint32_t rank = v[p] >> 20, kicker = v[p] & 0xFFFFF;
-        if (rank < best_rank) { best_rank = rank; best_kicker = kicker; win = 1u << p; }   // :140-144
-        else if (rank == best_rank) {
-            if (kicker > best_kicker) win = 1u << p;                                        // :146-149
-            else if (kicker == best_kicker) win |= 1u << p;                                 // :150-152
-        }
-     PK_END
+        bool first = !have && (v[p] >> 20) == best_rank;
+        k0 = first ? (v[p] & 0xFFFFF) : k0; have = have || first;
+    PK_END
+    uint32_t E = 0, G = 0;
+    PK_FOR(p, N)
+        bool br = (v[p] >> 20) == best_rank;
+        uint32_t k = v[p] & 0xFFFFF;
+        E |= (br && k == k0) ? (1u << p) : 0;
+        G |= (br && k > k0) ? (1u << p) : 0;
+    PK_END
+    uint32_t g = 31 - __clz((int)G);
+    uint32_t win = G ? ((1u << g) | (E & ~((2u << g) - 1))) : E;
     nw = __popc(win);
     return win;
 }
@@ -309,6 +323,28 @@ __device__ __forceinline__ uint32_t eval7_distinct(const uint32_t (&c)[7]) {
 //            the whole wave runs the block together; showdown hands of all parked lanes are compacted through LDS and
 //            evaluated one hand per lane (eval7_distinct).
 enum : int { LS_DONE = 0, LS_SCAN = 1, LS_TURN = 2, LS_END = 3 };
+#ifndef PK_WAVE
+#define PK_WAVE 64  // lanes per wavefront on gfx950 (tools/host_sim builds this header with 1)
+#endif
+
+// Diagnostic build only (-DPK_PROFILE, libpokerl_hip_prof.so; never the shipped library): per-wave cycle stamps
+// (s_memtime) around the blocks of the step machine, summed into State::prof.  Shares, not run times, are read from it.
+enum : int { PF_ACTION = 0, PF_CURSOR = 1, PF_END_PRE = 2, PF_EVAL = 3, PF_SIDEPOT = 4, PF_SETUP = 5, PF_DEAL = 6, PF_OTHER = 7,
+             PF_N_CURSOR = 8, PF_N_END = 9, PF_N_EVALPASS = 10, PF_N_SIDEPOT = 11, PF_SLOTS = 12 };
+#ifdef PK_PROFILE
+struct Prof {
+    unsigned long long acc[PF_SLOTS] = {0}, t0 = 0;
+    __device__ __forceinline__ void start() { t0 = __builtin_readcyclecounter(); }
+    __device__ __forceinline__ void lap(int slot) { unsigned long long t = __builtin_readcyclecounter(); acc[slot] += t - t0; t0 = t; }
+    __device__ __forceinline__ void count(int slot, unsigned n = 1) { acc[slot] += n; }
+    __device__ __forceinline__ void flush(unsigned long long *dst) {
+        if ((threadIdx.x & 63) == 0) for (int i = 0; i < PF_SLOTS; ++i) atomicAdd(&dst[i], acc[i]);
+    }
+};
+#define PK_PROF(x) x
+#else
+#define PK_PROF(x)
+#endif
 
 template <int N>
 struct Lds {  // per workgroup (= one wavefront); ~10 KB at N = 10
@@ -355,6 +391,7 @@ struct Table {
     bool foldout;
     // counters since load
     uint32_t evals, games, seen;
+    PK_PROF(Prof prof;)
 
     __device__ __forceinline__ void load(const State &S, int t) {
         PK_FOR(p, N)
@@ -532,23 +569,29 @@ struct Table {
     }
 
     // LS_SCAN / LS_TURN until this lane is DONE or parked at LS_END (one pass; the caller loops wave-wide).
+    __device__ __forceinline__ void scan() {                                       // game.py:607-611
+        int d = current - active; d = d < 0 ? d + N : d;                           // seats active..current (cyclic)
+        uint32_t window = rotr(st_active, active) & ((2u << d) - 1);
+        int a = active + (__ffs(window) - 1); a = a >= N ? a - N : a;
+        active = window ? a : current;                                             // else: walked up to current_player
+        lstate = window ? LS_DONE : LS_TURN;                                       //       -> next_turn()
+    }
     __device__ __forceinline__ void cursor_pass() {
-        if (lstate == LS_SCAN) {                                                   // game.py:607-611
-            int d = current - active; d = d < 0 ? d + N : d;                       // seats active..current (cyclic)
-            uint32_t window = rotr(st_active, active) & ((2u << d) - 1);
-            if (window) { int a = active + (__ffs(window) - 1); active = a >= N ? a - N : a; lstate = LS_DONE; }
-            else { active = current; lstate = LS_TURN; }                           // walked up to current_player -> next_turn()
-        }
+        if (lstate == LS_SCAN) scan();
         if (lstate == LS_TURN) {                                                   // game.py:554-576
-            PK_FOR(p, N) bets[p] = bets[p] + pending[p]; credits[p] = credits[p] - pending[p]; pending[p] = 0.0;  PK_END
+            PK_FOR(p, N) bets[p] = bets[p] + pending[p]; credits[p] = credits[p] - pending[p]; pending[p] = 0.0; PK_END
             min_raise = 0.0;
             turn += 1;                                                             // :561
+            if (turn < 4 && __popc(st_called) > 1) { st_active |= st_called; st_called = 0; }  // :566-572 (else-branch of turn == 4)
+            // Run-out: nobody is ACTIVE and nobody will be re-activated, so every later next_turn() before turn 4 only
+            // commits zero pending bets (x + 0.0 == x) and bumps `turn`; the walk cannot stop before end_hand().
+            if (st_active == 0) turn = 4;
             if (turn == 4) { lstate = LS_END; foldout = false; }                   // :563-565
             else {
-                if (__popc(st_called) > 1) { st_active |= st_called; st_called = 0; }  // :567-572
                 active = first_playing(dealer + 1);                                // :575
                 flags = PK_FLAG_TURN_OVER;                                         // :576
                 lstate = LS_SCAN;
+                scan();
             }
         }
     }
@@ -558,6 +601,7 @@ struct Table {
     // Game.reset() on the spot, as the rollout/bench loop does on the host side of the reference.
     __device__ __forceinline__ void end_block(const State &S, int t, uint32_t table_id, Lds<N> &lds, bool auto_reset) {
         const bool e = lstate == LS_END;
+        PK_PROF(prof.lap(PF_OTHER); prof.count(PF_N_END);)
         bool sd = false, nowin = false;
         uint32_t showdown = 0;
         int npw = 0;
@@ -570,6 +614,9 @@ struct Table {
             uint32_t pw = (st_active | st_called | st_allin) & FULL;               // :471 (not BROKEN, not FOLDED)
             npw = __popc(pw);                                                      // :472
             nowin = npw <= 0;                                                      // :473
+#ifdef PK_HOST_SIM_DEBUG
+            printf("  end t=%d foldout=%d turn=%d npw=%d act=%x call=%x allin=%x broke=%x bets0=%g bets1=%g hands=%d\n", t, (int)foldout, turn, npw, st_active, st_called, st_allin, st_broken, bets[0], bets[1], hands_this_step);
+#endif
             if (npw == 1) {                                                        // :475-480
                 int winner = __ffs(pw) - 1;
                 double pot = np_sum<N>(bets);
@@ -582,6 +629,7 @@ struct Table {
                 showdown = (st_called | st_allin) & FULL;                          // :488, :496
             }
         }
+        PK_PROF(prof.lap(PF_END_PRE);)
         // ---- showdown hands of all parked lanes -> LDS queue -> one hand per lane (game.py:488-489)
         const int lane = threadIdx.x & 63;
         uint32_t total = 0, my_base[N];
@@ -600,7 +648,8 @@ struct Table {
                 }
              PK_END
             __syncthreads();
-            for (uint32_t base = 0; base < total; base += 64) {
+            for (uint32_t base = 0; base < total; base += PK_WAVE) {
+                PK_PROF(prof.count(PF_N_EVALPASS);)
                 uint32_t i = base + lane;
                 if (i < total) {
                     uint32_t w0 = lds.item[i][0], w1 = lds.item[i][1];
@@ -613,6 +662,7 @@ struct Table {
             __syncthreads();  // the queue is reused by the next end_block of this wave
             evals += __popc(showdown);
         }
+        PK_PROF(prof.lap(PF_EVAL);)
         if (sd) {
             double wb[N];                                                          // :485
             PK_FOR(p, N)
@@ -622,40 +672,44 @@ struct Table {
              PK_END
             uint32_t todo = showdown;                                              // :495-496 argsort(bets) filtered, stable
             while (todo) {                                                         // :498
-                int player = 0; double best = 0.0; bool have = false;
-                PK_FOR(p, N)                                      // next in ascending original-bet order
-                    bool cand = (todo >> p) & 1;
-                    bool better = cand && (!have || bets[p] < best);
-                    player = better ? p : player; best = better ? bets[p] : best; have = have || cand;
-                 PK_END
-                todo &= ~(1u << player);
+                PK_PROF(prof.count(PF_N_SIDEPOT);)
                 bool any_pos = false;
                 PK_FOR(p, N) any_pos = any_pos || !(wb[p] <= 0.0); PK_END
-                if (!any_pos) break;                                               // :499
+                if (!any_pos) break;                                               // :499 (independent of which seat is next)
+                int player = 0; double best = 0.0, max_bet = 0.0; bool have = false;
+                PK_FOR(p, N)                                                       // next seat in ascending ORIGINAL-bet order
+                    bool cand = (todo >> p) & 1;
+                    bool better = cand && (!have || bets[p] < best);
+                    player = better ? p : player; best = better ? bets[p] : best; max_bet = better ? wb[p] : max_bet;  // :508
+                    have = have || cand;
+                PK_END
+                todo &= ~(1u << player);
                 if (npw == 1) {                                                    // :500-505
                     double s = np_sum<N>(wb);
-                    put<N>(payoffs, player, sel<N>(payoffs, player) + s);
+                    PK_FOR(p, N) payoffs[p] = (p == player) ? payoffs[p] + s : payoffs[p]; PK_END
                     break;
                 }
-                double max_bet = sel<N>(wb, player), mb[N];                        // :508-509 np.clip(bets, 0, max_bet)
-                PK_FOR(p, N) double x = wb[p]; x = (x < 0.0) ? 0.0 : x; x = (x > max_bet) ? max_bet : x; mb[p] = x;  PK_END
+                double mb[N];                                                      // :509 np.clip(bets, 0, max_bet)
+                PK_FOR(p, N) double x = wb[p]; x = (x < 0.0) ? 0.0 : x; x = (x > max_bet) ? max_bet : x; mb[p] = x; PK_END
                 int nw;
                 uint32_t win = compare_rankings<N>(hv, nw);                        // :512
                 double s = np_sum<N>(mb);
-                if (nw == 1) {                                                     // :515
-                    PK_FOR(p, N) payoffs[p] = ((win >> p) & 1) ? payoffs[p] + s : payoffs[p]; PK_END
-                } else {                                                           // :516  sum * onehot / sum(onehot)
-                    double k = (double)nw;
-                    PK_FOR(p, N) payoffs[p] = payoffs[p] + (s * (((win >> p) & 1) ? 1.0 : 0.0)) / k; PK_END
-                }
-                PK_FOR(p, N)                                      // :522-523
-                    hv[p] = (p == player) ? NONE_V : hv[p];
-                    wb[p] = wb[p] - mb[p];
-                 PK_END
+                // :515 single winner: += s.  :516 split: += s*onehot/k, i.e. s/k for winners ((s*1.0)/k == s/k) and
+                // (s*0.0)/k == +0.0 for the rest (s >= 0), which leaves a non-negative payoff unchanged bit for bit.
+                double share = (nw == 1) ? s : s / (double)nw;
+#ifdef PK_HOST_SIM_DEBUG
+                printf("  sidepot t=%d player=%d max_bet=%g s=%g win=%x nw=%d npw=%d hv0=%x hv1=%x wb0=%g wb1=%g\n", t, player, max_bet, s, win, nw, npw, hv[0], hv[1], wb[0], wb[1]);
+#endif
+                PK_FOR(p, N)
+                    payoffs[p] = ((win >> p) & 1) ? payoffs[p] + share : payoffs[p];
+                    hv[p] = (p == player) ? NONE_V : hv[p];                        // :522
+                    wb[p] = wb[p] - mb[p];                                         // :523
+                PK_END
                 npw -= 1;                                                          // :525
             }
             PK_FOR(p, N) credits[p] = credits[p] + payoffs[p]; PK_END  // :528
         }
+        PK_PROF(prof.lap(PF_SIDEPOT);)
         if (e) {
             if (nowin) {                                                           // :473 assert (state left as the reference leaves it)
                 terr |= PK_TERR_NO_WINNER; lstate = LS_DONE;
@@ -682,18 +736,23 @@ struct Table {
                     hand_serial += 1;      // the deck setup_hand() shuffled for the dead game is never looked at
                     reset_state(S, 0);
                 }
+                PK_PROF(prof.lap(PF_SETUP);)
                 deal(S, table_id);                                                 // :424
             }
         }
+        PK_PROF(prof.lap(PF_DEAL);)
     }
 
     // Runs the machine until every lane of the wave is DONE.  Must be called from wave-uniform control flow.
     __device__ __forceinline__ void run(const State &S, int t, uint32_t table_id, Lds<N> &lds, bool auto_reset) {
+        PK_PROF(prof.lap(PF_ACTION);)
         for (;;) {
-            while (__any(lstate == LS_SCAN || lstate == LS_TURN)) cursor_pass();
+            while (__any(lstate == LS_SCAN || lstate == LS_TURN)) { cursor_pass(); PK_PROF(prof.count(PF_N_CURSOR);) }
+            PK_PROF(prof.lap(PF_CURSOR);)
             if (!__any(lstate == LS_END)) break;
             end_block(S, t, table_id, lds, auto_reset);
         }
+        PK_PROF(prof.lap(PF_OTHER);)
         step_serial += (terr & PK_TERR_NO_WINNER) ? 0 : stepped;  // RNG spec: one serial per COMPLETED Game.step
         stepped = 0;
     }

@@ -1,0 +1,83 @@
+// Dev-only host simulation of the device step machine (one table per "wave") diffed against the CPU oracle.
+//   g++ -std=c++20 -O1 -ffp-contract=off -I. tools/host_sim/host_sim.cpp oracle/pokerl_oracle.c -o /tmp/host_sim
+#include "hip_shim.h"
+#define hip_runtime_h_shimmed
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+// keep pk_device.hpp from including the real HIP runtime
+#define HIP_INCLUDE_HIP_HIP_RUNTIME_H
+#include "../../pokerl_amd/csrc/pk_device.hpp"
+extern "C" {
+#include "../../oracle/pokerl_oracle.h"
+}
+using namespace pk;
+
+template <int N>
+static int run(int T, int K, int policy, uint64_t seed) {
+    const int KK = 5 + 2 * N, W = (KK + 3) / 4;
+    std::vector<double> cr(N * T), be(N * T), pe(N * T), pa(N * T), mr(T);
+    std::vector<uint64_t> ss(T, (1u << N) - 1);
+    std::vector<uint32_t> cur(T), hs(T), st(T), cards(W * T), show(N * T, NONE_V);
+    std::vector<int32_t> hand(T);
+    std::vector<uint8_t> valid(T), terr(T);
+    unsigned long long counters[4] = {0}, prof[16] = {0};
+    State S{};
+    S.credits = cr.data(); S.bets = be.data(); S.pending = pe.data(); S.payoffs = pa.data(); S.min_raise = mr.data();
+    S.seat_states = ss.data(); S.cursors = cur.data(); S.hand = hand.data(); S.hand_serial = hs.data(); S.step_serial = st.data();
+    S.cards = cards.data(); S.show = show.data(); S.valid = valid.data(); S.terr = terr.data(); S.counters = counters; S.prof = prof;
+    for (int p = 0; p < N; ++p) S.start_credits[p] = 100.0;
+    S.big_blind = 2; S.small_blind = 1; S.key0 = (uint32_t)seed; S.key1 = (uint32_t)(seed >> 32); S.table_id_base = 0; S.T = T;
+    double sc[16]; for (int p = 0; p < 16; ++p) sc[p] = 100.0;
+    orc_game *o = orc_create(T, N, sc, 2, 1, seed, 0);
+    orc_reset(o, nullptr, 0);
+    static Lds<N> lds;
+    std::vector<Table<N>> tb(T);
+    for (int t = 0; t < T; ++t) { tb[t].load(S, t); tb[t].reset_state(S, 0); tb[t].deal(S, (uint32_t)t); tb[t].store(S, t); }
+    std::vector<double> oc(N * T), ob(N * T), op(N * T), oy(N * T);
+    std::vector<uint8_t> ost(N * T);
+    std::vector<int32_t> ocur(6 * T);
+    for (int k = 0; k < K; ++k) {
+        uint64_t c4[4] = {0};
+        orc_rollout(o, 1, policy, 1, c4);
+        for (int t = 0; t < T; ++t) {
+            Table<N> &x = tb[t];
+            x.load(S, t);
+            double hb; uint32_t mask = x.valid_mask(hb);
+            ActionRng rng;
+            x.begin_step(S, pick_action(S, rng, (uint32_t)t, x.step_serial, mask, policy), hb);
+            x.run(S, t, (uint32_t)t, lds, true);
+            x.store(S, t);
+        }
+        orc_get_f64(o, 0, oc.data()); orc_get_f64(o, 1, ob.data()); orc_get_f64(o, 2, op.data()); orc_get_f64(o, 3, oy.data());
+        orc_get_states(o, ost.data()); orc_get_cursors(o, ocur.data());
+        for (int t = 0; t < T; ++t)
+            for (int p = 0; p < N; ++p) {
+                bool bad = memcmp(&oc[t * N + p], &cr[(size_t)p * T + t], 8) || memcmp(&ob[t * N + p], &be[(size_t)p * T + t], 8) ||
+                           memcmp(&op[t * N + p], &pe[(size_t)p * T + t], 8) || memcmp(&oy[t * N + p], &pa[(size_t)p * T + t], 8);
+                uint64_t s = ss[t];
+                int stt = ((s >> p) & 1) ? 1 : ((s >> (16 + p)) & 1) ? 2 : ((s >> (32 + p)) & 1) ? 3 : ((s >> (48 + p)) & 1) ? 4 : 0;
+                bad = bad || stt != ost[t * N + p] || (int)(cur[t] & 0xf) != ocur[6 * t];
+                if (bad) {
+                    printf("MISMATCH N=%d step %d table %d seat %d: credits %.17g/%.17g bets %.17g/%.17g pend %.17g/%.17g pay %.17g/%.17g state %d/%d active %d/%d turn %d/%d\n",
+                           N, k, t, p, oc[t * N + p], cr[(size_t)p * T + t], ob[t * N + p], be[(size_t)p * T + t], op[t * N + p], pe[(size_t)p * T + t],
+                           oy[t * N + p], pa[(size_t)p * T + t], ost[t * N + p], stt, ocur[6 * t], cur[t] & 0xf, ocur[6 * t + 1], (cur[t] >> 16) & 0xf);
+                    return 1;
+                }
+            }
+    }
+    printf("N=%d T=%d K=%d policy=%d: host-sim == oracle\n", N, T, K, policy);
+    orc_destroy(o);
+    return 0;
+}
+
+int main(int argc, char **argv) {
+    int T = argc > 1 ? atoi(argv[1]) : 256, K = argc > 2 ? atoi(argv[2]) : 400;
+    int rc = 0;
+    rc |= run<2>(T, K, 0, 0x706F6B65726Cull);
+    rc |= run<6>(T, K, 0, 0x706F6B65726Cull);
+    rc |= run<9>(T, K, 1, 0x706F6B65726Cull);
+    rc |= run<3>(T, K, 0, 7);
+    rc |= run<10>(T, K, 0, 99);
+    return rc;
+}

@@ -1,0 +1,16 @@
+#!/bin/bash
+# Runs ON THE GPU BOX (via gpurun): kernel trace + separate PMC passes of the bench command.  Output: gpurun_out/prof_<tag>/
+# usage: tools/profile_gpu.sh <tag> [bench args...]
+set -u
+TAG=$1; shift
+ROOT=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$ROOT/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+ARGS="--steps 2048 --warmup 256 --no-cpu-baseline $*"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py $ARGS > $OUT/trace.log 2>&1 || echo "trace failed"
+for C in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE SQ_THREAD_CYCLES_VALU SQ_LDS_BANK_CONFLICT"; do
+  N=$(echo $C | tr ' ' '_' | cut -c1-40)
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$N -- python3 $ROOT/bench.py $ARGS > $OUT/pmc_$N.log 2>&1 || echo "pmc $C failed"
+done
+find $OUT -name "*.csv" | head -50
