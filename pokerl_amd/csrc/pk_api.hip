@@ -84,9 +84,14 @@ __global__ void __launch_bounds__(PK_TABLE_BLOCK) k_pick(State S, int policy, in
     actions[t] = pick_action(S, rng, S.table_id_base + (uint32_t)t, S.step_serial[t], S.valid[t], policy);
 }
 
-// K lockstep steps, in-kernel agents, table state in registers for the whole launch (K == 1: the unfused form).
+// K steps per table, in-kernel agents, table state in registers for the whole launch (K == 1: the unfused form).
+// Tables are independent, so lanes need not stay in lockstep INSIDE the launch: a lane whose step reaches end_hand
+// parks at LS_END while the other lanes of the wave run ahead on their own step counters; the expensive end_block
+// (showdown + side pots + setup_hand + deal) runs only once `park` lanes are waiting (or nobody else can run), which
+// raises its lane utilisation from ~25 % to ~60 %.  Every table still makes exactly K steps with the actions the RNG
+// spec assigns to (table, step_serial), so the state after the launch is bit-identical to the lockstep order.
 template <int N>
-__global__ void __launch_bounds__(PK_TABLE_BLOCK) k_rollout(State S, int K, int policy, int auto_reset) {
+__global__ void __launch_bounds__(PK_TABLE_BLOCK) k_rollout(State S, int K, int policy, int auto_reset, int park) {
     __shared__ Lds<N> lds;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = t < S.T;
@@ -95,23 +100,40 @@ __global__ void __launch_bounds__(PK_TABLE_BLOCK) k_rollout(State S, int K, int 
     if (live) tb.load(S, t); else tb.blank();
     const uint32_t hs0 = tb.hand_serial;
     uint32_t steps = 0;
+    int kdone = 0;
     bool alive = live;
     ActionRng rng;
     double high_bet;
-    uint32_t mask = tb.valid_mask(high_bet);
     PK_PROF(tb.prof.start();)
-    for (int k = 0; k < K; ++k) {
-        if (alive) tb.begin_step(S, pick_action(S, rng, table_id, tb.step_serial, mask, policy), high_bet);
-        tb.run(S, t, table_id, lds, auto_reset != 0);
-        if (alive) {
+    auto retire = [&]() {  // a lane whose Game.step() has returned
+        if (tb.stepped && tb.lstate == LS_DONE) {
+            tb.finish_step();
+            ++kdone;
             if (tb.terr) alive = false;  // table keeps its (reference-identical) state; reported through terr
             else ++steps;
         }
-        mask = tb.valid_mask(high_bet);
+    };
+    for (;;) {
+        if (alive && tb.lstate == LS_DONE && kdone < K) {
+            uint32_t mask = tb.valid_mask(high_bet);
+            tb.begin_step(S, pick_action(S, rng, table_id, tb.step_serial, mask, policy), high_bet);
+        }
+        PK_PROF(tb.prof.lap(PF_ACTION);)
+        tb.cursor();
+        PK_PROF(tb.prof.count(PF_N_CURSOR);)
+        retire();
+        PK_PROF(tb.prof.lap(PF_CURSOR);)
+        const int parked = __popcll(__ballot(tb.lstate == LS_END));
+        const int runnable = __popcll(__ballot(alive && tb.lstate == LS_DONE && kdone < K));
+        if (parked == 0 && runnable == 0) break;
+        if (parked >= park || runnable == 0) {
+            tb.end_block(S, t, table_id, lds, auto_reset != 0);
+            retire();
+        }
     }
     if (live) {
         tb.store(S, t);
-        S.valid[t] = (uint8_t)mask;
+        S.valid[t] = (uint8_t)tb.valid_mask(high_bet);
         S.terr[t] = (uint8_t)(tb.terr | tb.seen);
     }
     wave_add_counters(S, steps, tb.hand_serial - hs0, tb.evals, tb.games);  // every lane takes part in the shuffles
@@ -346,6 +368,7 @@ static thread_local std::string g_err;
 
 struct pk_handle {
     int device = 0, T = 0, N = 0, Tpad = 0, block = 64, dealer = 0;
+    int park = 40;  // lanes parked at end_hand before a wave runs end_block (k_rollout); tuning knob PK_PARK
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     State S{};
@@ -433,6 +456,7 @@ int pk_create(pk_handle **out, int device, int num_tables, int num_players, cons
     pk_handle *h = new pk_handle();
     h->device = device; h->T = num_tables; h->N = num_players; h->dealer = dealer;
     h->block = PK_TABLE_BLOCK;
+    if (const char *pk = getenv("PK_PARK")) { int v = atoi(pk); if (v >= 1 && v <= 64) h->park = v; }
     auto bail = [&](int code) { g_err = h->err; pk_destroy(h); return code; };
     if (hipSetDevice(device) != hipSuccess) return bail(h->fail(PK_E_HIP, "hipSetDevice"));
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return bail(h->fail(PK_E_HIP, "hipStreamCreate"));
@@ -644,9 +668,9 @@ int pk_pick_actions(pk_handle *h, int policy, int32_t *actions) {
 
 static int launch_rollout(pk_handle *h, int k_steps, int policy, int auto_reset, int fused) {
     if (fused) {
-        DISPATCH_N(h, k_rollout, table_grid(h), h->S, k_steps, policy, auto_reset);
+        DISPATCH_N(h, k_rollout, table_grid(h), h->S, k_steps, policy, auto_reset, h->park);
     } else {
-        for (int k = 0; k < k_steps; ++k) DISPATCH_N(h, k_rollout, table_grid(h), h->S, 1, policy, auto_reset);
+        for (int k = 0; k < k_steps; ++k) DISPATCH_N(h, k_rollout, table_grid(h), h->S, 1, policy, auto_reset, h->park);
     }
     HIPCHK(h, hipGetLastError());
     return PK_OK;

@@ -317,12 +317,11 @@ __device__ __forceinline__ uint32_t eval7_distinct(const uint32_t (&c)[7]) {
 // One table per lane.  Game.step's nested calls (next_player -> next_turn -> end_hand -> setup_hand, game.py:578-619)
 // are flattened into a per-lane state machine so that a wavefront executes each expensive block ONCE per step for all
 // the lanes that need it, instead of once per call site and per lane-divergent path:
-//   LS_SCAN  the `while states[active] != ACTIVE` walk of next_player (game.py:607-611), O(1) with seat bitmasks
-//   LS_TURN  next_turn's commit / turn roll-over (game.py:554-576)
+//   LS_SCAN  next_player's walk to the next ACTIVE seat incl. next_turn's commit / turn roll-over (game.py:554-611)
 //   LS_END   end_hand + setup_hand (game.py:453-539, 414-451): lanes park here until no lane is in SCAN/TURN, then
 //            the whole wave runs the block together; showdown hands of all parked lanes are compacted through LDS and
 //            evaluated one hand per lane (eval7_distinct).
-enum : int { LS_DONE = 0, LS_SCAN = 1, LS_TURN = 2, LS_END = 3 };
+enum : int { LS_DONE = 0, LS_SCAN = 1, LS_END = 3 };
 #ifndef PK_WAVE
 #define PK_WAVE 64  // lanes per wavefront on gfx950 (tools/host_sim builds this header with 1)
 #endif
@@ -543,57 +542,65 @@ struct Table {
     }
 
     // Game.step up to the call of next_player (game.py:656-699) for an action already checked against the mask.
+    // Branch-free: every lane of the wave takes a different action, so the three arms are merged into selects.
     __device__ __forceinline__ void begin_step(const State &S, int action, double high_bet) {
         const int a = active;
+        const uint32_t b = 1u << a;
         hands_this_step = 0; terr = 0; flags = 0; stepped = 1;
-        if (action == MV_FOLD) set_state(a, PS_FOLDED);                            // :656-657
-        else if (action == MV_CHECK) set_state(a, PS_CALLED);                      // :659-660
-        else {
-            double bet_value = (S.big_blind > high_bet) ? S.big_blind : high_bet;  // :665 max(high_bet, big_blind)
-            double credit = sel<N>(credits, a);                                    // :666
-            double f = action == 3 ? 0.1 : (action == 4 ? 0.25 : 0.5);             // :676
-            double raised = bet_value + (credit - bet_value) * f;                  // :675-678
-            bool is_raise = action >= MV_RAISE_ANY && action < MV_ALL_IN;
-            bet_value = (action == MV_ALL_IN) ? credit : (is_raise ? raised : bet_value);  // :669-678
-            if (bet_value > high_bet) {                                            // :680-687
-                st_active |= st_called; st_called = 0;
-                min_raise = bet_value - high_bet;
-            }
-            set_state(a, action == MV_ALL_IN ? PS_ALL_IN : PS_CALLED);             // :667,:671,:684
-            put<N>(pending, a, bet_value);                                         // :696
-        }
+        const bool money = action >= MV_CALL;                                      // :662 (CALL / RAISE* / ALL_IN)
+        const double credit = sel<N>(credits, a);                                  // :666
+        const double base = (S.big_blind > high_bet) ? S.big_blind : high_bet;     // :665 max(high_bet, big_blind)
+        const double f = action == 3 ? 0.1 : (action == 4 ? 0.25 : 0.5);           // :676
+        const double raised = base + (credit - base) * f;                          // :675-678
+        const bool is_raise = action >= MV_RAISE_ANY && action < MV_ALL_IN;
+        const double bet_value = (action == MV_ALL_IN) ? credit : (is_raise ? raised : base);  // :669-678
+        const bool raises = money && bet_value > high_bet;                         // :680
+        st_active |= raises ? st_called : 0;                                       // :683 CALLED -> ACTIVE
+        st_called = raises ? 0 : st_called;
+        min_raise = raises ? bet_value - high_bet : min_raise;                     // :687
+        st_active &= ~b; st_called &= ~b; st_allin &= ~b; st_broken &= ~b;         // player_states[a] = ...
+        st_allin |= (action == MV_ALL_IN) ? b : 0;                                 // :671
+        st_called |= (action != MV_FOLD && action != MV_ALL_IN) ? b : 0;           // :660, :667 (FOLD: in no mask, :657)
+        PK_FOR(p, N) pending[p] = (money && p == a) ? bet_value : pending[p]; PK_END  // :696
         // next_player's entry (game.py:598-605,616-619)
-        uint32_t playing = (st_active | st_called | st_allin) & FULL;
-        if (__popc(playing) > 1) { current = a; active = (a + 1 == N) ? 0 : a + 1; lstate = LS_SCAN; }
-        else { lstate = LS_END; foldout = true; }
+        const bool many = __popc((st_active | st_called | st_allin) & FULL) > 1;
+        current = a;
+        active = many ? ((a + 1 == N) ? 0 : a + 1) : a;
+        lstate = many ? LS_SCAN : LS_END;
+        foldout = !many;
     }
 
-    // LS_SCAN / LS_TURN until this lane is DONE or parked at LS_END (one pass; the caller loops wave-wide).
-    __device__ __forceinline__ void scan() {                                       // game.py:607-611
+    // The `while states[active] != ACTIVE` walk of next_player (game.py:607-611) for one lane, O(1) with seat bitmasks.
+    __device__ __forceinline__ bool scan() {
         int d = current - active; d = d < 0 ? d + N : d;                           // seats active..current (cyclic)
         uint32_t window = rotr(st_active, active) & ((2u << d) - 1);
         int a = active + (__ffs(window) - 1); a = a >= N ? a - N : a;
         active = window ? a : current;                                             // else: walked up to current_player
-        lstate = window ? LS_DONE : LS_TURN;                                       //       -> next_turn()
+        return window != 0;
     }
-    __device__ __forceinline__ void cursor_pass() {
-        if (lstate == LS_SCAN) scan();
-        if (lstate == LS_TURN) {                                                   // game.py:554-576
-            PK_FOR(p, N) bets[p] = bets[p] + pending[p]; credits[p] = credits[p] - pending[p]; pending[p] = 0.0; PK_END
-            min_raise = 0.0;
-            turn += 1;                                                             // :561
-            if (turn < 4 && __popc(st_called) > 1) { st_active |= st_called; st_called = 0; }  // :566-572 (else-branch of turn == 4)
-            // Run-out: nobody is ACTIVE and nobody will be re-activated, so every later next_turn() before turn 4 only
-            // commits zero pending bets (x + 0.0 == x) and bumps `turn`; the walk cannot stop before end_hand().
-            if (st_active == 0) turn = 4;
-            if (turn == 4) { lstate = LS_END; foldout = false; }                   // :563-565
-            else {
-                active = first_playing(dealer + 1);                                // :575
-                flags = PK_FLAG_TURN_OVER;                                         // :576
-                lstate = LS_SCAN;
-                scan();
-            }
+    // Takes a lane from LS_SCAN to LS_DONE or LS_END in straight-line code (no wave-wide loop):
+    //   scan -> [next_turn (game.py:554-576) -> scan] -> DONE | END.
+    // If the scan after a next_turn() fails as well, every further next_turn() before turn 4 is a no-op for the
+    // outcome: pending bets are already zero (x + 0.0 == x), CALLED seats cannot be re-activated a second time (there
+    // are none left, or there was at most one), and the walk starts from the same seat over the same states, so it
+    // fails again -- the loop can only end in end_hand() at turn 4.  (This is how the reference skips betting rounds,
+    // SURVEY A.3; the flags of those intermediate turns are overwritten by end_hand's.)
+    __device__ __forceinline__ void cursor() {
+        if (lstate != LS_SCAN) return;
+        if (scan()) { lstate = LS_DONE; return; }
+        PK_FOR(p, N) bets[p] = bets[p] + pending[p]; credits[p] = credits[p] - pending[p]; pending[p] = 0.0; PK_END  // :554-557
+        min_raise = 0.0;                                                           // :558
+        turn += 1;                                                                 // :561
+        bool found = false;
+        if (turn < 4) {                                                            // :566-576
+            if (__popc(st_called) > 1) { st_active |= st_called; st_called = 0; }
+            active = first_playing(dealer + 1);
+            flags = PK_FLAG_TURN_OVER;
+            found = scan();
         }
+        lstate = found ? LS_DONE : LS_END;                                         // :563-565 (turn 4, now or after no-op turns)
+        turn = found ? turn : 4;
+        foldout = false;
     }
 
     // end_hand + setup_hand for every lane parked at LS_END (game.py:453-539), executed by the WHOLE wave.
@@ -747,12 +754,15 @@ struct Table {
     __device__ __forceinline__ void run(const State &S, int t, uint32_t table_id, Lds<N> &lds, bool auto_reset) {
         PK_PROF(prof.lap(PF_ACTION);)
         for (;;) {
-            while (__any(lstate == LS_SCAN || lstate == LS_TURN)) { cursor_pass(); PK_PROF(prof.count(PF_N_CURSOR);) }
-            PK_PROF(prof.lap(PF_CURSOR);)
+            cursor();
+            PK_PROF(prof.lap(PF_CURSOR); prof.count(PF_N_CURSOR);)
             if (!__any(lstate == LS_END)) break;
             end_block(S, t, table_id, lds, auto_reset);
         }
         PK_PROF(prof.lap(PF_OTHER);)
+        finish_step();
+    }
+    __device__ __forceinline__ void finish_step() {
         step_serial += (terr & PK_TERR_NO_WINNER) ? 0 : stepped;  // RNG spec: one serial per COMPLETED Game.step
         stepped = 0;
     }
