@@ -94,6 +94,30 @@ def shard(total_tables, ctx):
     return shard_tables(total_tables, ctx.rank, ctx.world)
 
 
+def baseline_config_index(tables, players, policy, world):
+    """Which entry of BASELINE.json `configs` this run is (None: a parity-test shape, not a listed config)."""
+    if world > 1:
+        return 3 if (tables, players, policy) == (65536, 6, "random") else None
+    return {(4096, 2, "random"): 1, (65536, 6, "random"): 2, (65536, 9, "allin"): 4}.get((tables, players, policy))
+
+
+def measured_traffic(tables, players, policy, kern_steps, fused):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/*_summary.json,
+    made by tools/profile_gpu.sh + tools/summarize_profile.py on this same command), or None if no profile matches."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_summary.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        w = d.get("workload", {})
+        if (w.get("tables"), w.get("players"), w.get("policy"), w.get("steps_per_launch"), w.get("fused")) == \
+                (tables, players, policy, kern_steps, fused) and "hbm_traffic_bytes_per_launch" in d:
+            best = (d["hbm_traffic_bytes_per_launch"], os.path.basename(f))
+    return best
+
+
 def cpu_baseline(n_players, policy, budget_s=12.0):
     """The scalar C oracle (bit-exact restatement of the reference) timed on ONE host core on a bounded sample of the
     same workload.  Reported beside the GPU number; it is not the target (the roofline fraction is)."""
@@ -165,22 +189,30 @@ def main():
     if ctx.rank == 0:
         alg_bytes = b_step(args.players) * n_local * kern_steps
         achieved = alg_bytes / (ms_launch * 1e-3) / 1e9
+        cfg_idx = baseline_config_index(args.tables, args.players, args.policy, ctx.world)
+        traffic = measured_traffic(args.tables, args.players, args.policy, kern_steps, fused)
         out = {
             "metric": "env-steps/sec (whole node) + showdown hand-evals/sec, 65 536 tables 6-max",
             "value": total_steps / seconds, "unit": "env-steps/s", "n_gpus": ctx.world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": seconds / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%d tables/GPU x %d GPU(s), num_players=%d, %s agents in-kernel (Philox4x32-10), "
-                                   "start_credits=100 blinds 1/2, auto-reset; BASELINE configs[%d]"
-                                   % (args.tables, ctx.world, args.players, args.policy, 2 if ctx.world == 1 else 3),
+                                   "start_credits=100 blinds 1/2, auto-reset; %s"
+                                   % (args.tables, ctx.world, args.players, args.policy,
+                                      "BASELINE configs[%d]" % cfg_idx if cfg_idx is not None else "not a BASELINE config"),
                        "tables_per_gpu": args.tables, "num_players": args.players, "policy": args.policy,
                        "kernel": "k_rollout (fused, %d steps/launch)" % kern_steps if fused else "k_rollout (1 step/launch)",
                        "parallelism": "env-parallel, %d shard(s), no collective on the step path" % ctx.world},
             "hand_evals_per_s": evals / seconds, "hands_per_s": hands / seconds, "games_per_s": games / seconds,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic[0] if traffic else None,
+                         "traffic_unit": "bytes per launch (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE, KiB)",
+                         "traffic_source": traffic[1] if traffic else None,
                          "kernel_ms": ms_launch, "algorithmic_bytes_per_launch": alg_bytes,
-                         "note": "algorithmic bytes = (2*(35N+21)+16) B/env-step x tables x steps per launch (SURVEY 8d)"},
+                         "note": "achieved = ALGORITHMIC bytes ((2*(35N+21)+16) B/env-step x tables x steps per launch, "
+                                 "SURVEY 8d) / HIP-event launch time. The fused kernel keeps table state in VGPRs for all "
+                                 "steps of a launch, so real HBM traffic (`traffic`) is ~0.2% of that; the kernel is "
+                                 "VALU-issue-bound at one wave per SIMD (DESIGN.md, Measurement)."},
         }
         if not args.no_cpu_baseline and ctx.world == 1:
             out["cpu_baseline"] = cpu_baseline(args.players, policy)

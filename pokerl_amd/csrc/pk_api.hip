@@ -667,6 +667,7 @@ int pk_pick_actions(pk_handle *h, int policy, int32_t *actions) {
 }
 
 static int launch_rollout(pk_handle *h, int k_steps, int policy, int auto_reset, int fused) {
+    if (k_steps <= 0) return PK_OK;  // nothing to run (callers use k_steps == 0 to just fetch the counters)
     if (fused) {
         DISPATCH_N(h, k_rollout, table_grid(h), h->S, k_steps, policy, auto_reset, h->park);
     } else {
