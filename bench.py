@@ -43,8 +43,8 @@ class DistContext:
             import torch
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            if backend is None:
-                backend = "nccl" if torch.cuda.is_available() else "gloo"
+            if backend is None:  # PK_BENCH_BACKEND=gloo: rehearsals where several ranks share one GPU (RCCL refuses that)
+                backend = os.environ.get("PK_BENCH_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
             if backend == "nccl":
                 torch.cuda.set_device(self.local_rank)
                 self.device = torch.device("cuda", self.local_rank)
@@ -158,7 +158,8 @@ def main():
     policy = 0 if args.policy == "random" else 1
     total_tables = args.tables * ctx.world
     n_local, base = shard(total_tables, ctx)
-    game = pokerl_amd.VecGame(n_local, num_players=args.players, device=ctx.local_rank, table_id_base=base)
+    device = 0 if os.environ.get("PK_BENCH_SAME_DEVICE") else ctx.local_rank  # rehearsal knob: all ranks on GPU 0
+    game = pokerl_amd.VecGame(n_local, num_players=args.players, device=device, table_id_base=base)
     game.reset()
     fused = not args.unfused
 

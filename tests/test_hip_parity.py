@@ -263,3 +263,107 @@ def test_observation_and_cards(HB, O):
     # every dealt prefix holds distinct valid cards
     assert all(len(set(row)) == len(row) for row in deck.tolist())
     assert ((deck & 0xf) < 13).all() and ((deck >> 4) < 4).all()
+
+
+def test_all_player_counts_fused_vs_oracle(HB, O):
+    """Every template instantiation (N = 2..10), ragged table count, both policies."""
+    for N in range(2, 11):
+        for policy in (0, 1):
+            T, K = 1000 + N, 150
+            o = O.OracleGame(T, N, seed=N * 17 + policy)
+            h = HB(T, N, seed=N * 17 + policy)
+            o.reset(); h.reset()
+            co, eo = o.rollout(K, policy, True)
+            ch = h.rollout(K, policy, True, fused=True)
+            assert co.tolist() == ch.tolist(), (N, policy)
+            assert_same(o.snapshot(), h.snapshot(), "N=%d policy=%d" % (N, policy))
+
+
+def test_hand_cap_rule(HB, O):
+    """start_credits = 0: every seat is re-dealt all-in with no chips for ever -- the reference's Game.step would never
+    return.  step() reports PK_TERR_HAND_CAP; a rollout with auto_reset treats it as a finished game."""
+    T, N = 256, 3
+    o = O.OracleGame(T, N, 0, 2, 1)
+    h = HB(T, N, 0, 2, 1)
+    o.reset(); h.reset()
+    a = o.pick_actions(1)
+    fo, eo = o.step(a)
+    fh, eh = h.step(a)
+    assert (eo == 4).all() and np.array_equal(eo, eh)
+    assert_same(o.snapshot(), h.snapshot(), "capped step")
+    o.reset(); h.reset()
+    co, _ = o.rollout(5, 1, True)
+    ch = h.rollout(5, 1, True)
+    assert co.tolist() == ch.tolist() and ch[0] == 5 * T and ch[3] == 5 * T   # 5 steps, each a "finished game"
+    assert_same(o.snapshot(), h.snapshot(), "capped rollout")
+
+
+def test_device_pointer_step(HB, O):
+    """pk_step_d: actions / flags / terr resident in HBM (buffers from hipMalloc through ctypes), asynchronous."""
+    import ctypes as C
+    import pokerl_amd
+    from pokerl_amd import _lib as L
+    hip = C.CDLL("libamdhip64.so")
+    T, N = 4096, 6
+    g = pokerl_amd.VecGame(T, num_players=N)
+    o = O.OracleGame(T, N)
+    g.reset(); o.reset()
+    d_act, d_flags, d_terr = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    assert hip.hipMalloc(C.byref(d_act), T * 4) == 0 and hip.hipMalloc(C.byref(d_flags), T) == 0 and hip.hipMalloc(C.byref(d_terr), T) == 0
+    lib = L.lib()
+    for s in range(40):
+        a = o.pick_actions(0)
+        fo, eo = o.step(a)
+        assert hip.hipMemcpy(d_act, a.ctypes.data_as(C.c_void_p), T * 4, 1) == 0          # H2D
+        L.check(lib.pk_step_d(g._h, d_act, d_flags, d_terr), g._h)
+        g.sync()
+        fl = np.zeros(T, np.uint8); te = np.zeros(T, np.uint8)
+        assert hip.hipMemcpy(fl.ctypes.data_as(C.c_void_p), d_flags, T, 2) == 0            # D2H
+        assert hip.hipMemcpy(te.ctypes.data_as(C.c_void_p), d_terr, T, 2) == 0
+        assert np.array_equal(fl, fo) and np.array_equal(te, eo)
+        over = (fo & 1).astype(np.uint8)
+        if over.any():
+            o.reset(mask=over); g.reset(mask=over)
+    assert GU.bits_equal(o.f64(0), g.credits) and GU.bits_equal(o.f64(3), g.payoffs)
+    for p in (d_act, d_flags, d_terr):
+        hip.hipFree(p)
+
+
+def test_bad_arguments_are_reported_not_fatal(HB):
+    import ctypes as C
+    import pokerl_amd
+    from pokerl_amd import _lib as L
+    lib = L.lib()
+    h = C.c_void_p()
+    assert lib.pk_create(C.byref(h), 0, 16, 11, None, 100.0, 2.0, 1.0, 0, 1, 0) == L.PK_E_INVALID_ARG   # N > 10
+    assert lib.pk_create(C.byref(h), 0, 0, 4, None, 100.0, 2.0, 1.0, 0, 1, 0) == L.PK_E_INVALID_ARG     # T < 1
+    assert lib.pk_create(C.byref(h), 99, 16, 4, None, 100.0, 2.0, 1.0, 0, 1, 0) == L.PK_E_INVALID_ARG   # no such device
+    assert b"device" in lib.pk_last_error(None)
+    with pytest.raises(ValueError):
+        pokerl_amd.VecGame(4, num_players=1)
+    g = pokerl_amd.VecGame(4, num_players=2)
+    assert lib.pk_get_f64(g._h, 9, None) == L.PK_E_INVALID_ARG
+    assert lib.pk_rollout(g._h, 5, 7, 1, 1, None) == L.PK_E_INVALID_ARG     # unknown policy
+    with pytest.raises(ValueError):
+        g.reset(mask=np.ones(3, np.uint8))
+
+
+def test_bench_two_ranks_rehearsal(tmp_path):
+    """bench.py under torch.distributed.run with 2 ranks (both on GPU 0, gloo -- RCCL refuses a shared device): the N>1
+    code path end to end with real kernels: sharding by global table id, barrier, SUM of units / MAX of seconds."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PK_BENCH_BACKEND="gloo", PK_BENCH_SAME_DEVICE="1", MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"),
+                          "--gpus", "2", "--tables", "8192", "--steps", "256", "--warmup", "64", "--chunk", "64"],
+                         capture_output=True, text=True, env=env, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    r = json.loads(line)
+    assert r["n_gpus"] == 2 and r["scaling"] == "weak" and r["steps"] == 256
+    assert r["value"] > 0 and abs(r["value"] - 2 * 8192 * 256 / (r["ms_per_step"] * 256 / 1e3)) / r["value"] < 1e-6
+    assert "cpu_baseline" not in r and r["roofline"]["frac"] > 0
