@@ -34,14 +34,14 @@ __device__ __forceinline__ void wave_add_counters(const State &S, uint32_t steps
 }
 
 template <int N>
-__global__ void __launch_bounds__(PK_TABLE_BLOCK) k_reset(State S, const uint8_t *mask, int dealer) {  // Game.reset, game.py:397-412
+__global__ void __launch_bounds__(PK_TABLE_BLOCK) k_reset(State S, Hot H, const uint8_t *mask, int dealer) {  // Game.reset, game.py:397-412
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= S.T) return;
     if (mask && !mask[t]) return;
     Table<N> tb;
     tb.load(S, t);
-    tb.reset_state(S, dealer);
-    tb.deal(S, S.table_id_base + (uint32_t)t);
+    tb.reset_state(H, dealer);
+    tb.deal(H, H.table_id_base + (uint32_t)t);
     tb.store(S, t);
     double hb;
     S.valid[t] = (uint8_t)tb.valid_mask(hb);
@@ -49,19 +49,19 @@ __global__ void __launch_bounds__(PK_TABLE_BLOCK) k_reset(State S, const uint8_t
 }
 
 template <int N>
-__global__ void __launch_bounds__(PK_TABLE_BLOCK) k_step(State S, const int32_t *actions, uint8_t *flags, uint8_t *terr) {  // Game.step, game.py:621-700
+__global__ void __launch_bounds__(PK_TABLE_BLOCK) k_step(State S, Hot H, const int32_t *actions, uint8_t *flags, uint8_t *terr) {  // Game.step, game.py:621-700
     __shared__ Lds<N> lds;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = t < S.T;
-    const uint32_t table_id = S.table_id_base + (uint32_t)t;
+    const uint32_t table_id = H.table_id_base + (uint32_t)t;
     Table<N> tb;
     if (live) tb.load(S, t); else tb.blank();
     double high_bet;
     uint32_t mask = tb.valid_mask(high_bet);                                       // :648
     const int action = live ? actions[t] : -1;
     const bool ok = live && action >= 0 && action < PK_NUM_MOVES && ((mask >> action) & 1);
-    if (ok) tb.begin_step(S, action, high_bet);
-    tb.run(S, t, table_id, lds, false);
+    if (ok) tb.begin_step(H, action, high_bet);
+    tb.run(H, t, table_id, lds, false);
     if (!live) return;
     if (!ok) {                                                                     // :649-651: no mutation
         flags[t] = 0;
@@ -77,11 +77,11 @@ __global__ void __launch_bounds__(PK_TABLE_BLOCK) k_step(State S, const int32_t 
 }
 
 template <int N>
-__global__ void __launch_bounds__(PK_TABLE_BLOCK) k_pick(State S, int policy, int32_t *actions) {
+__global__ void __launch_bounds__(PK_TABLE_BLOCK) k_pick(State S, Hot H, int policy, int32_t *actions) {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= S.T) return;
     ActionRng rng;
-    actions[t] = pick_action(S, rng, S.table_id_base + (uint32_t)t, S.step_serial[t], S.valid[t], policy);
+    actions[t] = pick_action(H, rng, H.table_id_base + (uint32_t)t, S.step_serial[t], S.valid[t], policy);
 }
 
 // K steps per table, in-kernel agents, table state in registers for the whole launch (K == 1: the unfused form).
@@ -91,11 +91,13 @@ __global__ void __launch_bounds__(PK_TABLE_BLOCK) k_pick(State S, int policy, in
 // raises its lane utilisation from ~25 % to ~60 %.  Every table still makes exactly K steps with the actions the RNG
 // spec assigns to (table, step_serial), so the state after the launch is bit-identical to the lockstep order.
 template <int N>
-__global__ void __launch_bounds__(PK_TABLE_BLOCK) k_rollout(State S, int K, int policy, int auto_reset, int park) {
+__global__ void __launch_bounds__(PK_TABLE_BLOCK) k_rollout(const State *__restrict__ Sp, Hot H, int K, int policy, int auto_reset, int park) {
+    // Array bases by pointer (loaded only where the table is loaded / stored), loop scalars by value: see pk::Hot.
+    const State &S = *Sp;
     __shared__ Lds<N> lds;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = t < S.T;
-    const uint32_t table_id = S.table_id_base + (uint32_t)t;
+    const uint32_t table_id = H.table_id_base + (uint32_t)t;
     Table<N> tb;
     if (live) tb.load(S, t); else tb.blank();
     const uint32_t hs0 = tb.hand_serial;
@@ -116,7 +118,7 @@ __global__ void __launch_bounds__(PK_TABLE_BLOCK) k_rollout(State S, int K, int 
     for (;;) {
         if (alive && tb.lstate == LS_DONE && kdone < K) {
             uint32_t mask = tb.valid_mask(high_bet);
-            tb.begin_step(S, pick_action(S, rng, table_id, tb.step_serial, mask, policy), high_bet);
+            tb.begin_step(H, pick_action(H, rng, table_id, tb.step_serial, mask, policy), high_bet);
         }
         PK_PROF(tb.prof.lap(PF_ACTION);)
         tb.cursor();
@@ -127,7 +129,7 @@ __global__ void __launch_bounds__(PK_TABLE_BLOCK) k_rollout(State S, int K, int 
         const int runnable = __popcll(__ballot(alive && tb.lstate == LS_DONE && kdone < K));
         if (parked == 0 && runnable == 0) break;
         if (parked >= park || runnable == 0) {
-            tb.end_block(S, t, table_id, lds, auto_reset != 0);
+            tb.end_block(H, t, table_id, lds, auto_reset != 0);
             retire();
         }
     }
@@ -142,24 +144,24 @@ __global__ void __launch_bounds__(PK_TABLE_BLOCK) k_rollout(State S, int K, int 
 
 // PokerGameEnv.reset, envs/game_env.py:20-29
 template <int N>
-__global__ void __launch_bounds__(PK_TABLE_BLOCK) k_env_reset(State S, const uint8_t *mask, int opp_policy) {
+__global__ void __launch_bounds__(PK_TABLE_BLOCK) k_env_reset(State S, Hot H, const uint8_t *mask, int opp_policy) {
     __shared__ Lds<N> lds;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = t < S.T && (!mask || mask[t < S.T ? t : 0]);
-    const uint32_t table_id = S.table_id_base + (uint32_t)t;
+    const uint32_t table_id = H.table_id_base + (uint32_t)t;
     Table<N> tb;
-    if (live) { tb.load(S, t); tb.reset_state(S, 0); tb.deal(S, table_id); } else tb.blank();   // :23
+    if (live) { tb.load(S, t); tb.reset_state(H, 0); tb.deal(H, table_id); } else tb.blank();   // :23
     ActionRng rng;
     double high_bet;
     uint32_t vm = tb.valid_mask(high_bet);
     bool more = live && tb.active != 0;                                            // :24
     while (__any(more)) {
-        if (more) tb.begin_step(S, pick_action(S, rng, table_id, tb.step_serial, vm, opp_policy), high_bet);  // :25-26
-        tb.run(S, t, table_id, lds, false);
+        if (more) tb.begin_step(H, pick_action(H, rng, table_id, tb.step_serial, vm, opp_policy), high_bet);  // :25-26
+        tb.run(H, t, table_id, lds, false);
         if (more) {
             if (tb.terr) more = false;
             else {
-                if (tb.flags & PK_FLAG_GAME_OVER) { tb.reset_state(S, 0); tb.deal(S, table_id); }  // :27
+                if (tb.flags & PK_FLAG_GAME_OVER) { tb.reset_state(H, 0); tb.deal(H, table_id); }  // :27
                 more = tb.active != 0;
             }
         }
@@ -174,11 +176,11 @@ __global__ void __launch_bounds__(PK_TABLE_BLOCK) k_env_reset(State S, const uin
 
 // PokerGameEnv.step, envs/game_env.py:31-53
 template <int N>
-__global__ void __launch_bounds__(PK_TABLE_BLOCK) k_env_step(State S, const int32_t *actions, int opp_policy, double *reward, uint8_t *done_out, uint8_t *hand_out, uint8_t *terr) {
+__global__ void __launch_bounds__(PK_TABLE_BLOCK) k_env_step(State S, Hot H, const int32_t *actions, int opp_policy, double *reward, uint8_t *done_out, uint8_t *hand_out, uint8_t *terr) {
     __shared__ Lds<N> lds;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = t < S.T;
-    const uint32_t table_id = S.table_id_base + (uint32_t)t;
+    const uint32_t table_id = H.table_id_base + (uint32_t)t;
     Table<N> tb;
     if (live) tb.load(S, t); else tb.blank();
     ActionRng rng;
@@ -187,16 +189,16 @@ __global__ void __launch_bounds__(PK_TABLE_BLOCK) k_env_step(State S, const int3
     const int action = live ? actions[t] : -1;
     const bool ok = live && action >= 0 && action < PK_NUM_MOVES && ((vm >> action) & 1);
     double rew = 0.0;                                                              // :34
-    if (ok) tb.begin_step(S, action, high_bet);                                    // :35
-    tb.run(S, t, table_id, lds, false);
+    if (ok) tb.begin_step(H, action, high_bet);                                    // :35
+    tb.run(H, t, table_id, lds, false);
     bool done = tb.flags & PK_FLAG_GAME_OVER, hand = tb.flags & PK_FLAG_HAND_OVER;
     bool fin = !ok || tb.terr != 0;
     if (!fin && (done || (tb.st_broken & 1))) { rew = tb.payoffs[0]; done = true; hand = true; fin = true; }  // :37-39
     vm = tb.valid_mask(high_bet);
     bool more = !fin && !hand && tb.active != 0;                                   // :41
     while (__any(more)) {
-        if (more) tb.begin_step(S, pick_action(S, rng, table_id, tb.step_serial, vm, opp_policy), high_bet);  // :43-44
-        tb.run(S, t, table_id, lds, false);
+        if (more) tb.begin_step(H, pick_action(H, rng, table_id, tb.step_serial, vm, opp_policy), high_bet);  // :43-44
+        tb.run(H, t, table_id, lds, false);
         if (more) {
             if (tb.terr) { fin = true; more = false; }
             else {
@@ -209,8 +211,8 @@ __global__ void __launch_bounds__(PK_TABLE_BLOCK) k_env_step(State S, const int3
     if (!fin && hand) rew = tb.payoffs[0];                                         // :47
     more = !fin && !done && tb.active != 0;                                        // :49
     while (__any(more)) {
-        if (more) tb.begin_step(S, pick_action(S, rng, table_id, tb.step_serial, vm, opp_policy), high_bet);  // :51-52
-        tb.run(S, t, table_id, lds, false);
+        if (more) tb.begin_step(H, pick_action(H, rng, table_id, tb.step_serial, vm, opp_policy), high_bet);  // :51-52
+        tb.run(H, t, table_id, lds, false);
         if (more) {
             if (tb.terr) { fin = true; more = false; }
             else { done = tb.flags & PK_FLAG_GAME_OVER; more = !done && tb.active != 0; }
@@ -372,6 +374,8 @@ struct pk_handle {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     State S{};
+    State *d_S = nullptr;  // device copy of S (kernels that take the state by pointer)
+    Hot hot{};             // loop scalars, passed by value
     void *arena = nullptr;
     // staging (device)
     int32_t *d_actions = nullptr;
@@ -468,7 +472,7 @@ int pk_create(pk_handle **out, int device, int num_tables, int num_players, cons
     size_t obs = (size_t)PK_OBS_DIM(N) * 8;
     h->export_bytes = al(T * (obs > N * 8 ? obs : N * 8));
     size_t total = 4 * al(T * N * 8) + al(T * 8) + al(T * 8) + 4 * al(T * 4) + al(W * T * 4) + al(N * T * 4) + 2 * al(T) +
-                   al(PK_NUM_COUNTERS * 8) + al(PF_SLOTS * 8) + al(T * 4) + 5 * al(T) + al(T * 8) + h->export_bytes;
+                   al(PK_NUM_COUNTERS * 8) + al(PF_SLOTS * 8) + al(sizeof(State)) + al(PK_MAX_PLAYERS * 8) + al(T * 4) + 5 * al(T) + al(T * 8) + h->export_bytes;
     e = hipMalloc(&h->arena, total);
     if (e != hipSuccess) return bail(h->fail(PK_E_OOM, "hipMalloc(table state)", e));
     if (hipMemsetAsync(h->arena, 0, total, h->stream) != hipSuccess) return bail(h->fail(PK_E_HIP, "hipMemset"));
@@ -486,6 +490,8 @@ int pk_create(pk_handle **out, int device, int num_tables, int num_players, cons
     S.valid = (uint8_t *)take(T); S.terr = (uint8_t *)take(T);
     S.counters = (unsigned long long *)take(PK_NUM_COUNTERS * 8);
     S.prof = (unsigned long long *)take(PF_SLOTS * 8);
+    h->d_S = (State *)take(sizeof(State));
+    double *d_start = (double *)take(PK_MAX_PLAYERS * 8);
     h->d_actions = (int32_t *)take(T * 4);
     h->d_flags = (uint8_t *)take(T); h->d_terr = (uint8_t *)take(T); h->d_mask = (uint8_t *)take(T);
     h->d_done = (uint8_t *)take(T); h->d_handf = (uint8_t *)take(T);
@@ -507,7 +513,11 @@ int pk_create(pk_handle **out, int device, int num_tables, int num_players, cons
         // literal get_valid_actions on the zero state: raises invalid (0 > 0 false), CHECK valid (high_bet == 0),
         // CALL invalid (0 < 0 false) -> FOLD|CHECK|ALL_IN
         for (auto &v : valid) v = (1u << MV_FOLD) | (1u << MV_CHECK) | (1u << MV_ALL_IN);
-        if (hipMemcpyAsync(S.seat_states, ss.data(), T * 8, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+        h->hot.big_blind = big_blind; h->hot.small_blind = small_blind; h->hot.start_credits = d_start; h->hot.show = S.show;
+        h->hot.key0 = S.key0; h->hot.key1 = S.key1; h->hot.table_id_base = table_id_base; h->hot.T = num_tables;
+        if (hipMemcpyAsync(d_start, S.start_credits, PK_MAX_PLAYERS * 8, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+            hipMemcpyAsync(h->d_S, &h->S, sizeof(State), hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+            hipMemcpyAsync(S.seat_states, ss.data(), T * 8, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
             hipMemcpyAsync(S.cursors, cur.data(), T * 4, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
             hipMemcpyAsync(S.show, show.data(), N * T * 4, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
             hipMemcpyAsync(S.valid, valid.data(), T, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
@@ -549,7 +559,7 @@ int pk_reset(pk_handle *h, const uint8_t *mask, int dealer) {
     int rc = upload_mask(h, mask, &dmask);
     if (rc) return rc;
     int d = ((dealer % h->N) + h->N) % h->N;
-    DISPATCH_N(h, k_reset, table_grid(h), h->S, dmask, d);
+    DISPATCH_N(h, k_reset, table_grid(h), h->S, h->hot, dmask, d);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return PK_OK;
@@ -558,7 +568,7 @@ int pk_reset(pk_handle *h, const uint8_t *mask, int dealer) {
 int pk_step_d(pk_handle *h, const int32_t *actions_d, uint8_t *flags_d, uint8_t *terr_d) {
     if (!h || !actions_d || !flags_d) return h ? h->fail(PK_E_INVALID_ARG, "pk_step_d: NULL buffer") : PK_E_INVALID_ARG;
     HIPCHK(h, hipSetDevice(h->device));
-    DISPATCH_N(h, k_step, table_grid(h), h->S, actions_d, flags_d, terr_d);
+    DISPATCH_N(h, k_step, table_grid(h), h->S, h->hot, actions_d, flags_d, terr_d);
     HIPCHK(h, hipGetLastError());
     return PK_OK;
 }
@@ -659,7 +669,7 @@ int pk_get_obs(pk_handle *h, double *out) {
 int pk_pick_actions(pk_handle *h, int policy, int32_t *actions) {
     if (!h || !actions || policy < 0 || policy > 1) return h ? h->fail(PK_E_INVALID_ARG, "pk_pick_actions: bad argument") : PK_E_INVALID_ARG;
     HIPCHK(h, hipSetDevice(h->device));
-    DISPATCH_N(h, k_pick, table_grid(h), h->S, policy, h->d_actions);
+    DISPATCH_N(h, k_pick, table_grid(h), h->S, h->hot, policy, h->d_actions);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipMemcpyAsync(actions, h->d_actions, (size_t)h->T * 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -668,11 +678,9 @@ int pk_pick_actions(pk_handle *h, int policy, int32_t *actions) {
 
 static int launch_rollout(pk_handle *h, int k_steps, int policy, int auto_reset, int fused) {
     if (k_steps <= 0) return PK_OK;  // nothing to run (callers use k_steps == 0 to just fetch the counters)
-    if (fused) {
-        DISPATCH_N(h, k_rollout, table_grid(h), h->S, k_steps, policy, auto_reset, h->park);
-    } else {
-        for (int k = 0; k < k_steps; ++k) DISPATCH_N(h, k_rollout, table_grid(h), h->S, 1, policy, auto_reset, h->park);
-    }
+    const int launches = fused ? 1 : k_steps, k_each = fused ? k_steps : 1;
+    for (int k = 0; k < launches; ++k)
+        DISPATCH_N(h, k_rollout, table_grid(h), (const State *)h->d_S, h->hot, k_each, policy, auto_reset, h->park);
     HIPCHK(h, hipGetLastError());
     return PK_OK;
 }
@@ -720,7 +728,7 @@ int pk_env_reset(pk_handle *h, const uint8_t *mask, int opp_policy) {
     const uint8_t *dmask;
     int rc = upload_mask(h, mask, &dmask);
     if (rc) return rc;
-    DISPATCH_N(h, k_env_reset, table_grid(h), h->S, dmask, opp_policy);
+    DISPATCH_N(h, k_env_reset, table_grid(h), h->S, h->hot, dmask, opp_policy);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return PK_OK;
@@ -733,7 +741,7 @@ int pk_env_step(pk_handle *h, const int32_t *actions, int opp_policy, double *re
     HIPCHK(h, hipSetDevice(h->device));
     const size_t T = (size_t)h->T;
     HIPCHK(h, hipMemcpyAsync(h->d_actions, actions, T * 4, hipMemcpyHostToDevice, h->stream));
-    DISPATCH_N(h, k_env_step, table_grid(h), h->S, (const int32_t *)h->d_actions, opp_policy, h->d_reward, h->d_done, h->d_handf, h->d_terr);
+    DISPATCH_N(h, k_env_step, table_grid(h), h->S, h->hot, (const int32_t *)h->d_actions, opp_policy, h->d_reward, h->d_done, h->d_handf, h->d_terr);
     HIPCHK(h, hipGetLastError());
     std::vector<uint8_t> te(T);
     HIPCHK(h, hipMemcpyAsync(reward, h->d_reward, T * 8, hipMemcpyDeviceToHost, h->stream));

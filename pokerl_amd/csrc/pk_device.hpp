@@ -43,6 +43,18 @@ struct State {
     int T;
 };
 
+// The few scalars the step machine needs inside its loop, passed BY VALUE (kernel-argument SGPRs); the array bases of
+// State are taken by pointer and s_load-ed only where a table is loaded / stored.  (All of State by value kept ~35 SGPR
+// pairs live across the loop and spilled 66 SGPRs into VGPR lanes; all of it by pointer made the compiler re-issue
+// scalar loads inside the loop.)
+struct Hot {
+    double big_blind, small_blind;
+    const double *start_credits;  // [N], device memory (read on Game.reset only)
+    uint32_t *show;               // State::show
+    uint32_t key0, key1, table_id_base;
+    int T;
+};
+
 // ---------------------------------------------------------------------------------------------- helpers
 // Compile-time expansion of `for p in 0..N-1`: every state-array subscript is a constant when the IR is first built, so
 // the whole table is scalarised into VGPRs by the first SROA pass.  (With `#pragma unroll` loops the arrays are still
@@ -246,20 +258,16 @@ __device__ __forceinline__ uint32_t compare_rankings(const uint32_t (&v)[N], int
 //   * the `flush` group is the suit with >=5 cards, else the lowest suit present (:52-58);
 //   * wheel checks are if/elif (:83-88): a 5-4-3-2 run in that group without its ace suppresses the plain wheel.
 // Equality with the reference on all C(52,7) hands is a test (tests/test_hip_parity.py, eval7 digest).
-__device__ __forceinline__ void take_top(uint32_t &m, uint32_t &kick) {
-    int i = 31 - __clz((int)m);
-    kick = (kick << 4) | (uint32_t)(i + 1);
-    m &= ~(1u << i);
-}
 __device__ __forceinline__ uint32_t eval7_distinct(const uint32_t (&c)[7]) {
     uint32_t m01 = 0, m23 = 0;  // suit s -> 13 rank bits (bit r-1, ace-high rank r) at offset 16*(s&1) of m01 / m23
-    PK_FOR(i, 7)
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
         uint32_t r0 = c[i] & 0xf, s = c[i] >> 4;
         uint32_t b = r0 ? r0 - 1 : 12;                                             // cards.py:14: ace ranks highest
         uint32_t bit = 1u << (b + ((s & 1) << 4));
         m01 |= (s & 2) ? 0 : bit;
         m23 |= (s & 2) ? bit : 0;
-     PK_END
+    }
     const uint32_t sa = m01 & 0x1fff, sb = m01 >> 16, sc = m23 & 0x1fff, sd = m23 >> 16;
     const uint32_t um = sa | sb | sc | sd;
     const uint32_t s1 = sa ^ sb, c1 = sa & sb, s2 = sc ^ sd, c2 = sc & sd;      // per-rank count = bit0 + 2*t + 4*quads
@@ -273,44 +281,42 @@ __device__ __forceinline__ uint32_t eval7_distinct(const uint32_t (&c)[7]) {
     const uint32_t run = gm & ~(gm + (gm & (0u - gm)));
     const int bcount = __popc(run), btop = 31 - __clz((int)run);
     const uint32_t m5 = um & (um >> 1) & (um >> 2) & (um >> 3) & (um >> 4);        // bit i: ranks i+1..i+5 all present
-    if (bcount == 4 && btop == 3) {                                                // :83-85
-        if (gm & (1u << 12)) return ((uint32_t)HR_SF << 20) | 4;
+    // Category cascade of :90-99 from the weakest to the strongest (later assignments override), as selects.  A hand is
+    // [up to 2 ranks taken from the top of L] + [up to 5 ranks from the top of (base minus what was taken)], or a
+    // straight-type hand with a single kicker `direct`.
+    uint32_t cat = HR_HIGH, L = 0, base = um, direct = 0;
+    int nl = 0, nm = 5;                                                            // :99
+    if (pairs) { cat = HR_PAIR; L = pairs; nl = 1; nm = 3; }                       // :98
+    if (pairs & (pairs - 1)) { cat = HR_TWO_PAIR; nl = 2; nm = 1; }                // :97
+    if (trips) { cat = HR_TRIS; L = trips; nl = 1; nm = 2; }                       // :96
+    if (m5) { cat = HR_STRAIGHT; direct = (uint32_t)(31 - __clz((int)m5) + 5); nl = 0; nm = 0; }  // :95
+    if (has_flush) { cat = HR_FLUSH; L = 0; nl = 0; base = gm; nm = 5; direct = 0; }               // :94
+    if (trips && pairs) { cat = HR_FULL; L = trips; nl = 1; base = pairs; nm = 1; direct = 0; }    // :93
+    if (trips & (trips - 1)) { cat = HR_FULL; L = trips; nl = 2; nm = 0; direct = 0; }             // :92
+    if (quads) { cat = HR_POKER; L = quads; nl = 1; base = um; nm = 1; direct = 0; }               // :91
+    if (bcount >= 5) { cat = HR_SF; direct = (uint32_t)(btop + 1); nl = 0; nm = 0; }               // :90
+    if (bcount == 4 && btop == 3) {                                                // :83-85 (if/elif: see header note)
+        if (gm & (1u << 12)) { cat = HR_SF; direct = 4; nl = 0; nm = 0; }
     } else if (m5 == 0 && (um & 0x1f) == 0xf) {                                    // :86-88
-        if (um & (1u << 12)) return ((uint32_t)HR_STRAIGHT << 20) | 4;
+        if (um & (1u << 12)) { cat = HR_STRAIGHT; direct = 4; nl = 0; nm = 0; }
     }
-    if (bcount >= 5) return ((uint32_t)HR_SF << 20) | (uint32_t)(btop + 1);        // :90
-    uint32_t kick = 0, m;
-    if (quads) {                                                                   // :91
-        m = quads; take_top(m, kick);
-        m = um & ~quads; take_top(m, kick);
-        return ((uint32_t)HR_POKER << 20) | kick;
+    uint32_t kick = direct, taken = 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        uint32_t bit = (0x80000000u >> __clz((int)L));
+        bool take = i < nl;                                                        // nl > 0 implies L has that many bits
+        kick = take ? ((kick << 4) | (uint32_t)(32 - __clz((int)L))) : kick;
+        taken |= take ? bit : 0; L = take ? (L & ~bit) : L;
     }
-    if (trips & (trips - 1)) { m = trips; take_top(m, kick); take_top(m, kick); return ((uint32_t)HR_FULL << 20) | kick; }  // :92
-    if (trips && pairs) { m = trips; take_top(m, kick); m = pairs; take_top(m, kick); return ((uint32_t)HR_FULL << 20) | kick; }  // :93
-    if (has_flush) {                                                               // :94
-        m = gm;
-        PK_FOR(i, 5) take_top(m, kick); PK_END
-        return ((uint32_t)HR_FLUSH << 20) | kick;
+    uint32_t m = base & ~taken;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        uint32_t bit = (0x80000000u >> __clz((int)m));
+        bool take = i < nm;
+        kick = take ? ((kick << 4) | (uint32_t)(32 - __clz((int)m))) : kick;
+        m = take ? (m & ~bit) : m;
     }
-    if (m5) return ((uint32_t)HR_STRAIGHT << 20) | (uint32_t)(31 - __clz((int)m5) + 5);  // :95
-    if (trips) {                                                                   // :96
-        m = trips; take_top(m, kick);
-        m = um & ~trips; take_top(m, kick); take_top(m, kick);
-        return ((uint32_t)HR_TRIS << 20) | kick;
-    }
-    if (pairs & (pairs - 1)) {                                                     // :97
-        m = pairs; take_top(m, kick); take_top(m, kick);
-        m = um & ~(pairs & ~m); take_top(m, kick);                                 // highest rank outside the two top pairs
-        return ((uint32_t)HR_TWO_PAIR << 20) | kick;
-    }
-    if (pairs) {                                                                   // :98
-        m = pairs; take_top(m, kick);
-        m = um & ~pairs; take_top(m, kick); take_top(m, kick); take_top(m, kick);
-        return ((uint32_t)HR_PAIR << 20) | kick;
-    }
-    m = um;                                                                        // :99
-    PK_FOR(i, 5) take_top(m, kick); PK_END
-    return ((uint32_t)HR_HIGH << 20) | kick;
+    return (cat << 20) | kick;
 }
 
 // ---------------------------------------------------------------------------------------------- the table
@@ -353,7 +359,7 @@ struct Lds {  // per workgroup (= one wavefront); ~10 KB at N = 10
 
 struct ActionRng {  // one Philox block serves four consecutive steps of a table (RNG spec)
     uint32_t idx = 0xffffffffu, w[4];
-    __device__ __forceinline__ uint32_t word(const State &S, uint32_t table_id, uint32_t step_serial) {
+    __device__ __forceinline__ uint32_t word(const Hot &S, uint32_t table_id, uint32_t step_serial) {
         if ((step_serial >> 2) != idx) {
             idx = step_serial >> 2;
             philox4x32_10(table_id, idx, STREAM_ACTION, 0u, S.key0, S.key1, w);
@@ -364,7 +370,7 @@ struct ActionRng {  // one Philox block serves four consecutive steps of a table
 };
 
 // Synthetic agents (RandomAgent semantics of pokerl/agents/random.py:12-16 under the RNG spec).
-__device__ __forceinline__ int pick_action(const State &S, ActionRng &rng, uint32_t table_id, uint32_t step_serial, uint32_t mask, int policy) {
+__device__ __forceinline__ int pick_action(const Hot &S, ActionRng &rng, uint32_t table_id, uint32_t step_serial, uint32_t mask, int policy) {
     if (policy == PK_POLICY_ALLIN) return MV_ALL_IN;
     uint32_t k = __umulhi(rng.word(S, table_id, step_serial), (uint32_t)__popc(mask));
     uint32_t m = mask;
@@ -467,7 +473,7 @@ struct Table {
     }
 
     // Deck of this hand (RNG spec: DESIGN.md, "RNG specification") -> cards[]; replaces random.shuffle(self.deck), game.py:424.
-    __device__ __forceinline__ void deal(const State &S, uint32_t table_id) {
+    __device__ __forceinline__ void deal(const Hot &S, uint32_t table_id) {
         uint32_t c[K];
         constexpr int NB = (K + 17) / 18;
         PK_FOR(b, NB)
@@ -511,7 +517,7 @@ struct Table {
     __device__ __forceinline__ uint32_t card(int i) const { return (cards[i >> 2] >> (8 * (i & 3))) & 0xff; }  // compile-time i
 
     // Game.setup_hand minus the shuffle, game.py:414-451
-    __device__ __forceinline__ void setup_state(const State &S) {
+    __device__ __forceinline__ void setup_state(const Hot &S) {
         hand += 1; turn = 0;                                                       // :417-418
         st_active = ~st_broken & FULL; st_called = 0; st_allin = 0;                // :421
         dealer = first_playing(dealer + 1);                                        // :432
@@ -534,7 +540,7 @@ struct Table {
         hands_this_step += 1;
     }
     // Game.reset minus the shuffle, game.py:397-412
-    __device__ __forceinline__ void reset_state(const State &S, int dealer_cfg) {
+    __device__ __forceinline__ void reset_state(const Hot &S, int dealer_cfg) {
         dealer = dealer_cfg; hand = 0; active = 0;                                 // :403-407
         PK_FOR(p, N) credits[p] = S.start_credits[p]; PK_END  // :408
         st_active = FULL; st_called = st_allin = st_broken = 0;                    // :409
@@ -543,7 +549,7 @@ struct Table {
 
     // Game.step up to the call of next_player (game.py:656-699) for an action already checked against the mask.
     // Branch-free: every lane of the wave takes a different action, so the three arms are merged into selects.
-    __device__ __forceinline__ void begin_step(const State &S, int action, double high_bet) {
+    __device__ __forceinline__ void begin_step(const Hot &S, int action, double high_bet) {
         const int a = active;
         const uint32_t b = 1u << a;
         hands_this_step = 0; terr = 0; flags = 0; stepped = 1;
@@ -606,7 +612,7 @@ struct Table {
     // end_hand + setup_hand for every lane parked at LS_END (game.py:453-539), executed by the WHOLE wave.
     // auto_reset: a finished game (or a table that hit PK_HAND_CAP, which the reference would never leave) is
     // Game.reset() on the spot, as the rollout/bench loop does on the host side of the reference.
-    __device__ __forceinline__ void end_block(const State &S, int t, uint32_t table_id, Lds<N> &lds, bool auto_reset) {
+    __device__ __forceinline__ void end_block(const Hot &S, int t, uint32_t table_id, Lds<N> &lds, bool auto_reset) {
         const bool e = lstate == LS_END;
         PK_PROF(prof.lap(PF_OTHER); prof.count(PF_N_END);)
         bool sd = false, nowin = false;
@@ -751,7 +757,7 @@ struct Table {
     }
 
     // Runs the machine until every lane of the wave is DONE.  Must be called from wave-uniform control flow.
-    __device__ __forceinline__ void run(const State &S, int t, uint32_t table_id, Lds<N> &lds, bool auto_reset) {
+    __device__ __forceinline__ void run(const Hot &S, int t, uint32_t table_id, Lds<N> &lds, bool auto_reset) {
         PK_PROF(prof.lap(PF_ACTION);)
         for (;;) {
             cursor();

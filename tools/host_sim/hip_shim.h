@@ -15,7 +15,7 @@ static dim3_ threadIdx, blockIdx, blockDim;
 static inline int __popc(unsigned x) { return __builtin_popcount(x); }
 static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 static inline int __ffs(unsigned x) { return __builtin_ffs((int)x); }
-static inline int __clz(int x) { return x ? __builtin_clz((unsigned)x) : 32; }
+static inline int __clz(int x) { return x ? __builtin_clz((unsigned)x) : 32; }  // device: v_ffbh_u32 -> 32 (as -1 -> clamped) for 0
 static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 static inline unsigned long long __ballot(int p) { return p ? 1ull : 0ull; }
 static inline int __any(int p) { return p; }

@@ -29,11 +29,13 @@ static int run(int T, int K, int policy, uint64_t seed) {
     for (int p = 0; p < N; ++p) S.start_credits[p] = 100.0;
     S.big_blind = 2; S.small_blind = 1; S.key0 = (uint32_t)seed; S.key1 = (uint32_t)(seed >> 32); S.table_id_base = 0; S.T = T;
     double sc[16]; for (int p = 0; p < 16; ++p) sc[p] = 100.0;
+    Hot H{}; H.big_blind = 2; H.small_blind = 1; H.start_credits = sc; H.show = show.data();
+    H.key0 = S.key0; H.key1 = S.key1; H.table_id_base = 0; H.T = T;
     orc_game *o = orc_create(T, N, sc, 2, 1, seed, 0);
     orc_reset(o, nullptr, 0);
     static Lds<N> lds;
     std::vector<Table<N>> tb(T);
-    for (int t = 0; t < T; ++t) { tb[t].load(S, t); tb[t].reset_state(S, 0); tb[t].deal(S, (uint32_t)t); tb[t].store(S, t); }
+    for (int t = 0; t < T; ++t) { tb[t].load(S, t); tb[t].reset_state(H, 0); tb[t].deal(H, (uint32_t)t); tb[t].store(S, t); }
     std::vector<double> oc(N * T), ob(N * T), op(N * T), oy(N * T);
     std::vector<uint8_t> ost(N * T);
     std::vector<int32_t> ocur(6 * T);
@@ -45,8 +47,8 @@ static int run(int T, int K, int policy, uint64_t seed) {
             x.load(S, t);
             double hb; uint32_t mask = x.valid_mask(hb);
             ActionRng rng;
-            x.begin_step(S, pick_action(S, rng, (uint32_t)t, x.step_serial, mask, policy), hb);
-            x.run(S, t, (uint32_t)t, lds, true);
+            x.begin_step(H, pick_action(H, rng, (uint32_t)t, x.step_serial, mask, policy), hb);
+            x.run(H, t, (uint32_t)t, lds, true);
             x.store(S, t);
         }
         orc_get_f64(o, 0, oc.data()); orc_get_f64(o, 1, ob.data()); orc_get_f64(o, 2, op.data()); orc_get_f64(o, 3, oy.data());
@@ -71,7 +73,30 @@ static int run(int T, int K, int policy, uint64_t seed) {
     return 0;
 }
 
+// exhaustive: eval7_distinct (host build of the device function) vs the oracle over all C(52,7) hands
+static int check_eval7() {
+    std::vector<uint32_t> out(2200000);
+    size_t total = 0, bad = 0;
+    for (int a = 0; a < 52; ++a)
+        for (int b = a + 1; b < 52; ++b) {
+            size_t n = orc_eval7_prefix(a, b, out.data());
+            size_t i = 0;
+            auto canon = [](int c) { return (uint32_t)(((c % 4) << 4) | (c / 4)); };
+            for (int c = b + 1; c < 52; ++c) for (int d = c + 1; d < 52; ++d) for (int e = d + 1; e < 52; ++e)
+            for (int f = e + 1; f < 52; ++f) for (int g = f + 1; g < 52; ++g) {
+                uint32_t h[7] = {canon(a), canon(b), canon(c), canon(d), canon(e), canon(f), canon(g)};
+                uint32_t v = eval7_distinct(h);
+                if (v != out[i]) { if (bad++ < 5) printf("eval7 MISMATCH %d %d %d %d %d %d %d: %x vs %x\n", a, b, c, d, e, f, g, v, out[i]); }
+                ++i; ++total;
+            }
+            if (i != n) { printf("count mismatch\n"); return 1; }
+        }
+    printf("eval7_distinct vs oracle: %zu hands, %zu mismatches\n", total, bad);
+    return bad != 0;
+}
+
 int main(int argc, char **argv) {
+    if (argc > 1 && !strcmp(argv[1], "eval7")) return check_eval7();
     int T = argc > 1 ? atoi(argv[1]) : 256, K = argc > 2 ? atoi(argv[2]) : 400;
     int rc = 0;
     rc |= run<2>(T, K, 0, 0x706F6B65726Cull);
