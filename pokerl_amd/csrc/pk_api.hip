@@ -19,18 +19,31 @@ using namespace pk;
 #define PK_TABLE_BLOCK 64
 
 __device__ __forceinline__ void wave_add_counters(const State &S, uint32_t steps, uint32_t hands, uint32_t evals, uint32_t games) {
-    // 64-wide butterfly reduction in registers, one atomic per wave and counter.
+    // 64-wide butterfly reduction in registers, then lane 0 adds to the slot this wavefront owns (plain RMW, no atomics).
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         steps += __shfl_down(steps, off, 64); hands += __shfl_down(hands, off, 64);
         evals += __shfl_down(evals, off, 64); games += __shfl_down(games, off, 64);
     }
     if ((threadIdx.x & 63) == 0) {
-        if (steps) atomicAdd(&S.counters[PK_C_STEPS], (unsigned long long)steps);
-        if (hands) atomicAdd(&S.counters[PK_C_HANDS], (unsigned long long)hands);
-        if (evals) atomicAdd(&S.counters[PK_C_EVALS], (unsigned long long)evals);
-        if (games) atomicAdd(&S.counters[PK_C_GAMES], (unsigned long long)games);
+        unsigned long long *slot = S.counters + (size_t)blockIdx.x * PK_NUM_COUNTERS;
+        slot[PK_C_STEPS] += steps; slot[PK_C_HANDS] += hands; slot[PK_C_EVALS] += evals; slot[PK_C_GAMES] += games;
     }
+}
+
+// Sums and clears the per-wave counter slots: one workgroup, grid-stride over the slots.
+__global__ void __launch_bounds__(256) k_sum_counters(unsigned long long *slots, int nslots, unsigned long long *out) {
+    __shared__ unsigned long long part[256][PK_NUM_COUNTERS];
+    unsigned long long acc[PK_NUM_COUNTERS] = {0, 0, 0, 0};
+    for (int i = threadIdx.x; i < nslots; i += 256)
+        for (int c = 0; c < PK_NUM_COUNTERS; ++c) { acc[c] += slots[(size_t)i * PK_NUM_COUNTERS + c]; slots[(size_t)i * PK_NUM_COUNTERS + c] = 0; }
+    for (int c = 0; c < PK_NUM_COUNTERS; ++c) part[threadIdx.x][c] = acc[c];
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) for (int c = 0; c < PK_NUM_COUNTERS; ++c) part[threadIdx.x][c] += part[threadIdx.x + s][c];
+        __syncthreads();
+    }
+    if (threadIdx.x < PK_NUM_COUNTERS) out[threadIdx.x] = part[0][threadIdx.x];
 }
 
 template <int N>
@@ -376,6 +389,7 @@ struct pk_handle {
     State S{};
     State *d_S = nullptr;  // device copy of S (kernels that take the state by pointer)
     Hot hot{};             // loop scalars, passed by value
+    unsigned long long *d_totals = nullptr;  // [PK_NUM_COUNTERS] output of k_sum_counters
     void *arena = nullptr;
     // staging (device)
     int32_t *d_actions = nullptr;
@@ -472,7 +486,7 @@ int pk_create(pk_handle **out, int device, int num_tables, int num_players, cons
     size_t obs = (size_t)PK_OBS_DIM(N) * 8;
     h->export_bytes = al(T * (obs > N * 8 ? obs : N * 8));
     size_t total = 4 * al(T * N * 8) + al(T * 8) + al(T * 8) + 4 * al(T * 4) + al(W * T * 4) + al(N * T * 4) + 2 * al(T) +
-                   al(PK_NUM_COUNTERS * 8) + al(PF_SLOTS * 8) + al(sizeof(State)) + al(PK_MAX_PLAYERS * 8) + al(T * 4) + 5 * al(T) + al(T * 8) + h->export_bytes;
+                   al(((T + PK_TABLE_BLOCK - 1) / PK_TABLE_BLOCK) * PK_NUM_COUNTERS * 8) + al(PK_NUM_COUNTERS * 8) + al(PF_SLOTS * 8) + al(sizeof(State)) + al(PK_MAX_PLAYERS * 8) + al(T * 4) + 5 * al(T) + al(T * 8) + h->export_bytes;
     e = hipMalloc(&h->arena, total);
     if (e != hipSuccess) return bail(h->fail(PK_E_OOM, "hipMalloc(table state)", e));
     if (hipMemsetAsync(h->arena, 0, total, h->stream) != hipSuccess) return bail(h->fail(PK_E_HIP, "hipMemset"));
@@ -488,7 +502,8 @@ int pk_create(pk_handle **out, int device, int num_tables, int num_players, cons
     S.cards = (uint32_t *)take(W * T * 4);
     S.show = (uint32_t *)take(N * T * 4);
     S.valid = (uint8_t *)take(T); S.terr = (uint8_t *)take(T);
-    S.counters = (unsigned long long *)take(PK_NUM_COUNTERS * 8);
+    S.counters = (unsigned long long *)take(((T + PK_TABLE_BLOCK - 1) / PK_TABLE_BLOCK) * PK_NUM_COUNTERS * 8);
+    h->d_totals = (unsigned long long *)take(PK_NUM_COUNTERS * 8);
     S.prof = (unsigned long long *)take(PF_SLOTS * 8);
     h->d_S = (State *)take(sizeof(State));
     double *d_start = (double *)take(PK_MAX_PLAYERS * 8);
@@ -687,8 +702,9 @@ static int launch_rollout(pk_handle *h, int k_steps, int policy, int auto_reset,
 
 static int fetch_counters(pk_handle *h, uint64_t *counters) {
     unsigned long long c[PK_NUM_COUNTERS];
-    HIPCHK(h, hipMemcpyAsync(c, h->S.counters, sizeof(c), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipMemsetAsync(h->S.counters, 0, sizeof(c), h->stream));
+    hipLaunchKernelGGL(k_sum_counters, dim3(1), dim3(256), 0, h->stream, h->S.counters, table_grid(h), h->d_totals);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(c, h->d_totals, sizeof(c), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     for (int i = 0; i < PK_NUM_COUNTERS; ++i) counters[i] += c[i];
     return PK_OK;

@@ -35,7 +35,8 @@ struct State {
     uint32_t *show;                              // [N][T]   last showdown: HandRanking<<20 | kickers value
     uint8_t *valid;                              // [T]      valid-action bitmask of the active player (game.py:339-383)
     uint8_t *terr;                               // [T]      PK_TERR_* of the last call
-    unsigned long long *counters;                // [PK_NUM_COUNTERS]
+    unsigned long long *counters;                // [waves][PK_NUM_COUNTERS]: one slot per wavefront, no atomics (4 096
+                                                 // contended atomicAdds per launch cost ~46 us); summed by k_sum_counters
     unsigned long long *prof;                    // [PF_SLOTS], diagnostic build only
     double start_credits[PK_MAX_PLAYERS];
     double big_blind, small_blind;
