@@ -154,6 +154,14 @@ int pk_env_step(pk_handle *h, const int32_t *actions, int opp_policy, double *re
 #define PK_OBS_DIM(n) (3 + 7 + 2 + 5 + 3 * (n))
 int pk_get_obs(pk_handle *h, double *out /* [T][PK_OBS_DIM(N)] */);
 
+/* Device-resident variants for a learner that lives on the same GPU (no host round trip; asynchronous on the handle's
+ * stream -- order against your own stream with pk_sync or an event): out_d / actions_d / ... are DEVICE pointers. */
+int pk_get_obs_d(pk_handle *h, double *out_d /* [T][PK_OBS_DIM(N)] */);
+int pk_get_valid_actions_d(pk_handle *h, uint8_t *out_d /* [T][7] one-hot */);
+int pk_env_step_d(pk_handle *h, const int32_t *actions_d, int opp_policy, double *reward_d, uint8_t *done_d,
+                  uint8_t *hand_d, uint8_t *terr_d);
+int pk_env_reset_d(pk_handle *h, const uint8_t *mask_d /* NULL = all */, int opp_policy);
+
 /* Stream control / timing helpers (no torch types: plain HIP underneath). */
 int pk_sync(pk_handle *h);
 /* Runs `reps` back-to-back fused rollouts of k_steps each and returns the average device time of one launch in

@@ -681,6 +681,41 @@ int pk_get_obs(pk_handle *h, double *out) {
     });
 }
 
+int pk_get_obs_d(pk_handle *h, double *out_d) {
+    if (!h || !out_d) return PK_E_INVALID_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    hipLaunchKernelGGL(k_obs, dim3(flat_grid(h->T)), dim3(256), 0, h->stream, h->S, h->N, out_d);
+    HIPCHK(h, hipGetLastError());
+    return PK_OK;
+}
+
+int pk_get_valid_actions_d(pk_handle *h, uint8_t *out_d) {
+    if (!h || !out_d) return PK_E_INVALID_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    size_t n = (size_t)h->T * PK_NUM_MOVES;
+    hipLaunchKernelGGL(k_export_valid, dim3(flat_grid(n)), dim3(256), 0, h->stream, h->S.valid, h->T, out_d);
+    HIPCHK(h, hipGetLastError());
+    return PK_OK;
+}
+
+int pk_env_reset_d(pk_handle *h, const uint8_t *mask_d, int opp_policy) {
+    if (!h || opp_policy < 0 || opp_policy > 1) return h ? h->fail(PK_E_INVALID_ARG, "pk_env_reset_d: bad argument") : PK_E_INVALID_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    DISPATCH_N(h, k_env_reset, table_grid(h), h->S, h->hot, mask_d, opp_policy);
+    HIPCHK(h, hipGetLastError());
+    return PK_OK;
+}
+
+int pk_env_step_d(pk_handle *h, const int32_t *actions_d, int opp_policy, double *reward_d, uint8_t *done_d,
+                  uint8_t *hand_d, uint8_t *terr_d) {
+    if (!h || !actions_d || !reward_d || !done_d || !hand_d || !terr_d || opp_policy < 0 || opp_policy > 1)
+        return h ? h->fail(PK_E_INVALID_ARG, "pk_env_step_d: bad argument") : PK_E_INVALID_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    DISPATCH_N(h, k_env_step, table_grid(h), h->S, h->hot, actions_d, opp_policy, reward_d, done_d, hand_d, terr_d);
+    HIPCHK(h, hipGetLastError());
+    return PK_OK;
+}
+
 int pk_pick_actions(pk_handle *h, int policy, int32_t *actions) {
     if (!h || !actions || policy < 0 || policy > 1) return h ? h->fail(PK_E_INVALID_ARG, "pk_pick_actions: bad argument") : PK_E_INVALID_ARG;
     HIPCHK(h, hipSetDevice(h->device));

@@ -367,3 +367,58 @@ def test_bench_two_ranks_rehearsal(tmp_path):
     assert r["n_gpus"] == 2 and r["scaling"] == "weak" and r["steps"] == 256
     assert r["value"] > 0 and abs(r["value"] - 2 * 8192 * 256 / (r["ms_per_step"] * 256 / 1e3)) / r["value"] < 1e-6
     assert "cpu_baseline" not in r and r["roofline"]["frac"] > 0
+
+
+def test_device_resident_env_loop(HB, O):
+    """A learner on the same GPU: pk_env_reset_d / pk_get_obs_d / pk_get_valid_actions_d / pk_env_step_d with every
+    buffer in HBM, checked against the host-buffer entry points and the oracle."""
+    import ctypes as C
+    import pokerl_amd
+    from pokerl_amd import _lib as L
+    hip = C.CDLL("libamdhip64.so")
+    T, N = 2048, 6
+    D = 17 + 3 * N
+    env = pokerl_amd.VecPokerGameEnv(0, num_tables=T, num_players=N, seed=31)
+    g = env.game
+    o = O.OracleGame(T, N, seed=31)
+    lib = L.lib()
+
+    def dmalloc(nbytes):
+        p = C.c_void_p()
+        assert hip.hipMalloc(C.byref(p), nbytes) == 0
+        return p
+
+    d_obs, d_valid, d_act = dmalloc(T * D * 8), dmalloc(T * 7), dmalloc(T * 4)
+    d_rew, d_done, d_hand, d_terr, d_mask = dmalloc(T * 8), dmalloc(T), dmalloc(T), dmalloc(T), dmalloc(T)
+
+    def d2h(ptr, arr):
+        assert hip.hipMemcpy(arr.ctypes.data_as(C.c_void_p), ptr, arr.nbytes, 2) == 0
+        return arr
+
+    L.check(lib.pk_env_reset_d(g._h, None, 0), g._h)
+    o.env_reset(None, 0)
+    for s in range(60):
+        L.check(lib.pk_get_obs_d(g._h, d_obs), g._h)
+        L.check(lib.pk_get_valid_actions_d(g._h, d_valid), g._h)
+        g.sync()
+        obs = d2h(d_obs, np.zeros((T, D), np.float64))
+        valid = d2h(d_valid, np.zeros((T, 7), np.uint8))
+        assert GU.bits_equal(obs, g.observations) and np.array_equal(valid, g.get_valid_actions()[0].astype(np.uint8))
+        a = o.pick_actions(0)
+        assert all(valid[np.arange(T), a] == 1)
+        ro, do, ho, eo = o.env_step(a, 0)
+        assert hip.hipMemcpy(d_act, a.ctypes.data_as(C.c_void_p), T * 4, 1) == 0
+        L.check(lib.pk_env_step_d(g._h, d_act, 0, d_rew, d_done, d_hand, d_terr), g._h)
+        g.sync()
+        assert GU.bits_equal(ro, d2h(d_rew, np.zeros(T, np.float64)))
+        done = d2h(d_done, np.zeros(T, np.uint8))
+        assert np.array_equal(do, done) and np.array_equal(ho, d2h(d_hand, np.zeros(T, np.uint8)))
+        assert not d2h(d_terr, np.zeros(T, np.uint8)).any()
+        if done.any():
+            assert hip.hipMemcpy(d_mask, done.ctypes.data_as(C.c_void_p), T, 1) == 0
+            L.check(lib.pk_env_reset_d(g._h, d_mask, 0), g._h)
+            o.env_reset(done, 0)
+    g.sync()
+    assert GU.bits_equal(o.f64(0), g.credits) and GU.bits_equal(o.f64(3), g.payoffs)
+    for p in (d_obs, d_valid, d_act, d_rew, d_done, d_hand, d_terr, d_mask):
+        hip.hipFree(p)
