@@ -45,6 +45,10 @@ extern "C" {
 #define PK_TERR_NO_WINNER 2      /* Game.end_hand AssertionError, pokerl/game.py:473: state partially mutated as in the reference */
 #define PK_TERR_HAND_CAP 4       /* more than PK_HAND_CAP hands rolled inside one step (reference would keep looping) */
 #define PK_HAND_CAP 64
+#define PK_TERR_ENV_CAP 8        /* PokerGameEnv.reset/step auto-played more than PK_ENV_STEP_CAP opponent steps without
+                                    reaching seat 0 or the end of the game (the reference's loops, envs/game_env.py:24,
+                                    :41, :49, would still be spinning -- e.g. seat 0 broke with the game not over) */
+#define PK_ENV_STEP_CAP 8192
 
 /* step flags (bit set) = the tuple Game.step returns, pokerl/game.py:634-641 */
 #define PK_FLAG_GAME_OVER 1

@@ -12,7 +12,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libpokerl_oracle.so")
 
-ERR_INVALID_ACTION, ERR_NO_WINNER, ERR_HAND_CAP = 1, 2, 4
+ERR_INVALID_ACTION, ERR_NO_WINNER, ERR_HAND_CAP, ERR_ENV_CAP = 1, 2, 4, 8
 F_CREDITS, F_BETS, F_PENDING, F_PAYOFFS = 0, 1, 2, 3
 
 _u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")

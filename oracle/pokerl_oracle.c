@@ -513,10 +513,13 @@ int orc_rollout(orc_game *g, int K, int policy, int auto_reset, uint64_t *counte
 /* envs/game_env.py:20-29 */
 static void env_reset_table(orc_game *g, table_t *t, int opp_policy) {
     reset_table(g, t, 0);                                                          /* :23 */
+    int budget = ORC_ENV_STEP_CAP;
     while (t->active_player != 0) {                                                /* :24 */
         uint8_t fl;
         int a = pick_action(g->seed, t, opp_policy, valid_actions(g, t, t->active_player)); /* :25 */
-        if (step_table(g, t, a, &fl)) return;                                      /* :26 */
+        int e = step_table(g, t, a, &fl);                                          /* :26 */
+        if (--budget < 0) t->err |= ORC_ERR_ENV_CAP;
+        if (e || t->err) return;
         if (fl & 1) reset_table(g, t, 0);                                          /* :27 */
     }
 }
@@ -540,15 +543,20 @@ int orc_env_step(orc_game *g, const int32_t *actions, int opp_policy, double *re
             if (err) err[i] = 0;
             continue;
         }
+        int budget = ORC_ENV_STEP_CAP;
         while (!hand && t->active_player != 0) {                                   /* :41-44 */
             int a = pick_action(g->seed, t, opp_policy, valid_actions(g, t, t->active_player));
-            if ((e = step_table(g, t, a, &fl))) break;
+            e = step_table(g, t, a, &fl);
+            if (--budget < 0) { t->err |= ORC_ERR_ENV_CAP; e |= ORC_ERR_ENV_CAP; }
+            if (e) break;
             done = fl & 1; hand = (fl >> 1) & 1;
         }
-        if (hand) rew = t->payoffs[0];                                             /* :47 */
+        if (!e && hand) rew = t->payoffs[0];                                       /* :47 */
         while (!e && !done && t->active_player != 0) {                             /* :49-52 */
             int a = pick_action(g->seed, t, opp_policy, valid_actions(g, t, t->active_player));
-            if ((e = step_table(g, t, a, &fl))) break;
+            e = step_table(g, t, a, &fl);
+            if (--budget < 0) { t->err |= ORC_ERR_ENV_CAP; e |= ORC_ERR_ENV_CAP; }
+            if (e) break;
             done = fl & 1;
         }
         reward[i] = rew; done_out[i] = (uint8_t)done; hand_out[i] = (uint8_t)hand; /* :53 */

@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("POKERL_HIP_LIB") or os.path.join(HERE, "libpokerl_hip.so")  # override: diagnostic builds
 
 PK_OK, PK_E_INVALID_ARG, PK_E_NO_DEVICE, PK_E_HIP, PK_E_OOM, PK_E_TABLE = 0, -1, -2, -3, -4, -5
-TERR_INVALID_ACTION, TERR_NO_WINNER, TERR_HAND_CAP = 1, 2, 4
+TERR_INVALID_ACTION, TERR_NO_WINNER, TERR_HAND_CAP, TERR_ENV_CAP = 1, 2, 4, 8
 FLAG_GAME_OVER, FLAG_HAND_OVER, FLAG_TURN_OVER = 1, 2, 4
 F_CREDITS, F_BETS, F_PENDING_BETS, F_PAYOFFS = 0, 1, 2, 3
 (I_ACTIVE_PLAYER, I_TURN, I_DEALER_IDX, I_SMALL_BLIND_IDX, I_BIG_BLIND_IDX, I_HAND, I_HAND_SERIAL,

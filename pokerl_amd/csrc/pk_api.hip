@@ -168,10 +168,12 @@ __global__ void __launch_bounds__(PK_TABLE_BLOCK) k_env_reset(State S, Hot H, co
     double high_bet;
     uint32_t vm = tb.valid_mask(high_bet);
     bool more = live && tb.active != 0;                                            // :24
+    int budget = PK_ENV_STEP_CAP;  // every wave-uniform loop in this file has an exit all lanes reach
     while (__any(more)) {
         if (more) tb.begin_step(H, pick_action(H, rng, table_id, tb.step_serial, vm, opp_policy), high_bet);  // :25-26
         tb.run(H, t, table_id, lds, false);
         if (more) {
+            if (--budget < 0) tb.terr |= PK_TERR_ENV_CAP;
             if (tb.terr) more = false;
             else {
                 if (tb.flags & PK_FLAG_GAME_OVER) { tb.reset_state(H, 0); tb.deal(H, table_id); }  // :27
@@ -209,10 +211,12 @@ __global__ void __launch_bounds__(PK_TABLE_BLOCK) k_env_step(State S, Hot H, con
     if (!fin && (done || (tb.st_broken & 1))) { rew = tb.payoffs[0]; done = true; hand = true; fin = true; }  // :37-39
     vm = tb.valid_mask(high_bet);
     bool more = !fin && !hand && tb.active != 0;                                   // :41
+    int budget = PK_ENV_STEP_CAP;
     while (__any(more)) {
         if (more) tb.begin_step(H, pick_action(H, rng, table_id, tb.step_serial, vm, opp_policy), high_bet);  // :43-44
         tb.run(H, t, table_id, lds, false);
         if (more) {
+            if (--budget < 0) tb.terr |= PK_TERR_ENV_CAP;
             if (tb.terr) { fin = true; more = false; }
             else {
                 done = tb.flags & PK_FLAG_GAME_OVER; hand = tb.flags & PK_FLAG_HAND_OVER;
@@ -227,6 +231,7 @@ __global__ void __launch_bounds__(PK_TABLE_BLOCK) k_env_step(State S, Hot H, con
         if (more) tb.begin_step(H, pick_action(H, rng, table_id, tb.step_serial, vm, opp_policy), high_bet);  // :51-52
         tb.run(H, t, table_id, lds, false);
         if (more) {
+            if (--budget < 0) tb.terr |= PK_TERR_ENV_CAP;
             if (tb.terr) { fin = true; more = false; }
             else { done = tb.flags & PK_FLAG_GAME_OVER; more = !done && tb.active != 0; }
         }

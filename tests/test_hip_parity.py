@@ -422,3 +422,17 @@ def test_device_resident_env_loop(HB, O):
     assert GU.bits_equal(o.f64(0), g.credits) and GU.bits_equal(o.f64(3), g.payoffs)
     for p in (d_obs, d_valid, d_act, d_rew, d_done, d_hand, d_terr, d_mask):
         hip.hipFree(p)
+
+
+def test_env_loops_are_bounded(HB, O):
+    """Seat 0 starts with no chips: once it is broke the reference's PokerGameEnv.reset loop (envs/game_env.py:24-27)
+    never sees seat 0 active again and spins for ever.  The kernel must not hang the GPU: PK_TERR_ENV_CAP after
+    PK_ENV_STEP_CAP auto-played steps, with the same state the (equally capped) oracle reaches."""
+    T, N = 64, 3
+    o = O.OracleGame(T, N, [0, 100, 100], 2, 1, seed=3)
+    h = HB(T, N, [0, 100, 100], 2, 1, seed=3)
+    o.env_reset(None, 1)
+    h.env_reset(None, 1)
+    assert_same(o.snapshot(), h.snapshot(), "capped env reset")
+    import pokerl_amd
+    assert (h.g.step_serial >= 8192).all()   # every table ran into the cap
