@@ -387,7 +387,7 @@ __global__ void k_eval7_prefix(int a, int b, int fast, uint32_t count, uint32_t 
 static thread_local std::string g_err;
 
 struct pk_handle {
-    int device = 0, T = 0, N = 0, Tpad = 0, block = 64, dealer = 0;
+    int device = 0, T = 0, N = 0, block = 64, dealer = 0;
     int park = 40;  // lanes parked at end_hand before a wave runs end_block (k_rollout); tuning knob PK_PARK
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -410,6 +410,21 @@ struct pk_handle {
         return code;
     }
 };
+
+// Entry points run on the handle's device but leave the caller's current device as they found it (a host
+// application may be driving other GPUs, e.g. through torch, from the same thread).
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int device) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        ok = hipSetDevice(device) == hipSuccess;
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+#define ON_DEVICE(h)                                             \
+    DeviceGuard guard_((h)->device);                             \
+    if (!guard_.ok) return (h)->fail(PK_E_HIP, "hipSetDevice")
 
 #define HIPCHK(h, call)                                            \
     do {                                                           \
@@ -438,7 +453,7 @@ static inline int flat_grid(size_t n) { return (int)((n + 255) / 256); }
 
 template <typename F>
 static int export_to_host(pk_handle *h, void *out, size_t bytes, F launch) {
-    HIPCHK(h, hipSetDevice(h->device));
+    ON_DEVICE(h);
     if (bytes > h->export_bytes) return h->fail(PK_E_INVALID_ARG, "export buffer too small");
     launch();
     HIPCHK(h, hipGetLastError());
@@ -481,7 +496,8 @@ int pk_create(pk_handle **out, int device, int num_tables, int num_players, cons
     h->block = PK_TABLE_BLOCK;
     if (const char *pk = getenv("PK_PARK")) { int v = atoi(pk); if (v >= 1 && v <= 64) h->park = v; }
     auto bail = [&](int code) { g_err = h->err; pk_destroy(h); return code; };
-    if (hipSetDevice(device) != hipSuccess) return bail(h->fail(PK_E_HIP, "hipSetDevice"));
+    DeviceGuard guard(device);
+    if (!guard.ok) return bail(h->fail(PK_E_HIP, "hipSetDevice"));
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return bail(h->fail(PK_E_HIP, "hipStreamCreate"));
     if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) return bail(h->fail(PK_E_HIP, "hipEventCreate"));
 
@@ -529,10 +545,9 @@ int pk_create(pk_handle **out, int device, int num_tables, int num_players, cons
         int d = ((dealer % num_players) + num_players) % num_players;
         std::vector<uint32_t> cur(T, (uint32_t)d << 4);
         std::vector<uint32_t> show(N * T, NONE_V);
-        std::vector<uint8_t> valid(T, 0x7f);  // all credits/pending 0: FOLD, CHECK, ALL_IN valid; literal value set below
-        // literal get_valid_actions on the zero state: raises invalid (0 > 0 false), CHECK valid (high_bet == 0),
-        // CALL invalid (0 < 0 false) -> FOLD|CHECK|ALL_IN
-        for (auto &v : valid) v = (1u << MV_FOLD) | (1u << MV_CHECK) | (1u << MV_ALL_IN);
+        // get_valid_actions on the un-reset state (all credits and pending bets 0): raises invalid (0 > 0 is false),
+        // CHECK valid (high_bet == 0), CALL invalid (0 < 0 is false) -> FOLD | CHECK | ALL_IN
+        std::vector<uint8_t> valid(T, (uint8_t)((1u << MV_FOLD) | (1u << MV_CHECK) | (1u << MV_ALL_IN)));
         h->hot.big_blind = big_blind; h->hot.small_blind = small_blind; h->hot.start_credits = d_start; h->hot.show = S.show;
         h->hot.key0 = S.key0; h->hot.key1 = S.key1; h->hot.table_id_base = table_id_base; h->hot.T = num_tables;
         if (hipMemcpyAsync(d_start, S.start_credits, PK_MAX_PLAYERS * 8, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
@@ -550,7 +565,7 @@ int pk_create(pk_handle **out, int device, int num_tables, int num_players, cons
 
 int pk_destroy(pk_handle *h) {
     if (!h) return PK_OK;
-    (void)hipSetDevice(h->device);
+    DeviceGuard guard(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->arena) (void)hipFree(h->arena);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -574,7 +589,7 @@ static int upload_mask(pk_handle *h, const uint8_t *mask, const uint8_t **dmask)
 
 int pk_reset(pk_handle *h, const uint8_t *mask, int dealer) {
     if (!h) return PK_E_INVALID_ARG;
-    HIPCHK(h, hipSetDevice(h->device));
+    ON_DEVICE(h);
     const uint8_t *dmask;
     int rc = upload_mask(h, mask, &dmask);
     if (rc) return rc;
@@ -587,7 +602,7 @@ int pk_reset(pk_handle *h, const uint8_t *mask, int dealer) {
 
 int pk_step_d(pk_handle *h, const int32_t *actions_d, uint8_t *flags_d, uint8_t *terr_d) {
     if (!h || !actions_d || !flags_d) return h ? h->fail(PK_E_INVALID_ARG, "pk_step_d: NULL buffer") : PK_E_INVALID_ARG;
-    HIPCHK(h, hipSetDevice(h->device));
+    ON_DEVICE(h);
     DISPATCH_N(h, k_step, table_grid(h), h->S, h->hot, actions_d, flags_d, terr_d);
     HIPCHK(h, hipGetLastError());
     return PK_OK;
@@ -600,7 +615,7 @@ static int any_terr(const uint8_t *terr, int T) {
 
 int pk_step(pk_handle *h, const int32_t *actions, uint8_t *flags, uint8_t *terr) {
     if (!h || !actions || !flags) return h ? h->fail(PK_E_INVALID_ARG, "pk_step: NULL buffer") : PK_E_INVALID_ARG;
-    HIPCHK(h, hipSetDevice(h->device));
+    ON_DEVICE(h);
     const size_t T = (size_t)h->T;
     HIPCHK(h, hipMemcpyAsync(h->d_actions, actions, T * 4, hipMemcpyHostToDevice, h->stream));
     int rc = pk_step_d(h, h->d_actions, h->d_flags, h->d_terr);
@@ -633,7 +648,7 @@ int pk_get_f64(pk_handle *h, int field, double *out) {
 
 int pk_get_min_raise(pk_handle *h, double *out) {
     if (!h || !out) return PK_E_INVALID_ARG;
-    HIPCHK(h, hipSetDevice(h->device));
+    ON_DEVICE(h);
     HIPCHK(h, hipMemcpyAsync(out, h->S.min_raise, (size_t)h->T * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return PK_OK;
@@ -665,7 +680,7 @@ int pk_get_cards(pk_handle *h, uint8_t *out) {
 
 int pk_get_hand_ranks(pk_handle *h, uint8_t *rank, uint32_t *kick) {
     if (!h || !rank || !kick) return PK_E_INVALID_ARG;
-    HIPCHK(h, hipSetDevice(h->device));
+    ON_DEVICE(h);
     size_t n = (size_t)h->T * h->N;
     uint32_t *dk = (uint32_t *)h->d_export;
     uint8_t *dr = (uint8_t *)h->d_export + n * 4;
@@ -688,7 +703,7 @@ int pk_get_obs(pk_handle *h, double *out) {
 
 int pk_get_obs_d(pk_handle *h, double *out_d) {
     if (!h || !out_d) return PK_E_INVALID_ARG;
-    HIPCHK(h, hipSetDevice(h->device));
+    ON_DEVICE(h);
     hipLaunchKernelGGL(k_obs, dim3(flat_grid(h->T)), dim3(256), 0, h->stream, h->S, h->N, out_d);
     HIPCHK(h, hipGetLastError());
     return PK_OK;
@@ -696,7 +711,7 @@ int pk_get_obs_d(pk_handle *h, double *out_d) {
 
 int pk_get_valid_actions_d(pk_handle *h, uint8_t *out_d) {
     if (!h || !out_d) return PK_E_INVALID_ARG;
-    HIPCHK(h, hipSetDevice(h->device));
+    ON_DEVICE(h);
     size_t n = (size_t)h->T * PK_NUM_MOVES;
     hipLaunchKernelGGL(k_export_valid, dim3(flat_grid(n)), dim3(256), 0, h->stream, h->S.valid, h->T, out_d);
     HIPCHK(h, hipGetLastError());
@@ -705,7 +720,7 @@ int pk_get_valid_actions_d(pk_handle *h, uint8_t *out_d) {
 
 int pk_env_reset_d(pk_handle *h, const uint8_t *mask_d, int opp_policy) {
     if (!h || opp_policy < 0 || opp_policy > 1) return h ? h->fail(PK_E_INVALID_ARG, "pk_env_reset_d: bad argument") : PK_E_INVALID_ARG;
-    HIPCHK(h, hipSetDevice(h->device));
+    ON_DEVICE(h);
     DISPATCH_N(h, k_env_reset, table_grid(h), h->S, h->hot, mask_d, opp_policy);
     HIPCHK(h, hipGetLastError());
     return PK_OK;
@@ -715,7 +730,7 @@ int pk_env_step_d(pk_handle *h, const int32_t *actions_d, int opp_policy, double
                   uint8_t *hand_d, uint8_t *terr_d) {
     if (!h || !actions_d || !reward_d || !done_d || !hand_d || !terr_d || opp_policy < 0 || opp_policy > 1)
         return h ? h->fail(PK_E_INVALID_ARG, "pk_env_step_d: bad argument") : PK_E_INVALID_ARG;
-    HIPCHK(h, hipSetDevice(h->device));
+    ON_DEVICE(h);
     DISPATCH_N(h, k_env_step, table_grid(h), h->S, h->hot, actions_d, opp_policy, reward_d, done_d, hand_d, terr_d);
     HIPCHK(h, hipGetLastError());
     return PK_OK;
@@ -723,7 +738,7 @@ int pk_env_step_d(pk_handle *h, const int32_t *actions_d, int opp_policy, double
 
 int pk_pick_actions(pk_handle *h, int policy, int32_t *actions) {
     if (!h || !actions || policy < 0 || policy > 1) return h ? h->fail(PK_E_INVALID_ARG, "pk_pick_actions: bad argument") : PK_E_INVALID_ARG;
-    HIPCHK(h, hipSetDevice(h->device));
+    ON_DEVICE(h);
     DISPATCH_N(h, k_pick, table_grid(h), h->S, h->hot, policy, h->d_actions);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipMemcpyAsync(actions, h->d_actions, (size_t)h->T * 4, hipMemcpyDeviceToHost, h->stream));
@@ -752,7 +767,7 @@ static int fetch_counters(pk_handle *h, uint64_t *counters) {
 
 int pk_rollout(pk_handle *h, int k_steps, int policy, int auto_reset, int fused, uint64_t *counters) {
     if (!h || k_steps < 0 || policy < 0 || policy > 1) return h ? h->fail(PK_E_INVALID_ARG, "pk_rollout: bad argument") : PK_E_INVALID_ARG;
-    HIPCHK(h, hipSetDevice(h->device));
+    ON_DEVICE(h);
     int rc = launch_rollout(h, k_steps, policy, auto_reset, fused);
     if (rc) return rc;
     if (counters) return fetch_counters(h, counters);
@@ -762,7 +777,7 @@ int pk_rollout(pk_handle *h, int k_steps, int policy, int auto_reset, int fused,
 int pk_time_rollout(pk_handle *h, int k_steps, int policy, int auto_reset, int fused, int reps, double *ms_per_launch,
                     uint64_t *counters) {
     if (!h || !ms_per_launch || reps < 1) return h ? h->fail(PK_E_INVALID_ARG, "pk_time_rollout: bad argument") : PK_E_INVALID_ARG;
-    HIPCHK(h, hipSetDevice(h->device));
+    ON_DEVICE(h);
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
     for (int r = 0; r < reps; ++r) {
         int rc = launch_rollout(h, k_steps, policy, auto_reset, fused);
@@ -780,7 +795,7 @@ int pk_time_rollout(pk_handle *h, int k_steps, int policy, int auto_reset, int f
 
 int pk_env_reset(pk_handle *h, const uint8_t *mask, int opp_policy) {
     if (!h || opp_policy < 0 || opp_policy > 1) return h ? h->fail(PK_E_INVALID_ARG, "pk_env_reset: bad argument") : PK_E_INVALID_ARG;
-    HIPCHK(h, hipSetDevice(h->device));
+    ON_DEVICE(h);
     const uint8_t *dmask;
     int rc = upload_mask(h, mask, &dmask);
     if (rc) return rc;
@@ -794,7 +809,7 @@ int pk_env_step(pk_handle *h, const int32_t *actions, int opp_policy, double *re
                 uint8_t *terr) {
     if (!h || !actions || !reward || !done || !hand || opp_policy < 0 || opp_policy > 1)
         return h ? h->fail(PK_E_INVALID_ARG, "pk_env_step: bad argument") : PK_E_INVALID_ARG;
-    HIPCHK(h, hipSetDevice(h->device));
+    ON_DEVICE(h);
     const size_t T = (size_t)h->T;
     HIPCHK(h, hipMemcpyAsync(h->d_actions, actions, T * 4, hipMemcpyHostToDevice, h->stream));
     DISPATCH_N(h, k_env_step, table_grid(h), h->S, h->hot, (const int32_t *)h->d_actions, opp_policy, h->d_reward, h->d_done, h->d_handf, h->d_terr);
@@ -814,7 +829,7 @@ int pk_env_step(pk_handle *h, const int32_t *actions, int opp_policy, double *re
 // Diagnostic library only: read and clear the per-block cycle sums (slots: pk_device.hpp PF_*).
 int pk_prof_read(pk_handle *h, unsigned long long *out) {
     if (!h || !out) return PK_E_INVALID_ARG;
-    HIPCHK(h, hipSetDevice(h->device));
+    ON_DEVICE(h);
     HIPCHK(h, hipMemcpyAsync(out, h->S.prof, PF_SLOTS * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemsetAsync(h->S.prof, 0, PF_SLOTS * 8, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -824,7 +839,7 @@ int pk_prof_read(pk_handle *h, unsigned long long *out) {
 
 int pk_sync(pk_handle *h) {
     if (!h) return PK_E_INVALID_ARG;
-    HIPCHK(h, hipSetDevice(h->device));
+    ON_DEVICE(h);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return PK_OK;
 }
@@ -837,7 +852,6 @@ static int check_device(int device) {
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0) { g_err = "no HIP device available; this library has no CPU fallback"; return PK_E_NO_DEVICE; }
     if (device < 0 || device >= ndev) { g_err = "device index out of range"; return PK_E_INVALID_ARG; }
-    if (hipSetDevice(device) != hipSuccess) { g_err = "hipSetDevice failed"; return PK_E_HIP; }
     return PK_OK;
 }
 
@@ -846,6 +860,8 @@ int pk_eval_hands(int device, const uint8_t *cards, const uint8_t *ncards, size_
     if (!cards || !rank || !kick) { g_err = "pk_eval_hands: NULL buffer"; return PK_E_INVALID_ARG; }
     int rc = check_device(device);
     if (rc) return rc;
+    DeviceGuard guard(device);
+    if (!guard.ok) { g_err = "hipSetDevice failed"; return PK_E_HIP; }
     if (m == 0) return PK_OK;
     tmp_handle th, *h = &th;
     uint8_t *d = nullptr;
@@ -870,6 +886,8 @@ int pk_compare_rankings(int device, const uint8_t *rank, const uint32_t *kick, i
     if (!rank || !kick || !onehot || n < 1 || n > 32) { g_err = "pk_compare_rankings: bad argument (1 <= n <= 32)"; return PK_E_INVALID_ARG; }
     int rc = check_device(device);
     if (rc) return rc;
+    DeviceGuard guard(device);
+    if (!guard.ok) { g_err = "hipSetDevice failed"; return PK_E_HIP; }
     if (m == 0) return PK_OK;
     tmp_handle th, *h = &th;
     size_t cnt = m * (size_t)n;
@@ -894,6 +912,8 @@ int pk_eval7_prefix(int device, int a, int b, int fast, uint32_t *out, size_t *c
     if (!out || a < 0 || b <= a || b > 51) { g_err = "pk_eval7_prefix: bad argument"; return PK_E_INVALID_ARG; }
     int rc = check_device(device);
     if (rc) return rc;
+    DeviceGuard guard(device);
+    if (!guard.ok) { g_err = "hipSetDevice failed"; return PK_E_HIP; }
     int n = 51 - b;
     size_t count = n >= 5 ? (size_t)n * (n - 1) * (n - 2) * (n - 3) * (n - 4) / 120 : 0;
     if (count_out) *count_out = count;

@@ -628,9 +628,6 @@ struct Table {
             uint32_t pw = (st_active | st_called | st_allin) & FULL;               // :471 (not BROKEN, not FOLDED)
             npw = __popc(pw);                                                      // :472
             nowin = npw <= 0;                                                      // :473
-#ifdef PK_HOST_SIM_DEBUG
-            printf("  end t=%d foldout=%d turn=%d npw=%d act=%x call=%x allin=%x broke=%x bets0=%g bets1=%g hands=%d\n", t, (int)foldout, turn, npw, st_active, st_called, st_allin, st_broken, bets[0], bets[1], hands_this_step);
-#endif
             if (npw == 1) {                                                        // :475-480
                 int winner = __ffs(pw) - 1;
                 double pot = np_sum<N>(bets);
@@ -710,10 +707,8 @@ struct Table {
                 double s = np_sum<N>(mb);
                 // :515 single winner: += s.  :516 split: += s*onehot/k, i.e. s/k for winners ((s*1.0)/k == s/k) and
                 // (s*0.0)/k == +0.0 for the rest (s >= 0), which leaves a non-negative payoff unchanged bit for bit.
-                double share = (nw == 1) ? s : s / (double)nw;
-#ifdef PK_HOST_SIM_DEBUG
-                printf("  sidepot t=%d player=%d max_bet=%g s=%g win=%x nw=%d npw=%d hv0=%x hv1=%x wb0=%g wb1=%g\n", t, player, max_bet, s, win, nw, npw, hv[0], hv[1], wb[0], wb[1]);
-#endif
+                double share = (nw == 2) ? s * 0.5 : s;                           // s / 2 == s * 0.5 exactly
+                if (nw > 2) share = s / (double)nw;                                // real division only for 3+-way ties
                 PK_FOR(p, N)
                     payoffs[p] = ((win >> p) & 1) ? payoffs[p] + share : payoffs[p];
                     hv[p] = (p == player) ? NONE_V : hv[p];                        // :522
