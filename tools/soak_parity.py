@@ -13,7 +13,7 @@ import golden_util as GU  # noqa: E402
 from hip_backend import HipBackend  # noqa: E402
 from oracle import loader as O  # noqa: E402
 
-CASES = [(65536, 6, 0, 4096), (65536, 9, 1, 2048), (65536, 2, 0, 4096), (16384, 10, 0, 3000)]
+CASES = [(65536, 6, 0, 4096), (65536, 9, 1, 2048), (65536, 2, 0, 4096), (16384, 10, 0, 3072)]
 THREADS = 16
 for T, N, policy, K in CASES:
     t0 = time.time()
