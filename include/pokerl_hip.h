@@ -43,8 +43,10 @@ extern "C" {
 /* per-table error bits */
 #define PK_TERR_INVALID_ACTION 1 /* Game.step ValueError, pokerl/game.py:649-651: that table is left untouched */
 #define PK_TERR_NO_WINNER 2      /* Game.end_hand AssertionError, pokerl/game.py:473: state partially mutated as in the reference */
-#define PK_TERR_HAND_CAP 4       /* more than PK_HAND_CAP hands rolled inside one step (reference would keep looping) */
-#define PK_HAND_CAP 64
+#define PK_TERR_HAND_CAP 4       /* more than PK_HAND_CAP hands rolled inside ONE step: the reference is (as good as) never
+                                    returning from Game.step (sane configs roll <= 6 hands per step; with blinds 40x the
+                                    stacks 1 315 were observed; with every seat at 0 credits the loop is infinite) */
+#define PK_HAND_CAP 4096
 #define PK_TERR_ENV_CAP 8        /* PokerGameEnv.reset/step auto-played more than PK_ENV_STEP_CAP opponent steps without
                                     reaching seat 0 or the end of the game (the reference's loops, envs/game_env.py:24,
                                     :41, :49, would still be spinning -- e.g. seat 0 broke with the game not over) */

@@ -26,7 +26,7 @@ extern "C" {
 #define ORC_ERR_INVALID_ACTION 1 /* game.py:649-651 ValueError, no mutation */
 #define ORC_ERR_NO_WINNER 2      /* game.py:473 AssertionError (state partially mutated, as in the reference) */
 #define ORC_ERR_HAND_CAP 4       /* >ORC_HAND_CAP hands inside one step (reference would keep looping) */
-#define ORC_HAND_CAP 64
+#define ORC_HAND_CAP 4096
 #define ORC_ERR_ENV_CAP 8        /* env loops auto-played more than ORC_ENV_STEP_CAP opponent steps (reference would spin on) */
 #define ORC_ENV_STEP_CAP 8192
 

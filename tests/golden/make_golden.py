@@ -11,6 +11,12 @@ What is injected (reference untouched on disk):
     of oracle/rng_spec.py for (seed, table_id, hand_serial)     [game.py:1,424]
   * pokerl.game.eval_hand -> recording wrapper (captures showdown rankings)  [game.py:489]
   * agents -> oracle/rng_spec.pick_action(seed, table_id, step_serial, mask)
+  * pokerl.game.np -> numpy with a STABLE np.argsort [game.py:495].  The side-pot order of seats with EQUAL bets is
+    whatever np.argsort returns for ties, and that is platform-dependent: numpy 2.2.6 on this AVX-512 host uses
+    x86-simd-sort (e.g. argsort([2,1,0,0,0,0,1]) = [3,2,5,4,6,1,0]), while the numpy the reference pins
+    (requirements.txt:4, 1.18.4) insertion-sorts arrays shorter than 16 and is stable.  The tie order decides who
+    collects a folded seat's surplus chips through the `num_potential_winners == 1` branch (game.py:500-505), so parity
+    is pinned to the reference's pinned-numpy behaviour: ascending seat index among equal bets.
 Everything else (Game, judger, cards, envs) is the reference's own code.
 """
 import argparse
@@ -54,6 +60,21 @@ class _DeckInjector:
 
 _injector = _DeckInjector()
 G.random = _injector
+
+
+class _StableArgsortNumpy:
+    """numpy as pokerl.game sees it: identical except that argsort's default kind is the stable one."""
+
+    def __getattr__(self, name):
+        return getattr(np, name)
+
+    @staticmethod
+    def argsort(a, *args, **kwargs):
+        kwargs.setdefault("kind", "stable")
+        return np.argsort(a, *args, **kwargs)
+
+
+G.np = _StableArgsortNumpy()
 
 _eval_sink = []
 _real_eval = G.eval_hand
@@ -142,18 +163,18 @@ def snap_digest(snaps_by_table):
 
 # --------------------------------------------------------------------------- Game trajectories
 def game_trajectory(n, policy, seed, tables, steps, table_id_base=0, cfg=None, full=True, digest_every=0,
-                    auto_reset=True):
+                    auto_reset=True, dealer=0):
     """auto_reset=False: finished games are NOT reset (the lone survivor keeps being stepped, which the
     reference allows); a survivor's FOLD then trips `assert num_potential_winners > 0` (game.py:473):
     recorded as err=2 with the partially mutated state, after which that table is reset."""
     cfg = cfg or dict(start_credits=100, big_blind=2, small_blind=1)
     ts = [Table(seed, table_id_base + i, n, **cfg) for i in range(tables)]
     for t in ts:
-        t.game.reset()
+        t.game.reset(dealer=dealer)          # only the FIRST reset takes the dealer; auto-resets use the default (0)
     init = [t.snapshot() for t in ts]
     out = {}
     meta = dict(kind="game", n=n, policy=policy, seed=seed, tables=tables, steps=steps,
-                table_id_base=table_id_base, cfg=cfg, auto_reset=auto_reset)
+                table_id_base=table_id_base, cfg=cfg, auto_reset=auto_reset, dealer=dealer)
     actions = np.zeros((steps, tables), np.int8)
     flags = np.zeros((steps, tables), np.uint8)
     errs = np.zeros((steps, tables), np.uint8)
@@ -383,6 +404,13 @@ GAME_SETS = {
                            dict(start_credits=[30, 100, 5], big_blind=4, small_blind=2)),
     "game_n10_random": (10, R.POLICY_RANDOM, 99, 4, 150, 5, None),
 }
+# odd configurations found worth pinning by tests/golden/fuzz_oracle_vs_reference.py: (n, policy, seed, tables, steps, base, cfg, dealer)
+ODD_SETS = {
+    "game_n5_zero_blinds": (5, R.POLICY_RANDOM, 21, 6, 150, 9, dict(start_credits=10, big_blind=0, small_blind=0), 3),
+    "game_n4_sb_gt_bb_fractional": (4, R.POLICY_RANDOM, 22, 6, 150, 0, dict(start_credits=[37.5, 3, 1000, 0.5], big_blind=0.25, small_blind=7.5), 1),
+    "game_n7_blinds_gt_stacks": (7, R.POLICY_RANDOM, 23, 6, 150, 4000000000, dict(start_credits=5, big_blind=40, small_blind=250), 6),
+    "game_n8_mixed_allin": (8, R.POLICY_ALLIN, 24, 6, 100, 0, dict(start_credits=[1, 2, 3, 5, 10, 100, 1000, 0.5], big_blind=3, small_blind=1), 0),
+}
 NORESET_SETS = {
     "game_n2_noreset": (2, R.POLICY_RANDOM, 11, 6, 150, 0, None),
     "game_n3_noreset": (3, R.POLICY_RANDOM, 12, 6, 200, 0, dict(start_credits=20, big_blind=2, small_blind=1)),
@@ -420,6 +448,11 @@ def main():
     for name, (n, pol, seed, tables, steps, base, cfg) in GAME_SETS.items():
         if want(name):
             out = game_trajectory(n, pol, seed, tables, steps, base, cfg)
+            np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+            print(name, "resets:", len(out["reset_idx"]), "hands:", int(out["post_hand_serial"].max()))
+    for name, (n, pol, seed, tables, steps, base, cfg, dealer) in ODD_SETS.items():
+        if want(name):
+            out = game_trajectory(n, pol, seed, tables, steps, base, cfg, dealer=dealer)
             np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
             print(name, "resets:", len(out["reset_idx"]), "hands:", int(out["post_hand_serial"].max()))
     for name, (n, pol, seed, tables, steps, base, cfg) in NORESET_SETS.items():

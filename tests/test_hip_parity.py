@@ -458,3 +458,39 @@ def test_launch_splitting_and_determinism(HB):
     d.reset()
     assert not np.array_equal(d.snapshot()["cards"], HB(T, N).snapshot()["cards"]) or True
     assert not np.array_equal(d.snapshot()["cards"][:64], sa["cards"][:64])
+
+
+def test_random_configurations_vs_oracle(HB, O):
+    """Seeded fuzz over odd configurations (zero / fractional blinds, small blind above big blind, blinds larger than
+    the stacks, per-seat stacks from 0.5 to 1e6, every N, table ids anywhere in 2^32, any first dealer): fused rollout
+    and a few lockstep steps against the oracle (which tests/golden/fuzz_oracle_vs_reference.py checks against the
+    imported reference on the same kind of configurations)."""
+    import random
+    rng = random.Random(99)
+    stacks = [0.5, 1, 2, 3, 5, 10, 37.5, 100, 1000, 1e6]
+    blinds = [0, 0.25, 0.5, 1, 2, 3, 7.5, 40]
+    for i in range(36):
+        N = 2 + i % 9
+        start = [rng.choice(stacks) for _ in range(N)] if rng.random() < 0.5 else rng.choice(stacks)
+        bb, sb = rng.choice(blinds), rng.choice(blinds)
+        policy = 1 if rng.random() < 0.25 else 0
+        seed, base, dealer = rng.getrandbits(63), rng.getrandbits(32) & 0xFFFFF000, rng.randrange(N)
+        T = rng.choice([65, 128, 300])
+        o = O.OracleGame(T, N, start, bb, sb, seed=seed, table_id_base=base)
+        h = HB(T, N, start, bb, sb, seed=seed, table_id_base=base)
+        o.reset(dealer=dealer); h.reset(dealer=dealer)
+        where = "cfg %d: N=%d start=%s bb=%s sb=%s policy=%d" % (i, N, start, bb, sb, policy)
+        assert_same(o.snapshot(), h.snapshot(), where + " reset")
+        co, _ = o.rollout(120, policy, True)
+        ch = h.rollout(120, policy, True)
+        assert co.tolist() == ch.tolist(), where
+        assert_same(o.snapshot(), h.snapshot(), where + " rollout")
+        for s in range(10):
+            a = o.pick_actions(policy)
+            fo, eo = o.step(a)
+            fh, eh = h.step(a)
+            assert np.array_equal(fo, fh) and np.array_equal(eo, eh), where
+            bad = ((fo & 1) | (eo != 0)).astype(np.uint8)
+            if bad.any():
+                o.reset(mask=bad); h.reset(mask=bad)
+        assert_same(o.snapshot(), h.snapshot(), where + " lockstep")

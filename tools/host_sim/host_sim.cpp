@@ -13,8 +13,11 @@ extern "C" {
 }
 using namespace pk;
 
+struct Cfg { double start[16]; double bb, sb; uint32_t base; int dealer; };
+static Cfg default_cfg() { Cfg c; for (int p = 0; p < 16; ++p) c.start[p] = 100.0; c.bb = 2; c.sb = 1; c.base = 0; c.dealer = 0; return c; }
+
 template <int N>
-static int run(int T, int K, int policy, uint64_t seed) {
+static int run(int T, int K, int policy, uint64_t seed, Cfg cfg = default_cfg(), bool quiet = false) {
     const int KK = 5 + 2 * N, W = (KK + 3) / 4;
     std::vector<double> cr(N * T), be(N * T), pe(N * T), pa(N * T), mr(T);
     std::vector<uint64_t> ss(T, (1u << N) - 1);
@@ -26,16 +29,16 @@ static int run(int T, int K, int policy, uint64_t seed) {
     S.credits = cr.data(); S.bets = be.data(); S.pending = pe.data(); S.payoffs = pa.data(); S.min_raise = mr.data();
     S.seat_states = ss.data(); S.cursors = cur.data(); S.hand = hand.data(); S.hand_serial = hs.data(); S.step_serial = st.data();
     S.cards = cards.data(); S.show = show.data(); S.valid = valid.data(); S.terr = terr.data(); S.counters = counters; S.prof = prof;
-    for (int p = 0; p < N; ++p) S.start_credits[p] = 100.0;
-    S.big_blind = 2; S.small_blind = 1; S.key0 = (uint32_t)seed; S.key1 = (uint32_t)(seed >> 32); S.table_id_base = 0; S.T = T;
-    double sc[16]; for (int p = 0; p < 16; ++p) sc[p] = 100.0;
-    Hot H{}; H.big_blind = 2; H.small_blind = 1; H.start_credits = sc; H.show = show.data();
-    H.key0 = S.key0; H.key1 = S.key1; H.table_id_base = 0; H.T = T;
-    orc_game *o = orc_create(T, N, sc, 2, 1, seed, 0);
-    orc_reset(o, nullptr, 0);
+    for (int p = 0; p < N; ++p) S.start_credits[p] = cfg.start[p];
+    S.big_blind = cfg.bb; S.small_blind = cfg.sb; S.key0 = (uint32_t)seed; S.key1 = (uint32_t)(seed >> 32); S.table_id_base = cfg.base; S.T = T;
+    double *sc = cfg.start;
+    Hot H{}; H.big_blind = cfg.bb; H.small_blind = cfg.sb; H.start_credits = sc; H.show = show.data();
+    H.key0 = S.key0; H.key1 = S.key1; H.table_id_base = cfg.base; H.T = T;
+    orc_game *o = orc_create(T, N, sc, cfg.bb, cfg.sb, seed, cfg.base);
+    orc_reset(o, nullptr, cfg.dealer);
     static Lds<N> lds;
     std::vector<Table<N>> tb(T);
-    for (int t = 0; t < T; ++t) { tb[t].load(S, t); tb[t].reset_state(H, 0); tb[t].deal(H, (uint32_t)t); tb[t].store(S, t); }
+    for (int t = 0; t < T; ++t) { tb[t].load(S, t); tb[t].reset_state(H, cfg.dealer % N); tb[t].deal(H, cfg.base + (uint32_t)t); tb[t].store(S, t); }
     std::vector<double> oc(N * T), ob(N * T), op(N * T), oy(N * T);
     std::vector<uint8_t> ost(N * T);
     std::vector<int32_t> ocur(6 * T);
@@ -47,8 +50,8 @@ static int run(int T, int K, int policy, uint64_t seed) {
             x.load(S, t);
             double hb; uint32_t mask = x.valid_mask(hb);
             ActionRng rng;
-            x.begin_step(H, pick_action(H, rng, (uint32_t)t, x.step_serial, mask, policy), hb);
-            x.run(H, t, (uint32_t)t, lds, true);
+            x.begin_step(H, pick_action(H, rng, cfg.base + (uint32_t)t, x.step_serial, mask, policy), hb);
+            x.run(H, t, cfg.base + (uint32_t)t, lds, true);
             x.store(S, t);
         }
         orc_get_f64(o, 0, oc.data()); orc_get_f64(o, 1, ob.data()); orc_get_f64(o, 2, op.data()); orc_get_f64(o, 3, oy.data());
@@ -68,7 +71,7 @@ static int run(int T, int K, int policy, uint64_t seed) {
                 }
             }
     }
-    printf("N=%d T=%d K=%d policy=%d: host-sim == oracle\n", N, T, K, policy);
+    if (!quiet) printf("N=%d T=%d K=%d policy=%d: host-sim == oracle\n", N, T, K, policy);
     orc_destroy(o);
     return 0;
 }
@@ -95,8 +98,41 @@ static int check_eval7() {
     return bad != 0;
 }
 
+template <int N>
+static int fuzz_one(uint64_t r, int T, int K) {
+    auto next = [&]() { r ^= r << 13; r ^= r >> 7; r ^= r << 17; return r; };
+    static const double stacks[] = {0.5, 1, 2, 3, 5, 10, 37.5, 100, 1000, 1e6}, blinds[] = {0, 0.25, 0.5, 1, 2, 3, 7.5, 40, 250};
+    Cfg c;
+    bool same = next() % 2;
+    double s0 = stacks[next() % 10];
+    for (int p = 0; p < 16; ++p) c.start[p] = same ? s0 : stacks[next() % 10];
+    c.bb = blinds[next() % 9]; c.sb = blinds[next() % 9];
+    c.base = (uint32_t)next(); c.dealer = (int)(next() % N);
+    int policy = next() % 4 == 0 ? 1 : 0;
+    uint64_t seed = next();
+    int rc = run<N>(T, K, policy, seed, c, true);
+    if (rc) printf("  ^ fuzz config: N=%d policy=%d bb=%g sb=%g start0=%g same=%d dealer=%d seed=%llu base=%u\n", N, policy, c.bb, c.sb, c.start[0], (int)same, c.dealer, (unsigned long long)seed, c.base);
+    return rc;
+}
+static int fuzz(int rounds, int T, int K) {
+    int bad = 0;
+    for (int i = 0; i < rounds; ++i) {
+        uint64_t r = 0x9E3779B97F4A7C15ull * (uint64_t)(i + 1);
+        switch (i % 9) {
+            case 0: bad += fuzz_one<2>(r, T, K); break; case 1: bad += fuzz_one<3>(r, T, K); break;
+            case 2: bad += fuzz_one<4>(r, T, K); break; case 3: bad += fuzz_one<5>(r, T, K); break;
+            case 4: bad += fuzz_one<6>(r, T, K); break; case 5: bad += fuzz_one<7>(r, T, K); break;
+            case 6: bad += fuzz_one<8>(r, T, K); break; case 7: bad += fuzz_one<9>(r, T, K); break;
+            default: bad += fuzz_one<10>(r, T, K); break;
+        }
+    }
+    printf("fuzz: %d configs, %d mismatching\n", rounds, bad);
+    return bad != 0;
+}
+
 int main(int argc, char **argv) {
     if (argc > 1 && !strcmp(argv[1], "eval7")) return check_eval7();
+    if (argc > 1 && !strcmp(argv[1], "fuzz")) return fuzz(argc > 2 ? atoi(argv[2]) : 90, argc > 3 ? atoi(argv[3]) : 64, argc > 4 ? atoi(argv[4]) : 300);
     int T = argc > 1 ? atoi(argv[1]) : 256, K = argc > 2 ? atoi(argv[2]) : 400;
     int rc = 0;
     rc |= run<2>(T, K, 0, 0x706F6B65726Cull);
