@@ -118,6 +118,22 @@ def measured_traffic(tables, players, policy, kern_steps, fused):
     return best
 
 
+def evaluator_leg(device, log2_m=28, reps=5):
+    """Second half of the metric as a stand-alone kernel: pk_eval7_d streams 2^28 device-resident 7-card hands
+    (2 GiB in, 1 GiB out: far beyond L2 / Infinity Cache) -- 12 algorithmic bytes per evaluation, HBM-bound."""
+    from pokerl_amd import judger
+    from pokerl_amd.hipmem import DeviceBuffer
+    m = 1 << log2_m
+    hands, out = DeviceBuffer(m * 8), DeviceBuffer(m * 4)
+    judger.make_hands(hands.ptr, m, device=device)
+    ms = judger.time_eval7_stream(hands.ptr, m, out.ptr, True, reps, device)
+    hands.free(); out.free()
+    gbs = 12.0 * m / (ms * 1e-3) / 1e9
+    return {"kernel": "k_eval7_stream (pk_eval7_d, 7 distinct cards)", "hands": m, "hand_evals_per_s": m / (ms * 1e-3),
+            "kernel_ms": ms, "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                          "frac": gbs / HBM_PEAK_GBS, "bytes_per_eval": 12}}
+
+
 def cpu_baseline(n_players, policy, budget_s=12.0):
     """The scalar C oracle (bit-exact restatement of the reference) timed on ONE host core on a bounded sample of the
     same workload.  Reported beside the GPU number; it is not the target (the roofline fraction is)."""
@@ -168,6 +184,7 @@ def main():
     ap.add_argument("--chunk", type=int, default=512, help="steps per fused launch")
     ap.add_argument("--unfused", action="store_true", help="one launch per step (state round-trips HBM every step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-evaluator", action="store_true", help="skip the stand-alone evaluator kernel leg")
     args = ap.parse_args()
 
     ctx = DistContext()
@@ -234,6 +251,8 @@ def main():
                                  "steps of a launch, so real HBM traffic (`traffic`) is ~0.2% of that; the kernel is "
                                  "VALU-issue-bound at one wave per SIMD (DESIGN.md, Measurement)."},
         }
+        if not args.no_evaluator:
+            out["evaluator"] = evaluator_leg(device)
         if not args.no_cpu_baseline and ctx.world == 1:
             out["cpu_baseline"] = cpu_baseline(args.players, policy)
         print(json.dumps(out))

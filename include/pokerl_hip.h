@@ -43,9 +43,10 @@ extern "C" {
 /* per-table error bits */
 #define PK_TERR_INVALID_ACTION 1 /* Game.step ValueError, pokerl/game.py:649-651: that table is left untouched */
 #define PK_TERR_NO_WINNER 2      /* Game.end_hand AssertionError, pokerl/game.py:473: state partially mutated as in the reference */
-#define PK_TERR_HAND_CAP 4       /* more than PK_HAND_CAP hands rolled inside ONE step: the reference is (as good as) never
-                                    returning from Game.step (sane configs roll <= 6 hands per step; with blinds 40x the
-                                    stacks 1 315 were observed; with every seat at 0 credits the loop is infinite) */
+#define PK_TERR_HAND_CAP 4       /* the reference would (as good as) never return from this Game.step: either every seat's
+                                    credits are exactly 0 with no seat ACTIVE after a hand rolled over (each further hand
+                                    re-creates that state: detected at once), or more than PK_HAND_CAP hands were rolled
+                                    inside ONE step (sane configs roll <= 6; blinds 40x the stacks: 1 315 observed) */
 #define PK_HAND_CAP 4096
 #define PK_TERR_ENV_CAP 8        /* PokerGameEnv.reset/step auto-played more than PK_ENV_STEP_CAP opponent steps without
                                     reaching seat 0 or the end of the game (the reference's loops, envs/game_env.py:24,
@@ -133,6 +134,16 @@ int pk_eval_hands(int device, const uint8_t *cards, const uint8_t *ncards, size_
 /* pokerl.judger.compare_rankings (pokerl/judger.py:111-158) on M lists of n rankings: rank[M][n], kick[M][n] ->
  * onehot[M][n].  Includes the reference's line-148 behaviour. */
 int pk_compare_rankings(int device, const uint8_t *rank, const uint32_t *kick, int n, size_t m, uint8_t *onehot);
+
+/* Streaming evaluator on device-resident data: hands_d[m] = one 7-card hand per 64-bit word (card i = byte i, byte 7
+ * unused), out_d[m] = HandRanking<<20 | kickers value.  12 algorithmic bytes per evaluation (8 in + 4 out): HBM-bound.
+ * distinct != 0: the caller guarantees 7 DISTINCT cards per hand (every in-game hand) and the bitmask evaluator is used;
+ * distinct == 0: the general (multiset) evaluator of pk_eval_hands.  Runs on the default stream, synchronous. */
+int pk_eval7_d(int device, const uint64_t *hands_d, size_t m, uint32_t *out_d, int distinct);
+/* Synthetic workload for it: hand i = the first 7 cards of the RNG-spec deck of (seed, table_id = i, hand_serial = 0). */
+int pk_make_hands_d(int device, uint64_t seed, size_t m, uint64_t *hands_d);
+/* `reps` back-to-back passes of pk_eval7_d timed with HIP events: average milliseconds per pass. */
+int pk_time_eval7_d(int device, const uint64_t *hands_d, size_t m, uint32_t *out_d, int distinct, int reps, double *ms_per_pass);
 
 /* Exhaustive-check hook for the evaluators: v = HandRanking<<20 | kickers value of every 7-card hand whose two lowest
  * canonical deck indices (pokerl/cards.py:77 order) are (a, b), in lexicographic order; out holds C(51-b, 5) words.

@@ -390,7 +390,12 @@ static done_t next_player(orc_game *g, table_t *t) { /* game.py:578-619 */
                 done = next_turn(g, t);                                            /* :609 */
                 if (t->err) return done;
                 if (done.game) return done;                                        /* :610 */
-                if (t->hands_this_step > ORC_HAND_CAP) { t->err |= ORC_ERR_HAND_CAP; return done; }
+                /* The step can never return: (a) dead table -- every seat's credits are exactly 0 and no seat is
+                 * ACTIVE, so each further hand is a zero-chip showdown that re-creates this very state (all cap events
+                 * seen in 4e8 default-config steps are of this kind); (b) backstop: ORC_HAND_CAP hands in one step. */
+                int dead = done.hand; /* only right after end_hand + setup_hand: mid-hand, all-in seats hold 0 credits too */
+                for (int p = 0; p < n; ++p) if (t->credits[p] != 0.0 || t->states[p] == PS_ACTIVE) dead = 0;
+                if (dead || t->hands_this_step > ORC_HAND_CAP) { t->err |= ORC_ERR_HAND_CAP; return done; }
             } else t->active_player = (t->active_player + 1) % n;                  /* :611 */
         }
         return done;                                                               /* :615 */

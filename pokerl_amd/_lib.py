@@ -23,7 +23,7 @@ SYMBOLS = ["pk_abi_version", "pk_device_count", "pk_last_error", "pk_create", "p
            "pk_get_min_raise", "pk_get_player_states", "pk_get_i32", "pk_get_cards", "pk_get_hand_ranks",
            "pk_eval_hands", "pk_compare_rankings", "pk_eval7_prefix", "pk_pick_actions", "pk_rollout",
            "pk_env_reset", "pk_env_step", "pk_get_obs", "pk_sync", "pk_time_rollout", "pk_get_obs_d",
-           "pk_get_valid_actions_d", "pk_env_step_d", "pk_env_reset_d"]
+           "pk_get_valid_actions_d", "pk_env_step_d", "pk_env_reset_d", "pk_eval7_d", "pk_make_hands_d", "pk_time_eval7_d"]
 
 
 class PokerlHipError(RuntimeError):
@@ -74,6 +74,9 @@ def lib():
     L.pk_get_valid_actions_d.argtypes = [_vp, _vp]
     L.pk_env_step_d.argtypes = [_vp, _vp, C.c_int, _vp, _vp, _vp, _vp]
     L.pk_env_reset_d.argtypes = [_vp, _vp, C.c_int]
+    L.pk_eval7_d.argtypes = [C.c_int, _vp, C.c_size_t, _vp, C.c_int]
+    L.pk_make_hands_d.argtypes = [C.c_int, C.c_uint64, C.c_size_t, _vp]
+    L.pk_time_eval7_d.argtypes = [C.c_int, _vp, C.c_size_t, _vp, C.c_int, C.c_int, C.POINTER(C.c_double)]
     L.pk_sync.argtypes = [_vp]
     L.pk_time_rollout.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), _vp]
     for name in SYMBOLS:

@@ -355,6 +355,35 @@ __global__ void k_compare(const uint8_t *rank, const uint32_t *kick, int n, size
     }
     for (int p = 0; p < n; ++p) onehot[i * n + p] = (win >> p) & 1;
 }
+// Streaming evaluator: two hands per lane per iteration (one 16-byte load, one 8-byte store), grid-stride.
+template <bool DISTINCT>
+__global__ void __launch_bounds__(256) k_eval7_stream(const uint64_t *__restrict__ hands, size_t m, uint32_t *__restrict__ out) {
+    const size_t pairs = m / 2, stride = (size_t)gridDim.x * blockDim.x;
+    auto eval1 = [](uint64_t w) {
+        uint32_t lo = (uint32_t)w, hi = (uint32_t)(w >> 32);
+        uint32_t c[7] = {lo & 0xff, (lo >> 8) & 0xff, (lo >> 16) & 0xff, lo >> 24, hi & 0xff, (hi >> 8) & 0xff, (hi >> 16) & 0xff};
+        int nk;
+        return DISTINCT ? eval7_distinct(c) : eval_hand(c, 7, nk);
+    };
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < pairs; i += stride) {
+        const ulonglong2 w = reinterpret_cast<const ulonglong2 *>(hands)[i];
+        uint2 r;
+        r.x = eval1(w.x); r.y = eval1(w.y);
+        reinterpret_cast<uint2 *>(out)[i] = r;
+    }
+    if ((m & 1) && blockIdx.x == 0 && threadIdx.x == 0) out[m - 1] = eval1(hands[m - 1]);
+}
+// hand i = first 7 cards of the RNG-spec deck of (table_id = i, hand_serial = 0): the deal of a 1-seat table
+__global__ void __launch_bounds__(256) k_make_hands(Hot H, size_t m, uint64_t *out) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride) {
+        Table<1> tb;
+        tb.hand_serial = 0;
+        tb.deal(H, (uint32_t)i);
+        out[i] = (uint64_t)tb.cards[0] | ((uint64_t)(tb.cards[1] & 0x00ffffffu) << 32);
+    }
+}
+
 // Exhaustive 7-card sweep used by tests (digest definition: tests/golden/make_eval_digest.py): all hands with prefix
 // (a, b); hand index within the prefix -> combination of 5 from the cards above b is decoded per lane.
 __global__ void k_eval7_prefix(int a, int b, int fast, uint32_t count, uint32_t *out) {
@@ -903,6 +932,59 @@ int pk_compare_rankings(int device, const uint8_t *rank, const uint32_t *kick, i
     if (e == hipSuccess) e = hipMemcpy(onehot, d + off_o, cnt, hipMemcpyDeviceToHost);
     (void)hipFree(d);
     if (e != hipSuccess) return th.fail(PK_E_HIP, "pk_compare_rankings", e);
+    return PK_OK;
+}
+
+static int launch_eval7(const uint64_t *hands_d, size_t m, uint32_t *out_d, int distinct) {
+    const unsigned grid = 256 * 16;  // 16 workgroups per CU, grid-stride over the rest
+    if (distinct) hipLaunchKernelGGL(k_eval7_stream<true>, dim3(grid), dim3(256), 0, 0, hands_d, m, out_d);
+    else hipLaunchKernelGGL(k_eval7_stream<false>, dim3(grid), dim3(256), 0, 0, hands_d, m, out_d);
+    return hipGetLastError() == hipSuccess ? PK_OK : PK_E_HIP;
+}
+
+int pk_eval7_d(int device, const uint64_t *hands_d, size_t m, uint32_t *out_d, int distinct) {
+    if (!hands_d || !out_d) { g_err = "pk_eval7_d: NULL buffer"; return PK_E_INVALID_ARG; }
+    int rc = check_device(device);
+    if (rc) return rc;
+    DeviceGuard guard(device);
+    if (!guard.ok) { g_err = "hipSetDevice failed"; return PK_E_HIP; }
+    if (m == 0) return PK_OK;
+    if (launch_eval7(hands_d, m, out_d, distinct) != PK_OK || hipDeviceSynchronize() != hipSuccess) { g_err = "pk_eval7_d: launch failed"; return PK_E_HIP; }
+    return PK_OK;
+}
+
+int pk_make_hands_d(int device, uint64_t seed, size_t m, uint64_t *hands_d) {
+    if (!hands_d) { g_err = "pk_make_hands_d: NULL buffer"; return PK_E_INVALID_ARG; }
+    int rc = check_device(device);
+    if (rc) return rc;
+    DeviceGuard guard(device);
+    if (!guard.ok) { g_err = "hipSetDevice failed"; return PK_E_HIP; }
+    if (m == 0) return PK_OK;
+    Hot H{};
+    H.key0 = (uint32_t)seed; H.key1 = (uint32_t)(seed >> 32);
+    hipLaunchKernelGGL(k_make_hands, dim3(256 * 16), dim3(256), 0, 0, H, m, hands_d);
+    if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) { g_err = "pk_make_hands_d: launch failed"; return PK_E_HIP; }
+    return PK_OK;
+}
+
+int pk_time_eval7_d(int device, const uint64_t *hands_d, size_t m, uint32_t *out_d, int distinct, int reps, double *ms_per_pass) {
+    if (!hands_d || !out_d || !ms_per_pass || reps < 1) { g_err = "pk_time_eval7_d: bad argument"; return PK_E_INVALID_ARG; }
+    int rc = check_device(device);
+    if (rc) return rc;
+    DeviceGuard guard(device);
+    if (!guard.ok) { g_err = "hipSetDevice failed"; return PK_E_HIP; }
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { g_err = "hipEventCreate failed"; return PK_E_HIP; }
+    launch_eval7(hands_d, m, out_d, distinct);  // warm (instruction cache, clocks)
+    (void)hipEventRecord(e0, 0);
+    for (int r = 0; r < reps; ++r) launch_eval7(hands_d, m, out_d, distinct);
+    (void)hipEventRecord(e1, 0);
+    hipError_t e = hipEventSynchronize(e1);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (e != hipSuccess) { g_err = std::string("pk_time_eval7_d: ") + hipGetErrorString(e); return PK_E_HIP; }
+    *ms_per_pass = (double)ms / reps;
     return PK_OK;
 }
 

@@ -735,8 +735,16 @@ struct Table {
                 else {
                     flags = (go ? PK_FLAG_GAME_OVER : 0) | PK_FLAG_HAND_OVER | PK_FLAG_TURN_OVER;              // :565
                     if (go) lstate = LS_DONE;                                      // :610
-                    else if (hands_this_step > PK_HAND_CAP) { terr |= PK_TERR_HAND_CAP; lstate = LS_DONE; }
-                    else lstate = LS_SCAN;
+                    else {
+                        // The step can never return: (a) dead table -- every seat's credits are exactly 0 and no seat
+                        // is ACTIVE, so each further hand is a zero-chip showdown that re-creates this very state;
+                        // (b) backstop: PK_HAND_CAP hands inside one step.
+                        bool chips = false;
+                        PK_FOR(p, N) chips = chips || credits[p] != 0.0; PK_END
+                        const bool dead = !chips && st_active == 0;
+                        if (dead || hands_this_step > PK_HAND_CAP) { terr |= PK_TERR_HAND_CAP; lstate = LS_DONE; }
+                        else lstate = LS_SCAN;
+                    }
                 }
                 if (auto_reset && lstate == LS_DONE && (go || (terr & PK_TERR_HAND_CAP))) {
                     seen |= terr; terr = 0;

@@ -1,0 +1,46 @@
+"""Minimal device-memory helper for callers that do not already own HBM buffers (tests, bench.py): hipMalloc / hipFree /
+hipMemcpy through ctypes.  A torch / cupy user passes `tensor.data_ptr()` to the `_d` entry points instead."""
+import ctypes as C
+
+import numpy as np
+
+_hip = None
+
+
+def _lib():
+    global _hip
+    if _hip is None:
+        _hip = C.CDLL("libamdhip64.so")
+    return _hip
+
+
+class DeviceBuffer:
+    def __init__(self, nbytes):
+        self.nbytes = int(nbytes)
+        self.ptr = C.c_void_p()
+        rc = _lib().hipMalloc(C.byref(self.ptr), C.c_size_t(self.nbytes))
+        if rc != 0:
+            raise MemoryError("hipMalloc(%d) failed: %d" % (self.nbytes, rc))
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes <= self.nbytes
+        assert _lib().hipMemcpy(self.ptr, arr.ctypes.data_as(C.c_void_p), C.c_size_t(arr.nbytes), 1) == 0
+        return self
+
+    def download(self, dtype, count, offset_bytes=0):
+        out = np.zeros(count, dtype)
+        src = C.c_void_p(self.ptr.value + offset_bytes)
+        assert _lib().hipMemcpy(out.ctypes.data_as(C.c_void_p), src, C.c_size_t(out.nbytes), 2) == 0
+        return out
+
+    def free(self):
+        if self.ptr and self.ptr.value:
+            _lib().hipFree(self.ptr)
+            self.ptr = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

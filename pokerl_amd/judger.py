@@ -84,3 +84,20 @@ def eval7_prefix(a, b, fast=True, device=0):
 
 
 NONE_RANKING = (HandRanking.NONE, [])
+
+
+def eval7_stream(hands_d, m, out_d, distinct=True, device=0):
+    """pk_eval7_d: m 7-card hands resident in HBM (one per 64-bit word, card i = byte i) -> rank<<20|kickers words."""
+    L.check(L.lib().pk_eval7_d(int(device), hands_d, int(m), out_d, int(bool(distinct))))
+
+
+def make_hands(hands_d, m, seed=0x706F6B65726C, device=0):
+    """pk_make_hands_d: synthetic distinct 7-card hands (first 7 cards of the RNG-spec deck of table_id = i)."""
+    L.check(L.lib().pk_make_hands_d(int(device), int(seed), int(m), hands_d))
+
+
+def time_eval7_stream(hands_d, m, out_d, distinct=True, reps=5, device=0):
+    import ctypes as C
+    ms = C.c_double(0.0)
+    L.check(L.lib().pk_time_eval7_d(int(device), hands_d, int(m), out_d, int(bool(distinct)), int(reps), C.byref(ms)))
+    return ms.value

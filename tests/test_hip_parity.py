@@ -494,3 +494,34 @@ def test_random_configurations_vs_oracle(HB, O):
             if bad.any():
                 o.reset(mask=bad); h.reset(mask=bad)
         assert_same(o.snapshot(), h.snapshot(), where + " lockstep")
+
+
+def test_streaming_evaluator(HB, O):
+    """pk_make_hands_d + pk_eval7_d (device-resident, 12 B per evaluation) against the RNG spec and the oracle."""
+    from pokerl_amd import judger
+    from pokerl_amd.hipmem import DeviceBuffer
+    from oracle import rng_spec as R
+    m = (1 << 20) + 3            # odd count: exercises the tail hand
+    hands_d, out_d = DeviceBuffer(m * 8), DeviceBuffer(m * 4)
+    judger.make_hands(hands_d.ptr, m, seed=R.DEFAULT_SEED)
+    words = hands_d.download(np.uint64, m)
+    cards = words.view(np.uint8).reshape(m, 8)[:, :7]
+    canon = R.canonical_deck_values()
+    for i in (0, 1, 77, 65535, m - 1):
+        assert cards[i].tolist() == [canon[j] for j in R.deck_permutation(R.DEFAULT_SEED, i, 0, ndraws=7)[:7]]
+    assert (np.sort(cards, axis=1)[:, 1:] != np.sort(cards, axis=1)[:, :-1]).all()    # 7 distinct cards in every hand
+    rank, kick, _ = O.eval_hands(np.ascontiguousarray(cards))
+    expect = (rank.astype(np.uint32) << 20) | kick
+    for distinct in (True, False):
+        judger.eval7_stream(hands_d.ptr, m, out_d.ptr, distinct)
+        assert np.array_equal(out_d.download(np.uint32, m), expect), distinct
+    # multiset input (duplicate cards) through the general evaluator
+    dup = cards[:4096].copy()
+    dup[:, 6] = dup[:, 0]
+    w = np.zeros((4096, 8), np.uint8); w[:, :7] = dup
+    hands_d.upload(w)
+    judger.eval7_stream(hands_d.ptr, 4096, out_d.ptr, distinct=False)
+    r2, k2, _ = O.eval_hands(dup)
+    assert np.array_equal(out_d.download(np.uint32, 4096), (r2.astype(np.uint32) << 20) | k2)
+    assert judger.time_eval7_stream(hands_d.ptr, 4096, out_d.ptr, True, reps=2) > 0
+    hands_d.free(); out_d.free()
