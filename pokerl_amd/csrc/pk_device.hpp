@@ -260,16 +260,14 @@ __device__ __forceinline__ uint32_t compare_rankings(const uint32_t (&v)[N], int
 //   * wheel checks are if/elif (:83-88): a 5-4-3-2 run in that group without its ace suppresses the plain wheel.
 // Equality with the reference on all C(52,7) hands is a test (tests/test_hip_parity.py, eval7 digest).
 __device__ __forceinline__ uint32_t eval7_distinct(const uint32_t (&c)[7]) {
-    uint32_t m01 = 0, m23 = 0;  // suit s -> 13 rank bits (bit r-1, ace-high rank r) at offset 16*(s&1) of m01 / m23
+    // A card byte (suit<<4)|rank0 (cards.py:28-62) is already a bit index into a 64-bit word of four 16-bit suit lanes.
+    uint64_t bits = 0;
 #pragma unroll
-    for (int i = 0; i < 7; ++i) {
-        uint32_t r0 = c[i] & 0xf, s = c[i] >> 4;
-        uint32_t b = r0 ? r0 - 1 : 12;                                             // cards.py:14: ace ranks highest
-        uint32_t bit = 1u << (b + ((s & 1) << 4));
-        m01 |= (s & 2) ? 0 : bit;
-        m23 |= (s & 2) ? bit : 0;
-    }
-    const uint32_t sa = m01 & 0x1fff, sb = m01 >> 16, sc = m23 & 0x1fff, sd = m23 >> 16;
+    for (int i = 0; i < 7; ++i) bits |= 1ull << (c[i] & 63);
+    // ace-high inside every lane at once (cards.py:14): rank0 0 (ace) -> bit 12, rank0 k -> bit k-1
+    const uint64_t hi = ((bits >> 1) & 0x0fff0fff0fff0fffull) | ((bits & 0x0001000100010001ull) << 12);
+    const uint32_t h01 = (uint32_t)hi, h23 = (uint32_t)(hi >> 32);
+    const uint32_t sa = h01 & 0x1fff, sb = h01 >> 16, sc = h23 & 0x1fff, sd = h23 >> 16;
     const uint32_t um = sa | sb | sc | sd;
     const uint32_t s1 = sa ^ sb, c1 = sa & sb, s2 = sc ^ sd, c2 = sc & sd;      // per-rank count = bit0 + 2*t + 4*quads
     const uint32_t bit0 = s1 ^ s2, t = c1 ^ c2 ^ (s1 & s2), quads = c1 & c2;
