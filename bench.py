@@ -45,12 +45,25 @@ class DistContext:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             if backend is None:  # PK_BENCH_BACKEND=gloo: rehearsals where several ranks share one GPU (RCCL refuses that)
                 backend = os.environ.get("PK_BENCH_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
-            if backend == "nccl":
-                torch.cuda.set_device(self.local_rank)
-                self.device = torch.device("cuda", self.local_rank)
-                dist.init_process_group("nccl", device_id=self.device)   # "nccl" is RCCL on ROCm
-            else:
-                dist.init_process_group("gloo")
+            # RCCL prints a banner (HIP / ROCm version, library path) on stdout when it initialises: keep stdout for the
+            # ONE JSON line by pointing fd 1 at stderr until the first collective has run.
+            sys.stdout.flush()
+            saved = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                if backend == "nccl":
+                    torch.cuda.set_device(self.local_rank)
+                    self.device = torch.device("cuda", self.local_rank)
+                    dist.init_process_group("nccl", device_id=self.device)   # "nccl" is RCCL on ROCm
+                    warm = torch.zeros(1, device=self.device)
+                    dist.all_reduce(warm)
+                    torch.cuda.synchronize()
+                else:
+                    dist.init_process_group("gloo")
+            finally:
+                sys.stdout.flush()
+                os.dup2(saved, 1)
+                os.close(saved)
             self.dist = dist
             self.torch = torch
 
