@@ -525,3 +525,21 @@ def test_streaming_evaluator(HB, O):
     assert np.array_equal(out_d.download(np.uint32, 4096), (r2.astype(np.uint32) << 20) | k2)
     assert judger.time_eval7_stream(hands_d.ptr, 4096, out_d.ptr, True, reps=2) > 0
     hands_d.free(); out_d.free()
+
+
+def test_empty_and_minimal_inputs(HB, O):
+    """Empty batches and the smallest shapes: zero hands, zero-card hands, one table."""
+    from pokerl_amd import judger
+    r, k, n = judger.eval_hands(np.zeros((0, 7), np.uint8))
+    assert len(r) == len(k) == len(n) == 0
+    assert judger.compare_rankings_batch(np.zeros((0, 3), np.uint8), np.zeros((0, 3), np.uint32)).shape == (0, 3)
+    r, k, n = judger.eval_hands(np.zeros((5, 7), np.uint8), np.zeros(5, np.uint8))      # five empty hands
+    assert r.tolist() == [10] * 5 and k.tolist() == [0] * 5 and n.tolist() == [0] * 5   # (NONE, []) judger.py:30
+    import pokerl_amd
+    assert pokerl_amd.eval_hand([]) == (10, [])
+    assert pokerl_amd.eval_hand(["KS"]) == (9, [12])                                     # judger.py:31
+    assert pokerl_amd.eval_hand(["KS", "KD"]) == (8, [12]) and pokerl_amd.eval_hand(["2S", "AD"]) == (9, [13, 1])
+    h = HB(1, 2)
+    h.reset()
+    assert h.rollout(0, 0).tolist() == [0, 0, 0, 0]
+    assert h.rollout(300, 0)[0] == 300
