@@ -579,6 +579,8 @@ int pk_create(pk_handle **out, int device, int num_tables, int num_players, cons
         std::vector<uint8_t> valid(T, (uint8_t)((1u << MV_FOLD) | (1u << MV_CHECK) | (1u << MV_ALL_IN)));
         h->hot.big_blind = big_blind; h->hot.small_blind = small_blind; h->hot.start_credits = d_start; h->hot.show = S.show;
         h->hot.key0 = S.key0; h->hot.key1 = S.key1; h->hot.table_id_base = table_id_base; h->hot.T = num_tables;
+        h->hot.start_uniform = S.start_credits[0]; h->hot.start_is_uniform = 1;
+        for (int i = 1; i < num_players; ++i) if (S.start_credits[i] != S.start_credits[0]) h->hot.start_is_uniform = 0;
         if (hipMemcpyAsync(d_start, S.start_credits, PK_MAX_PLAYERS * 8, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
             hipMemcpyAsync(h->d_S, &h->S, sizeof(State), hipMemcpyHostToDevice, h->stream) != hipSuccess ||
             hipMemcpyAsync(S.seat_states, ss.data(), T * 8, hipMemcpyHostToDevice, h->stream) != hipSuccess ||

@@ -50,7 +50,9 @@ struct State {
 // scalar loads inside the loop.)
 struct Hot {
     double big_blind, small_blind;
-    const double *start_credits;  // [N], device memory (read on Game.reset only)
+    const double *start_credits;  // [N], device memory: per-seat start credits (read on Game.reset only)
+    double start_uniform;         // the common case, every seat starts with the same credits: no memory read at all
+    int start_is_uniform;
     uint32_t *show;               // State::show
     uint32_t key0, key1, table_id_base;
     int T;
@@ -541,7 +543,11 @@ struct Table {
     // Game.reset minus the shuffle, game.py:397-412
     __device__ __forceinline__ void reset_state(const Hot &S, int dealer_cfg) {
         dealer = dealer_cfg; hand = 0; active = 0;                                 // :403-407
-        PK_FOR(p, N) credits[p] = S.start_credits[p]; PK_END  // :408
+        if (S.start_is_uniform) {                                                  // :408 (scalar branch: S is wave-uniform)
+            PK_FOR(p, N) credits[p] = S.start_uniform; PK_END
+        } else {
+            PK_FOR(p, N) credits[p] = S.start_credits[p]; PK_END
+        }
         st_active = FULL; st_called = st_allin = st_broken = 0;                    // :409
         setup_state(S);                                                            // :412
     }

@@ -34,6 +34,8 @@ static int run(int T, int K, int policy, uint64_t seed, Cfg cfg = default_cfg(),
     double *sc = cfg.start;
     Hot H{}; H.big_blind = cfg.bb; H.small_blind = cfg.sb; H.start_credits = sc; H.show = show.data();
     H.key0 = S.key0; H.key1 = S.key1; H.table_id_base = cfg.base; H.T = T;
+    H.start_uniform = sc[0]; H.start_is_uniform = 1;
+    for (int p = 1; p < N; ++p) if (sc[p] != sc[0]) H.start_is_uniform = 0;
     orc_game *o = orc_create(T, N, sc, cfg.bb, cfg.sb, seed, cfg.base);
     orc_reset(o, nullptr, cfg.dealer);
     static Lds<N> lds;
