@@ -304,7 +304,7 @@ __device__ __forceinline__ uint32_t eval7_distinct(const uint32_t (&c)[7]) {
     uint32_t kick = direct, taken = 0;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        uint32_t bit = (0x80000000u >> __clz((int)L));
+        uint32_t bit = 0x80000000u >> (__clz((int)L) & 31);  // (& 31: defined for an exhausted mask, whose bit is never used)
         bool take = i < nl;                                                        // nl > 0 implies L has that many bits
         kick = take ? ((kick << 4) | (uint32_t)(32 - __clz((int)L))) : kick;
         taken |= take ? bit : 0; L = take ? (L & ~bit) : L;
@@ -312,7 +312,7 @@ __device__ __forceinline__ uint32_t eval7_distinct(const uint32_t (&c)[7]) {
     uint32_t m = base & ~taken;
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
-        uint32_t bit = (0x80000000u >> __clz((int)m));
+        uint32_t bit = 0x80000000u >> (__clz((int)m) & 31);
         bool take = i < nm;
         kick = take ? ((kick << 4) | (uint32_t)(32 - __clz((int)m))) : kick;
         m = take ? (m & ~bit) : m;
