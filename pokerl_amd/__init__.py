@@ -5,8 +5,9 @@ from .game import VecGame
 from .envs import VecPokerGameEnv
 from .judger import compare_hands, compare_rankings, eval_hand, eval_hands
 from .sharding import shard_tables
+from .state_view import Card, StateView
 from ._lib import PokerlHipError, device_count
 
 __all__ = ['VecGame', 'VecPokerGameEnv', 'eval_hand', 'eval_hands', 'compare_rankings', 'compare_hands',
-           'shard_tables', 'HandRanking', 'PokerMoves', 'PlayerState', 'CardRank', 'CardSuit', 'Policy',
+           'shard_tables', 'Card', 'StateView', 'HandRanking', 'PokerMoves', 'PlayerState', 'CardRank', 'CardSuit', 'Policy',
            'PokerlHipError', 'device_count']

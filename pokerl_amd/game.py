@@ -231,4 +231,13 @@ class VecGame:
         L.check(self._lib.pk_get_obs(self._h, L.ptr(out)), self._h)
         return out
 
+    def state_views(self):
+        """One `StateView` (the reference's observation object, game.py:39-240) per table, for host-side policies."""
+        from .state_view import StateView
+        return [StateView(row, self.num_players) for row in self.observations]
+
+    def state_view(self, table=0):
+        from .state_view import StateView
+        return StateView(self.observations[table], self.num_players)
+
     active_state = observations

@@ -260,6 +260,13 @@ def test_observation_and_cards(HB, O):
         assert (obs[t, 12 + nvis:17] == -1).all()
         assert obs[t, 10:12].tolist() == deck[t, 5 + 2 * active[t]:7 + 2 * active[t]].tolist()
     assert np.array_equal(g.get_hand_for(active)[:, 5:], g.get_cards_of(active))
+    views = g.state_views()                                   # the reference's observation object, per table
+    credits = g.credits
+    for t in range(0, T, 31):
+        sv = views[t]
+        assert sv.player == active[t] and sv.turn == turn[t] and sv.credit == credits[t, active[t]]
+        assert [c.value for c in sv.player_cards] == deck[t, 5 + 2 * active[t]:7 + 2 * active[t]].tolist()
+        assert len(sv.community_cards) == (0 if turn[t] == 0 else turn[t] + 2)
     # every dealt prefix holds distinct valid cards
     assert all(len(set(row)) == len(row) for row in deck.tolist())
     assert ((deck & 0xf) < 13).all() and ((deck >> 4) < 4).all()

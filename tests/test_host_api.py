@@ -106,3 +106,24 @@ def test_bench_aggregation_gloo_world2(tmp_path):
     assert r["world"] == 2 and r["n"] == 65536 and r["base"] == 0
     assert r["total"] == 131072 * 10          # units of ALL ranks
     assert r["seconds"] == 2.0                # MAX over ranks
+
+
+def test_state_view_mirror_fields_and_pickle():
+    """StateView / Card host mirrors (reference game.py:39-240, cards.py:4-72): built from a dense observation row."""
+    import pickle
+    from pokerl_amd import Card, StateView
+    n = 3
+    row = np.array([1, 2, 4.5,  1, 0, 1, 1, 0, 0, 1,  0x20, 0x3c,  0x01, 0x15, 0x2b, 0x09, -1,
+                    90, 80, 70,  5, 6, 7,  1, 2, 3], np.float64)
+    sv = StateView(row, n)
+    assert (sv.player, sv.turn, sv.num_players, sv.minimum_raise_value) == (1, 2, 3, 4.5)
+    assert list(sv.valid_action_indices) == [0, 2, 3, 6]
+    assert [c.value for c in sv.player_cards] == [0x20, 0x3c] and len(sv.community_cards) == 4   # turn 2: four cards
+    assert sv.player_cards[0].rank == 13 and sv.player_cards[0].suit == 2 and sv.player_cards[0].id == 26
+    assert sv.pot == 18.0 and sv.high_bet == 3.0 and sv.credit == 80.0
+    assert len(sv.player_hand) == 6
+    state = sv.__getstate__()
+    assert len(state) == 10 and state[0] == 1 and state[3] == 2          # tuple order of game.py:211-223
+    sv2 = pickle.loads(pickle.dumps(sv))
+    assert sv2.credit == 80.0 and sv2.player_cards == sv.player_cards
+    assert Card("AD") == Card(0x20) == Card((13, 2)) and repr(Card("KC"))
