@@ -131,7 +131,8 @@ def measured_traffic(tables, players, policy, kern_steps, fused):
     return best
 
 
-def evaluator_leg(device, log2_m=28, reps=5):
+def evaluator_leg(device, log2_m=None, reps=5):
+    log2_m = int(os.environ.get("PK_BENCH_EVAL_LOG2", "28")) if log2_m is None else log2_m
     """Second half of the metric as a stand-alone kernel: pk_eval7_d streams 2^28 device-resident 7-card hands
     (2 GiB in, 1 GiB out: far beyond L2 / Infinity Cache) -- 12 algorithmic bytes per evaluation, HBM-bound."""
     from pokerl_amd import judger
@@ -147,7 +148,8 @@ def evaluator_leg(device, log2_m=28, reps=5):
                                           "frac": gbs / HBM_PEAK_GBS, "bytes_per_eval": 12}}
 
 
-def cpu_baseline(n_players, policy, budget_s=12.0):
+def cpu_baseline(n_players, policy, budget_s=None):
+    budget_s = float(os.environ.get("PK_BENCH_CPU_BUDGET", "12")) if budget_s is None else budget_s
     """The scalar C oracle (bit-exact restatement of the reference) timed on ONE host core on a bounded sample of the
     same workload.  Reported beside the GPU number; it is not the target (the roofline fraction is)."""
     import numpy as np

@@ -550,3 +550,34 @@ def test_empty_and_minimal_inputs(HB, O):
     h.reset()
     assert h.rollout(0, 0).tolist() == [0, 0, 0, 0]
     assert h.rollout(300, 0)[0] == 300
+
+
+def test_bench_json_contract():
+    """`python bench.py` prints exactly ONE JSON line on stdout with every field the driver's contract names."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PK_BENCH_CPU_BUDGET="1", PK_BENCH_EVAL_LOG2="22")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "256", "--warmup", "64"],
+                         capture_output=True, text=True, env=env, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    r = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in r, k
+    assert r["n_gpus"] == 1 and r["steps"] == 256 and r["warmup"] == 64 and r["higher_is_better"] is True
+    assert r["scaling"] == "weak" and r["vs_baseline"] is None and r["dtype"] == "f64" and r["data"] == "synthetic"
+    assert "workload" in r["config"] and "model" not in r["config"] and "BASELINE configs[2]" in r["config"]["workload"]
+    assert abs(r["value"] - 65536 * 256 / (r["ms_per_step"] * 256 / 1e3)) / r["value"] < 1e-6
+    rf = r["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and "traffic" in rf
+    assert abs(rf["achieved"] - rf["algorithmic_bytes_per_launch"] / (rf["kernel_ms"] * 1e-3) / 1e9) / rf["achieved"] < 1e-6
+    cb = r["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and cb["unit"] == "env-steps/s" and cb["sample"]
+    ev = r["evaluator"]
+    assert ev["roofline"]["bytes_per_eval"] == 12 and ev["hand_evals_per_s"] > 0
