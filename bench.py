@@ -196,7 +196,8 @@ def main():
     ap.add_argument("--tables", type=int, default=65536, help="tables per GPU (weak scaling)")
     ap.add_argument("--players", type=int, default=6)
     ap.add_argument("--policy", choices=["random", "allin"], default="random")
-    ap.add_argument("--chunk", type=int, default=512, help="steps per fused launch")
+    ap.add_argument("--chunk", type=int, default=4096,
+                    help="steps per fused launch (long launches amortise the run-ahead tail: 17.7 G env-steps/s at 512, 19.0 G at 4096)")
     ap.add_argument("--unfused", action="store_true", help="one launch per step (state round-trips HBM every step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-evaluator", action="store_true", help="skip the stand-alone evaluator kernel leg")
@@ -235,7 +236,7 @@ def main():
 
     # roofline leg (rank 0): HIP events on the handle's own stream around back-to-back launches of the dominant kernel
     kern_steps = min(args.chunk, max(1, args.steps)) if fused else 1
-    reps = max(1, min(8, args.steps // max(1, kern_steps)))
+    reps = max(3, min(8, args.steps // max(1, kern_steps))) if fused else max(1, min(8, args.steps))
     ms_launch, _ = game.time_rollout(kern_steps * (1 if fused else reps), policy, True, fused, reps if fused else 1)
     ctx.barrier()
     if ctx.rank == 0:

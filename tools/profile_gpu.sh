@@ -7,8 +7,8 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 2048 --warmup 512 --no-cpu-baseline $*"
-echo "{\"tables\": ${PK_TABLES:-65536}, \"players\": ${PK_PLAYERS:-6}, \"policy\": \"${PK_POLICY:-random}\", \"steps_per_launch\": ${PK_CHUNK:-512}, \"fused\": true, \"command\": \"python3 bench.py $ARGS\"}" > $OUT/workload.json
+ARGS="--steps 8192 --warmup 4096 --no-cpu-baseline $*"
+echo "{\"tables\": ${PK_TABLES:-65536}, \"players\": ${PK_PLAYERS:-6}, \"policy\": \"${PK_POLICY:-random}\", \"steps_per_launch\": ${PK_CHUNK:-4096}, \"fused\": true, \"command\": \"python3 bench.py $ARGS\"}" > $OUT/workload.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py $ARGS > $OUT/trace.log 2>&1 || echo "trace failed"
 for C in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE SQ_THREAD_CYCLES_VALU SQ_LDS_BANK_CONFLICT"; do
   N=$(echo $C | tr ' ' '_' | cut -c1-40)
