@@ -114,9 +114,14 @@ def baseline_config_index(tables, players, policy, world):
     return {(4096, 2, "random"): 1, (65536, 6, "random"): 2, (65536, 9, "allin"): 4}.get((tables, players, policy))
 
 
-def measured_traffic(tables, players, policy, kern_steps, fused):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/*_summary.json,
-    made by tools/profile_gpu.sh + tools/summarize_profile.py on this same command), or None if no profile matches."""
+VALU_PEAK_WAVE_INSTS_PER_S = 256 * 4 * 2.4e9 / 2.0   # 256 CUs x 4 SIMDs, one wave64 VALU instruction per 2 cycles at 2.4 GHz
+#   (guides/MI355X_MICROARCH.md: "v_fma_f32 (wave64) 2 cyc (SIMD-32); one wave alone: 4" -- with the one wave per
+#   SIMD that 65 536 tables give, 0.5 of this peak is the ceiling; tools/microbench/valu_rates.hip measures both)
+
+
+def profile_summary(tables, players, policy):
+    """The committed rocprofv3 summary (profiles/*_summary.json: kernel trace + separate PMC passes of THIS bench command,
+    made by tools/profile_gpu.sh + tools/summarize_profile.py) for this workload, newest round first; None if none."""
     import glob
     best = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_summary.json"))):
@@ -125,20 +130,19 @@ def measured_traffic(tables, players, policy, kern_steps, fused):
         except Exception:
             continue
         w = d.get("workload", {})
-        if (w.get("tables"), w.get("players"), w.get("policy"), w.get("steps_per_launch"), w.get("fused")) == \
-                (tables, players, policy, kern_steps, fused) and "hbm_traffic_bytes_per_launch" in d:
-            best = (d["hbm_traffic_bytes_per_launch"], os.path.basename(f))
+        if (w.get("tables"), w.get("players"), w.get("policy")) == (tables, players, policy) and w.get("fused", True):
+            best = (d, os.path.basename(f))
     return best
 
 
 def evaluator_leg(device, log2_m=None, reps=5):
-    log2_m = int(os.environ.get("PK_BENCH_EVAL_LOG2", "28")) if log2_m is None else log2_m
     """Second half of the metric as a stand-alone kernel: pk_eval7_d streams 2^28 device-resident 7-card hands
     (2 GiB in, 1 GiB out: far beyond L2 / Infinity Cache) -- 12 algorithmic bytes per evaluation, HBM-bound."""
+    log2_m = int(os.environ.get("PK_BENCH_EVAL_LOG2", "28")) if log2_m is None else log2_m
     from pokerl_amd import judger
     from pokerl_amd.hipmem import DeviceBuffer
     m = 1 << log2_m
-    hands, out = DeviceBuffer(m * 8), DeviceBuffer(m * 4)
+    hands, out = DeviceBuffer(m * 8, device), DeviceBuffer(m * 4, device)
     judger.make_hands(hands.ptr, m, device=device)
     ms = judger.time_eval7_stream(hands.ptr, m, out.ptr, True, reps, device)
     hands.free(); out.free()
@@ -149,9 +153,9 @@ def evaluator_leg(device, log2_m=None, reps=5):
 
 
 def cpu_baseline(n_players, policy, budget_s=None):
-    budget_s = float(os.environ.get("PK_BENCH_CPU_BUDGET", "12")) if budget_s is None else budget_s
     """The scalar C oracle (bit-exact restatement of the reference) timed on ONE host core on a bounded sample of the
     same workload.  Reported beside the GPU number; it is not the target (the roofline fraction is)."""
+    budget_s = float(os.environ.get("PK_BENCH_CPU_BUDGET", "12")) if budget_s is None else budget_s
     import numpy as np
     from oracle import loader as O
     tables, chunk = 2048, 50
@@ -188,17 +192,67 @@ def cpu_baseline(n_players, policy, budget_s=None):
     return out
 
 
+def env_mode(args, ctx, device):
+    """--mode env: the RL-facing path as a device-resident loop -- seat 0 picks with the in-kernel random
+    agent (pk_pick_actions_d), PokerGameEnv.step auto-plays the opponents (pk_env_step_d), finished episodes are reset
+    (pk_env_reset_d with the done mask), observations are exported (pk_get_obs_d).  Not the headline metric."""
+    import numpy as np
+    import pokerl_amd
+    from pokerl_amd import _lib as L
+    from pokerl_amd.hipmem import DeviceBuffer
+    T, N = args.tables, args.players
+    env = pokerl_amd.VecPokerGameEnv(0, num_tables=T, num_players=N, device=device)
+    g, lib = env.game, L.lib()
+    D = 17 + 3 * N
+    act, rew, done, hand, terr, obs = (DeviceBuffer(T * 4, device), DeviceBuffer(T * 8, device), DeviceBuffer(T, device),
+                                       DeviceBuffer(T, device), DeviceBuffer(T, device), DeviceBuffer(T * D * 8, device))
+    L.check(lib.pk_env_reset_d(g._h, None, 0), g._h)
+
+    def loop(k):
+        for _ in range(k):
+            L.check(lib.pk_pick_actions_d(g._h, 0, act.ptr), g._h)
+            L.check(lib.pk_env_step_d(g._h, act.ptr, 0, rew.ptr, done.ptr, hand.ptr, terr.ptr), g._h)
+            L.check(lib.pk_env_reset_d(g._h, done.ptr, 0), g._h)
+            L.check(lib.pk_get_obs_d(g._h, -1, obs.ptr), g._h)
+
+    loop(args.warmup)
+    g.sync()
+    s0 = int(g.step_serial.sum())
+    ctx.barrier()
+    t0 = time.perf_counter()
+    loop(args.steps)
+    g.sync(); ctx.barrier()
+    dt = time.perf_counter() - t0
+    game_steps = int(g.step_serial.sum()) - s0
+    assert not terr.download(np.uint8, T).any()
+    if ctx.rank == 0:
+        print(json.dumps({
+            "metric": "PokerGameEnv.step seat-0 steps/s (device-resident loop: pick + env_step + env_reset(done) + obs)",
+            "value": T * args.steps / dt, "unit": "env.step/s", "n_gpus": ctx.world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%d tables x %d seats, seat 0 + opponents random in-kernel, episodes auto-reset; "
+                                   "reference pokerl/envs/game_env.py:20-53" % (T, N)},
+            "game_steps_per_s": game_steps / dt, "game_steps_per_env_step": game_steps / (T * args.steps)}))
+    env.game.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4096)
+    ap.add_argument("--steps", type=int, default=4096, help="K: Game.step()s per table in one timed block")
     ap.add_argument("--warmup", type=int, default=512)
     ap.add_argument("--tables", type=int, default=65536, help="tables per GPU (weak scaling)")
     ap.add_argument("--players", type=int, default=6)
     ap.add_argument("--policy", choices=["random", "allin"], default="random")
-    ap.add_argument("--chunk", type=int, default=4096,
-                    help="steps per fused launch (long launches amortise the run-ahead tail: 17.7 G env-steps/s at 512, 19.0 G at 4096)")
+    ap.add_argument("--chunk", type=int, default=4096, help="at most this many steps per fused launch")
+    ap.add_argument("--reps", type=int, default=0,
+                    help="blocks of --steps per timed sample (0 = as many as make a sample >= --min-steps steps, so that a "
+                         "short --steps is not one launch-latency sample)")
+    ap.add_argument("--min-steps", type=int, default=4096)
+    ap.add_argument("--samples", type=int, default=5, help="timed samples; the MEDIAN is reported")
     ap.add_argument("--unfused", action="store_true", help="one launch per step (state round-trips HBM every step)")
+    ap.add_argument("--mode", choices=["game", "env"], default="game")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-evaluator", action="store_true", help="skip the stand-alone evaluator kernel leg")
     args = ap.parse_args()
@@ -207,48 +261,99 @@ def main():
     if ctx.world != max(1, args.gpus) and ctx.rank == 0:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, ctx.world), file=sys.stderr)
     import pokerl_amd
+    device = 0 if os.environ.get("PK_BENCH_SAME_DEVICE") else ctx.local_rank  # rehearsal knob: all ranks on GPU 0
+    if args.mode == "env":
+        env_mode(args, ctx, device)
+        ctx.close()
+        return
     policy = 0 if args.policy == "random" else 1
     total_tables = args.tables * ctx.world
     n_local, base = shard(total_tables, ctx)
-    device = 0 if os.environ.get("PK_BENCH_SAME_DEVICE") else ctx.local_rank  # rehearsal knob: all ranks on GPU 0
     game = pokerl_amd.VecGame(n_local, num_players=args.players, device=device, table_id_base=base)
     game.reset()
     fused = not args.unfused
+    K = max(1, args.steps)
+    reps = args.reps if args.reps > 0 else max(1, -(-args.min_steps // K))
+    if not fused:
+        reps = args.reps if args.reps > 0 else 1
 
-    def run(steps):
+    def block():  # K steps on every table; launches are asynchronous and may defer their stragglers to the next launch
         done = 0
-        while done < steps:
-            k = min(args.chunk, steps - done)
+        while done < K:
+            k = min(args.chunk, K - done)
             game.rollout(k, policy, True, fused, counters=False)
             done += k
 
-    run(args.warmup)
-    game.rollout(0, policy, True, fused, counters=True)  # drain + zero the device counters
-    ctx.barrier(); game.sync()
-    t0 = time.perf_counter()
-    run(args.steps)
-    game.sync(); ctx.barrier()
-    dt = time.perf_counter() - t0
+    done = 0
+    while done < args.warmup:
+        k = min(args.chunk, args.warmup - done)
+        game.rollout(k, policy, True, fused, counters=False)
+        done += k
+    game.rollout(0, policy, True, fused, counters=True)  # complete + zero the device counters
+    sample_s = []
+    for _ in range(max(1, args.samples)):
+        ctx.barrier(); game.sync()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            block()
+        game.sync(); ctx.barrier()   # sync() completes every deferred step: exactly reps*K steps per table are inside
+        sample_s.append(ctx.aggregate(0, time.perf_counter() - t0)[1])   # MAX over ranks
     c = game.rollout(0, policy, True, fused, counters=True)
-    assert c["steps"] == n_local * args.steps, (c, n_local, args.steps)
-    total_steps, seconds = ctx.aggregate(c["steps"], dt)
+    assert c["steps"] == n_local * K * reps * len(sample_s), (c, n_local, K, reps)
+    seconds = sorted(sample_s)[len(sample_s) // 2]
+    total_steps = ctx.aggregate(n_local * K * reps, 0.0)[0]
+    scale = 1.0 / (sum(sample_s))   # counters cover all samples
     hands, evals, games = ctx.sum_list([c["hands"], c["evals"], c["games"]])
 
     # roofline leg (rank 0): HIP events on the handle's own stream around back-to-back launches of the dominant kernel
-    kern_steps = min(args.chunk, max(1, args.steps)) if fused else 1
-    reps = max(3, min(8, args.steps // max(1, kern_steps))) if fused else max(1, min(8, args.steps))
-    ms_launch, _ = game.time_rollout(kern_steps * (1 if fused else reps), policy, True, fused, reps if fused else 1)
+    kern_steps = min(args.chunk, K) if fused else 1
+    ev_reps = max(3, min(256, args.min_steps // kern_steps)) if fused else 1
+    ms_launch, _ = game.time_rollout(kern_steps if fused else min(K, 64), policy, True, fused, ev_reps)
     ctx.barrier()
     if ctx.rank == 0:
         alg_bytes = b_step(args.players) * n_local * kern_steps
         achieved = alg_bytes / (ms_launch * 1e-3) / 1e9
         cfg_idx = baseline_config_index(args.tables, args.players, args.policy, ctx.world)
-        traffic = measured_traffic(args.tables, args.players, args.policy, kern_steps, fused)
+        prof = profile_summary(args.tables, args.players, args.policy) if fused else None
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "traffic_unit": "bytes per launch (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE, KiB)",
+                "kernel_ms": ms_launch, "launches_timed": ev_reps, "algorithmic_bytes_per_launch": alg_bytes,
+                "note": "achieved = ALGORITHMIC bytes ((2*(35N+21)+16) B/env-step x tables x steps per launch, SURVEY 8d) / "
+                        "HIP-event launch time: what a one-HBM-round-trip-per-step design would move. The fused kernel "
+                        "keeps table state in VGPRs for all steps of a launch, so its real HBM traffic (`traffic`: one "
+                        "read + one write of the table state per launch, whatever the launch length) is a small "
+                        "fraction of that and `frac` can exceed what any such design could reach; the binding "
+                        "roofline is VALU issue: see `valu`."}
+        if prof:
+            d, src = prof
+            pmc = d.get("pmc_per_full_launch", {})
+            roof["traffic"] = d.get("hbm_traffic_bytes_per_launch")
+            roof["traffic_source"] = src
+            w = d.get("workload", {})
+            k_prof = w.get("steps_per_launch")
+            if "SQ_INSTS_VALU" in pmc and "SQ_WAVES" in pmc and k_prof:
+                waves = pmc["SQ_WAVES"]
+                per_wave_step = pmc["SQ_INSTS_VALU"] / waves / k_prof       # wave-level VALU instructions per env-step batch of 64
+                valu_rate = per_wave_step * (n_local / 64.0) * kern_steps / (ms_launch * 1e-3)
+                lanes = pmc.get("SQ_THREAD_CYCLES_VALU", 0) / (64.0 * pmc["SQ_ACTIVE_INST_VALU"]) if pmc.get("SQ_ACTIVE_INST_VALU") else None
+                roof["valu"] = {"bound": "valu-issue", "achieved": valu_rate, "peak": VALU_PEAK_WAVE_INSTS_PER_S,
+                                "unit": "wave-instr/s", "frac": valu_rate / VALU_PEAK_WAVE_INSTS_PER_S,
+                                "valu_insts_per_wave_step": per_wave_step, "lanes_active": lanes,
+                                "waves_per_simd": waves / 1024.0,
+                                "wait_any_frac": d.get("wait_any_frac_of_wave_cycles"), "source": src,
+                                "note": "achieved = SQ_INSTS_VALU per wave-step (from the committed PMC pass of this "
+                                        "workload) x wave-steps per launch / this run's HIP-event launch time; peak = "
+                                        "256 CU x 4 SIMD x 2.4 GHz / 2 cycles per wave64 VALU instruction; one wave "
+                                        "per SIMD cannot exceed 0.5 (4-cycle single-wave issue)"}
         out = {
             "metric": "env-steps/sec (whole node) + showdown hand-evals/sec, 65 536 tables 6-max",
-            "value": total_steps / seconds, "unit": "env-steps/s", "n_gpus": ctx.world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": seconds / args.steps * 1e3, "higher_is_better": True,
+            "value": total_steps / seconds, "unit": "env-steps/s", "n_gpus": ctx.world, "steps": K,
+            "warmup": args.warmup, "ms_per_step": seconds / (K * reps) * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "reps": reps, "samples": len(sample_s), "sample_seconds": sample_s,
+            "timing": "each sample = %d block(s) of %d steps per table, launched back to back and completed by a sync inside "
+                      "the timed region; value = steps of one sample / MEDIAN sample time (MAX over ranks per sample)" % (reps, K),
             "config": {"workload": "%d tables/GPU x %d GPU(s), num_players=%d, %s agents in-kernel (Philox4x32-10), "
                                    "start_credits=100 blinds 1/2, auto-reset; %s"
                                    % (args.tables, ctx.world, args.players, args.policy,
@@ -256,16 +361,8 @@ def main():
                        "tables_per_gpu": args.tables, "num_players": args.players, "policy": args.policy,
                        "kernel": "k_rollout (fused, %d steps/launch)" % kern_steps if fused else "k_rollout (1 step/launch)",
                        "parallelism": "env-parallel, %d shard(s), no collective on the step path" % ctx.world},
-            "hand_evals_per_s": evals / seconds, "hands_per_s": hands / seconds, "games_per_s": games / seconds,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic[0] if traffic else None,
-                         "traffic_unit": "bytes per launch (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE, KiB)",
-                         "traffic_source": traffic[1] if traffic else None,
-                         "kernel_ms": ms_launch, "algorithmic_bytes_per_launch": alg_bytes,
-                         "note": "achieved = ALGORITHMIC bytes ((2*(35N+21)+16) B/env-step x tables x steps per launch, "
-                                 "SURVEY 8d) / HIP-event launch time. The fused kernel keeps table state in VGPRs for all "
-                                 "steps of a launch, so real HBM traffic (`traffic`) is ~0.2% of that; the kernel is "
-                                 "VALU-issue-bound at one wave per SIMD (DESIGN.md, Measurement)."},
+            "hand_evals_per_s": evals * scale, "hands_per_s": hands * scale, "games_per_s": games * scale,
+            "roofline": roof,
         }
         if not args.no_evaluator:
             out["evaluator"] = evaluator_leg(device)

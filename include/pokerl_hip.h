@@ -13,7 +13,11 @@
  *   - a handle is bound to one device and one HIP stream and is not thread-safe; different handles may be
  *     driven from different threads/processes (one process per GPU is the intended deployment);
  *   - RNG is counter-based per handle: Philox4x32-10 keyed by `seed`, indexed by the GLOBAL table id
- *     (table_id_base + t), so results do not depend on how tables are sharded over GPUs.
+ *     (table_id_base + t) and 64-bit per-table serials, so results do not depend on how tables are sharded over
+ *     GPUs and a table's streams never repeat;
+ *   - `_d` entry points are asynchronous on the handle's stream and take buffers that must be COMPLETE in stream order:
+ *     either make the handle run on your stream (pk_set_stream) or order the two streams with events
+ *     (pk_wait_event before the call, pk_record_event after it).  pk_sync() waits for everything requested so far.
  *
  * All money arithmetic is IEEE binary64 in the reference's operation order (no FMA contraction), so
  * valid_actions / payoffs / credits / flags / hand ranks are bit-identical to the CPU reference.
@@ -27,9 +31,10 @@
 extern "C" {
 #endif
 
-#define PK_ABI_VERSION 1
+#define PK_ABI_VERSION 2
 #define PK_MIN_PLAYERS 2
 #define PK_MAX_PLAYERS 10
+#define PK_MAX_DEVICES 64 /* the handle-less judger calls keep one scratch arena per device index below this */
 #define PK_NUM_MOVES 7 /* pokerl/enums.py:104-114 PokerMoves */
 
 /* return codes */
@@ -75,12 +80,15 @@ extern "C" {
 #define PK_I_SMALL_BLIND_IDX 3
 #define PK_I_BIG_BLIND_IDX 4
 #define PK_I_HAND 5
-#define PK_I_HAND_SERIAL 6 /* RNG spec: setup_hand() calls so far */
-#define PK_I_STEP_SERIAL 7 /* RNG spec: completed Game.step() calls so far */
+
+/* f64 [T] per-table values of pk_get_table_f64 = Game properties */
+#define PK_TF_POT 0       /* Game.pot: np.sum(bets) in numpy's association order, pokerl/game.py:281-284 */
+#define PK_TF_HIGH_BET 1  /* Game.high_bet: np.max(pending_bets), pokerl/game.py:287-290 */
+#define PK_TF_MIN_RAISE 2 /* Game.minimum_raise_value */
 
 /* rollout counters */
 #define PK_C_STEPS 0
-#define PK_C_HANDS 1
+#define PK_C_HANDS 1 /* hands played: end_hand() calls that ran to their end, pokerl/game.py:453-539 */
 #define PK_C_EVALS 2 /* 7-card eval_hand calls made by showdowns, pokerl/game.py:489 */
 #define PK_C_GAMES 3
 #define PK_NUM_COUNTERS 4
@@ -111,14 +119,21 @@ int pk_step(pk_handle *h, const int32_t *actions, uint8_t *flags, uint8_t *terr)
 /* Same, device-resident I/O (inputs already in HBM; asynchronous on the handle's stream). */
 int pk_step_d(pk_handle *h, const int32_t *actions_d, uint8_t *flags_d, uint8_t *terr_d);
 
-/* Game.get_valid_actions() of the active player, pokerl/game.py:339-383: out[T][7] one-hot bytes. */
-int pk_get_valid_actions(pk_handle *h, uint8_t *out);
+/* Game.get_valid_actions(player), pokerl/game.py:339-383: out[T][7] one-hot bytes.  player < 0: each table's active
+ * player (the reference's `player=None`); 0 <= player < N: that seat on every table. */
+int pk_get_valid_actions(pk_handle *h, int player, uint8_t *out);
 
 /* State reads (Game attributes). */
 int pk_get_f64(pk_handle *h, int field, double *out /* [T][N] */);
 int pk_get_min_raise(pk_handle *h, double *out /* [T] minimum_raise_value */);
+int pk_get_table_f64(pk_handle *h, int field /* PK_TF_* */, double *out /* [T] */);
+int pk_get_game_over(pk_handle *h, uint8_t *out /* [T] Game.game_over, pokerl/game.py:317-320 */);
 int pk_get_player_states(pk_handle *h, uint8_t *out /* [T][N] PlayerState, pokerl/enums.py:130-136 */);
 int pk_get_i32(pk_handle *h, int field, int32_t *out /* [T] */);
+/* RNG-spec serials of each table: setup_hand() calls / completed Game.step() calls so far (64-bit; either pointer may be
+ * NULL).  pk_set_serials resumes a table's streams at given serials (e.g. restoring a checkpoint); call before pk_reset. */
+int pk_get_serials(pk_handle *h, uint64_t *hand_serial, uint64_t *step_serial);
+int pk_set_serials(pk_handle *h, const uint64_t *hand_serial, const uint64_t *step_serial);
 /* deck[0 : 5+2N] as Card.value bytes ((suit<<4)|rank0, pokerl/cards.py:28-62): community = [0:5], hole(p) = [5+2p : 7+2p]
  * (pokerl/game.py:385-395). out[T][5+2N]. */
 int pk_get_cards(pk_handle *h, uint8_t *out);
@@ -131,6 +146,10 @@ int pk_get_hand_ranks(pk_handle *h, uint8_t *rank, uint32_t *kick);
  * Multiset semantics: duplicate cards are legal, as in the reference's own tests. */
 int pk_eval_hands(int device, const uint8_t *cards, const uint8_t *ncards, size_t m, uint8_t *rank, uint32_t *kick,
                   uint8_t *nkick);
+/* Same op on device-resident buffers, asynchronous on `stream` (a hipStream_t; NULL = the default stream): the
+ * partial-hand rank feature of examples/q_learning.py:29-33 (2/5/6/7-card hands every step) without a host round trip. */
+int pk_eval_hands_d(int device, const uint8_t *cards_d, const uint8_t *ncards_d, size_t m, uint8_t *rank_d, uint32_t *kick_d,
+                    uint8_t *nkick_d, void *stream);
 /* pokerl.judger.compare_rankings (pokerl/judger.py:111-158) on M lists of n rankings: rank[M][n], kick[M][n] ->
  * onehot[M][n].  Includes the reference's line-148 behaviour. */
 int pk_compare_rankings(int device, const uint8_t *rank, const uint32_t *kick, int n, size_t m, uint8_t *onehot);
@@ -138,7 +157,9 @@ int pk_compare_rankings(int device, const uint8_t *rank, const uint32_t *kick, i
 /* Streaming evaluator on device-resident data: hands_d[m] = one 7-card hand per 64-bit word (card i = byte i, byte 7
  * unused), out_d[m] = HandRanking<<20 | kickers value.  12 algorithmic bytes per evaluation (8 in + 4 out): HBM-bound.
  * distinct != 0: the caller guarantees 7 DISTINCT cards per hand (every in-game hand) and the bitmask evaluator is used;
- * distinct == 0: the general (multiset) evaluator of pk_eval_hands.  Runs on the default stream, synchronous. */
+ * distinct == 0: the general (multiset) evaluator of pk_eval_hands.  Runs on the default stream, synchronous.
+ * hands_d must be 8-byte and out_d 4-byte aligned; 16-byte / 8-byte alignment (any allocation base) enables the
+ * two-hands-per-lane vector path. */
 int pk_eval7_d(int device, const uint64_t *hands_d, size_t m, uint32_t *out_d, int distinct);
 /* Synthetic workload for it: hand i = the first 7 cards of the RNG-spec deck of (seed, table_id = i, hand_serial = 0). */
 int pk_make_hands_d(int device, uint64_t seed, size_t m, uint64_t *hands_d);
@@ -152,12 +173,25 @@ int pk_eval7_prefix(int device, int a, int b, int fast, uint32_t *out, size_t *c
 
 /* Actions the in-kernel agent `policy` would take now (one per table) -- lets a host loop reproduce rollouts. */
 int pk_pick_actions(pk_handle *h, int policy, int32_t *actions);
+int pk_pick_actions_d(pk_handle *h, int policy, int32_t *actions_d);
 
 /* Throughput path: K lockstep Game.step()s per table with in-kernel agents; finished games are reset
  * (Game.reset()) when auto_reset != 0.  fused != 0: ONE launch, table state held in registers for all K steps;
  * fused == 0: K launches, state round-trips HBM every step.  counters[PK_NUM_COUNTERS] are ADDED to (may be NULL).
- * Asynchronous unless counters != NULL. */
+ * Asynchronous unless counters != NULL.  With counters == NULL a fused call may also DEFER part of its steps: a launch
+ * ends when the first lanes of a wave run out of work instead of idling until the slowest table has finished, and the
+ * tables remember what they still owe; the next pk_rollout picks that up, and every other entry point (getters,
+ * pk_step, pk_reset, pk_sync, pk_record_event, ...) first completes it (pk_flush), so no caller can observe a table
+ * that has made fewer than the requested steps.  Results do not depend on how the steps were split over launches. */
 int pk_rollout(pk_handle *h, int k_steps, int policy, int auto_reset, int fused, uint64_t *counters);
+/* Diagnostic: the steps each table still owes (out[T]); waits for the launches queued so far but does NOT complete the
+ * deferred work. */
+int pk_get_owed(pk_handle *h, uint32_t *out);
+/* Completes deferred rollout steps now (asynchronous on the handle's stream); a no-op when there are none. */
+int pk_flush(pk_handle *h);
+/* Tuning knobs of the fused rollout (values outside 1..64 leave the knob unchanged): `park` = lanes of a wave waiting at
+ * end_hand before the wave runs it; `endk` = a deferred launch ends once fewer than this many lanes have work (1 = never defer). */
+int pk_set_tuning(pk_handle *h, int park, int endk);
 
 /* PokerGameEnv.reset() / .step(action) (pokerl/envs/game_env.py:20-29, :31-53): seat 0 is the controlled seat,
  * the other seats play `opp_policy` in-kernel.  reward[T] f64, done[T], hand[T] bytes. */
@@ -169,17 +203,27 @@ int pk_env_step(pk_handle *h, const int32_t *actions, int opp_policy, double *re
  * per table: [player, turn, minimum_raise_value, valid_actions[7], player_cards[2], community_cards[5] (-1 where
  * not yet visible: game.py:278), credits[N], bets[N], pending_bets[N]]. */
 #define PK_OBS_DIM(n) (3 + 7 + 2 + 5 + 3 * (n))
-int pk_get_obs(pk_handle *h, double *out /* [T][PK_OBS_DIM(N)] */);
+/* player < 0: each table's active player (Game.active_state, game.py:323-332); else StateView(game, player). */
+int pk_get_obs(pk_handle *h, int player, double *out /* [T][PK_OBS_DIM(N)] */);
 
 /* Device-resident variants for a learner that lives on the same GPU (no host round trip; asynchronous on the handle's
- * stream -- order against your own stream with pk_sync or an event): out_d / actions_d / ... are DEVICE pointers. */
-int pk_get_obs_d(pk_handle *h, double *out_d /* [T][PK_OBS_DIM(N)] */);
-int pk_get_valid_actions_d(pk_handle *h, uint8_t *out_d /* [T][7] one-hot */);
+ * stream -- see "Stream control" below for ordering against your own stream): out_d / actions_d / ... are DEVICE pointers. */
+int pk_get_obs_d(pk_handle *h, int player, double *out_d /* [T][PK_OBS_DIM(N)] */);
+int pk_get_valid_actions_d(pk_handle *h, int player, uint8_t *out_d /* [T][7] one-hot */);
 int pk_env_step_d(pk_handle *h, const int32_t *actions_d, int opp_policy, double *reward_d, uint8_t *done_d,
                   uint8_t *hand_d, uint8_t *terr_d);
 int pk_env_reset_d(pk_handle *h, const uint8_t *mask_d /* NULL = all */, int opp_policy);
 
-/* Stream control / timing helpers (no torch types: plain HIP underneath). */
+/* Stream control (no torch types: `stream` is a hipStream_t, `event` a hipEvent_t, passed as void*).  A handle creates
+ * its own non-blocking stream.  pk_set_stream makes it run on the caller's stream instead (NULL: back to its own), which
+ * orders every `_d` call after the work already queued there; or keep two streams and order them with events:
+ * pk_wait_event = the handle's stream waits for `event` (record it on your stream after producing actions_d),
+ * pk_record_event = records `event` on the handle's stream (wait for it on your stream before reading obs_d). */
+int pk_get_stream(pk_handle *h, void **stream_out);
+int pk_set_stream(pk_handle *h, void *stream);
+int pk_wait_event(pk_handle *h, void *event);
+int pk_record_event(pk_handle *h, void *event);
+/* Completes deferred rollout steps and waits until everything requested so far has finished. */
 int pk_sync(pk_handle *h);
 /* Runs `reps` back-to-back fused rollouts of k_steps each and returns the average device time of one launch in
  * milliseconds, measured with HIP events on the handle's stream (used by bench.py's roofline leg). */

@@ -54,14 +54,15 @@ def lib():
     L.orc_get_min_raise.argtypes = [C.c_void_p, _f64p]
     L.orc_get_states.argtypes = [C.c_void_p, _u8p]
     L.orc_get_cursors.argtypes = [C.c_void_p, _i32p]
-    L.orc_get_serials.argtypes = [C.c_void_p, _u32p, _u32p]
+    L.orc_get_serials.argtypes = [C.c_void_p, _u64p, _u64p]
+    L.orc_set_serials.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.orc_get_cards.argtypes = [C.c_void_p, _u8p]
     L.orc_get_showdown.argtypes = [C.c_void_p, _u8p, _u32p]
     L.orc_eval_hands.argtypes = [_u8p, C.c_void_p, C.c_size_t, _u8p, _u32p, _u8p]
     L.orc_compare_rankings.argtypes = [_u8p, _u32p, C.c_int, _u8p]
     L.orc_compare_rankings.restype = C.c_int
     L.orc_philox4x32_10.argtypes = [_u32p, _u32p, _u32p]
-    L.orc_deck.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, _u8p]
+    L.orc_deck.argtypes = [C.c_uint64, C.c_uint32, C.c_uint64, _u8p]
     L.orc_eval7_digest.argtypes = [C.c_int, C.c_int, _u64p, _u64p]
     L.orc_eval7_prefix.argtypes = [C.c_int, C.c_int, _u32p]
     L.orc_eval7_prefix.restype = C.c_size_t
@@ -134,6 +135,14 @@ class OracleGame:
         self.L.orc_env_step(self.h, a, int(opp_policy), reward, done, hand, err)
         return reward, done, hand, err
 
+    def set_serials(self, hand_serial=None, step_serial=None):
+        """Resume the RNG streams at given 64-bit serials (scalars broadcast over tables)."""
+        def arr(v):
+            return None if v is None else np.ascontiguousarray(np.broadcast_to(np.asarray(v, np.uint64), (self.T,)))
+        hs, ss = arr(hand_serial), arr(step_serial)
+        self.L.orc_set_serials(self.h, None if hs is None else hs.ctypes.data_as(C.c_void_p),
+                               None if ss is None else ss.ctypes.data_as(C.c_void_p))
+
     def f64(self, field):
         out = np.zeros((self.T, self.N), np.float64)
         self.L.orc_get_f64(self.h, field, out)
@@ -153,8 +162,8 @@ class OracleGame:
         srank = np.zeros((T, N), np.uint8)
         skick = np.zeros((T, N), np.uint32)
         self.L.orc_get_showdown(self.h, srank, skick)
-        hs = np.zeros(T, np.uint32)
-        ss = np.zeros(T, np.uint32)
+        hs = np.zeros(T, np.uint64)
+        ss = np.zeros(T, np.uint64)
         self.L.orc_get_serials(self.h, hs, ss)
         return dict(active=cur[:, 0].astype(np.uint8), turn=cur[:, 1].astype(np.uint8),
                     dealer=cur[:, 2].astype(np.uint8), sb=cur[:, 3].astype(np.uint8),

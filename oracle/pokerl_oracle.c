@@ -18,7 +18,7 @@ enum { PS_FOLDED = 0, PS_ACTIVE = 1, PS_CALLED = 2, PS_ALL_IN = 3, PS_BROKEN = 4
 enum { RANK_FIVE = 4, RANK_ACE = 13, NUM_SUITS = 4 };
 
 #define STREAM_DECK 0x4445434Bu
-#define STREAM_ACTION 0x41435431u
+#define STREAM_ACTION 0x41435432u
 
 typedef struct {
     uint8_t deck[52]; /* Card.value, game.py:253 */
@@ -26,12 +26,13 @@ typedef struct {
     uint8_t states[ORC_MAX_PLAYERS];                                        /* game.py:259 */
     double credits[ORC_MAX_PLAYERS], bets[ORC_MAX_PLAYERS], pending[ORC_MAX_PLAYERS], payoffs[ORC_MAX_PLAYERS];
     double minimum_raise_value; /* game.py:263 */
-    uint32_t table_id, hand_serial, step_serial;
+    uint32_t table_id;
+    uint64_t hand_serial, step_serial; /* rng_spec: 64-bit serials */
     uint8_t srank[ORC_MAX_PLAYERS];
     uint32_t skick[ORC_MAX_PLAYERS];
     uint8_t err;
     int hands_this_step;
-    uint64_t evals, games;
+    uint64_t evals, games, hands; /* hands = end_hand() calls that ran to their end */
 } table_t;
 
 struct orc_game {
@@ -55,7 +56,7 @@ void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-void orc_deck(uint64_t seed, uint32_t table_id, uint32_t hand_serial, uint8_t out[52]) {
+void orc_deck(uint64_t seed, uint32_t table_id, uint64_t hand_serial, uint8_t out[52]) {
     uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
     uint8_t remaining[52];
     int nrem = 52;
@@ -63,7 +64,7 @@ void orc_deck(uint64_t seed, uint32_t table_id, uint32_t hand_serial, uint8_t ou
     for (int i = 0; i < 52; ++i) remaining[i] = (uint8_t)(((i % 4) << 4) | (i / 4)); /* cards.py:77 */
     for (int i = 0; i < 52; ++i) {
         if (i % 18 == 0) {
-            uint32_t ctr[4] = {table_id, hand_serial, STREAM_DECK, (uint32_t)(i / 18)}, w[4];
+            uint32_t ctr[4] = {table_id, (uint32_t)hand_serial, STREAM_DECK + (uint32_t)(i / 18), (uint32_t)(hand_serial >> 32)}, w[4];
             orc_philox4x32_10(ctr, key, w);
             words[0] = (uint64_t)w[0] | ((uint64_t)w[1] << 32);
             words[1] = (uint64_t)w[2] | ((uint64_t)w[3] << 32);
@@ -81,10 +82,13 @@ void orc_deck(uint64_t seed, uint32_t table_id, uint32_t hand_serial, uint8_t ou
 static int pick_action(uint64_t seed, const table_t *t, int policy, unsigned mask) {
     if (policy == 1) return MV_ALL_IN;
     uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)}, o[4];
-    uint32_t ctr[4] = {t->table_id, t->step_serial >> 2, STREAM_ACTION, 0};
+    uint64_t q = t->step_serial >> 3;
+    int j = (int)(t->step_serial & 7);
+    uint32_t ctr[4] = {t->table_id, (uint32_t)q, STREAM_ACTION, (uint32_t)(q >> 32)};
     orc_philox4x32_10(ctr, key, o);
+    uint32_t r = (o[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
     int n = __builtin_popcount(mask);
-    int k = (int)(((uint64_t)o[t->step_serial & 3] * (uint64_t)n) >> 32);
+    int k = (int)((r * (uint32_t)n) >> 16);
     for (int a = 0; a < MV_NUM; ++a)
         if ((mask >> a) & 1) { if (k == 0) return a; --k; }
     return -1;
@@ -345,6 +349,7 @@ static void end_hand(orc_game *g, table_t *t) { /* game.py:453-539 */
         }
         for (int p = 0; p < n; ++p) t->credits[p] = t->credits[p] + t->payoffs[p]; /* :528 */
     }
+    t->hands += 1;
     for (int p = 0; p < n; ++p) t->payoffs[p] = t->payoffs[p] - t->bets[p];        /* :531 */
     for (int p = 0; p < n; ++p) if (t->credits[p] <= 0.0) t->states[p] = PS_BROKEN; /* :536 */
     setup_hand(g, t);                                                              /* :539 */
@@ -497,7 +502,7 @@ int orc_rollout(orc_game *g, int K, int policy, int auto_reset, uint64_t *counte
     int any = 0;
     for (int i = 0; i < g->T; ++i) {
         table_t *t = &g->t[i];
-        uint32_t h0 = t->hand_serial; uint64_t e0 = t->evals, steps = 0, games = 0;
+        uint64_t h0 = t->hands; uint64_t e0 = t->evals, steps = 0, games = 0;
         for (int k = 0; k < K; ++k) {
             uint8_t fl;
             int a = pick_action(g->seed, t, policy, valid_actions(g, t, t->active_player));
@@ -510,7 +515,7 @@ int orc_rollout(orc_game *g, int K, int policy, int auto_reset, uint64_t *counte
             ++steps;
             if (fl & 1) { ++games; if (auto_reset) reset_table(g, t, 0); }
         }
-        if (counters) { counters[0] += steps; counters[1] += t->hand_serial - h0; counters[2] += t->evals - e0; counters[3] += games; }
+        if (counters) { counters[0] += steps; counters[1] += t->hands - h0; counters[2] += t->evals - e0; counters[3] += games; }
     }
     return any;
 }
@@ -587,8 +592,11 @@ void orc_get_cursors(const orc_game *g, int32_t *out) {
         o[0] = t->active_player; o[1] = t->turn; o[2] = t->dealer_idx; o[3] = t->small_blind_idx; o[4] = t->big_blind_idx; o[5] = t->hand;
     }
 }
-void orc_get_serials(const orc_game *g, uint32_t *hand_serial, uint32_t *step_serial) {
+void orc_get_serials(const orc_game *g, uint64_t *hand_serial, uint64_t *step_serial) {
     for (int i = 0; i < g->T; ++i) { if (hand_serial) hand_serial[i] = g->t[i].hand_serial; if (step_serial) step_serial[i] = g->t[i].step_serial; }
+}
+void orc_set_serials(orc_game *g, const uint64_t *hand_serial, const uint64_t *step_serial) {
+    for (int i = 0; i < g->T; ++i) { if (hand_serial) g->t[i].hand_serial = hand_serial[i]; if (step_serial) g->t[i].step_serial = step_serial[i]; }
 }
 void orc_get_cards(const orc_game *g, uint8_t *out) {
     int nc = 5 + 2 * g->N; if (nc > 52) nc = 52;

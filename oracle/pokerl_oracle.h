@@ -48,7 +48,7 @@ void orc_pick_actions(const orc_game *g, int policy, int32_t *actions);
 
 /* K lockstep steps with in-library agents; auto_reset != 0 resets finished games (dealer 0).
 * A table that hits ORC_ERR_HAND_CAP is treated as a finished game when auto_reset != 0 (return value still has the bit).
- * counters[0] += steps, [1] += hands dealt (setup_hand calls), [2] += showdown 7-card evals, [3] += games finished */
+ * counters[0] += steps, [1] += hands played (end_hand calls that ran to their end), [2] += showdown 7-card evals, [3] += games finished */
 int orc_rollout(orc_game *g, int K, int policy, int auto_reset, uint64_t *counters);
 
 /* PokerGameEnv.reset()/step() with seat 0 controlled and opponents playing `opp_policy`. envs/game_env.py:20-53 */
@@ -63,7 +63,9 @@ void orc_get_min_raise(const orc_game *g, double *out);
 void orc_get_states(const orc_game *g, uint8_t *out);
 /* [T][6] int32: active, turn, dealer, sb, bb, hand */
 void orc_get_cursors(const orc_game *g, int32_t *out);
-void orc_get_serials(const orc_game *g, uint32_t *hand_serial, uint32_t *step_serial);
+void orc_get_serials(const orc_game *g, uint64_t *hand_serial, uint64_t *step_serial);
+/* resume a table's RNG streams at given serials (rng_spec; either pointer may be NULL) */
+void orc_set_serials(orc_game *g, const uint64_t *hand_serial, const uint64_t *step_serial);
 void orc_get_cards(const orc_game *g, uint8_t *out /* [T][5+2N] Card.value */);
 void orc_get_showdown(const orc_game *g, uint8_t *rank, uint32_t *kick /* [T][N], last showdown */);
 
@@ -81,7 +83,7 @@ size_t orc_eval7_prefix(int a, int b, uint32_t *out);
 
 /* Spec helpers exposed for tests */
 void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
-void orc_deck(uint64_t seed, uint32_t table_id, uint32_t hand_serial, uint8_t out[52]);
+void orc_deck(uint64_t seed, uint32_t table_id, uint64_t hand_serial, uint8_t out[52]);
 double orc_np_sum(const double *a, int n);
 
 #ifdef __cplusplus

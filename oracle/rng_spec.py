@@ -8,8 +8,10 @@ RNG seeds" is defined by THIS counter-based spec instead:
 
   Philox4x32-10 (Salmon et al., Random123 constants), key = (seed_lo, seed_hi).
 
+  Serials are 64-bit (a table never repeats a stream: 2^64 hands / steps), table ids 32-bit.
+
   deck of a table's `hand_serial`-th setup_hand() call (0-based, never reset):
-      block b = philox(counter = (table_id, hand_serial, STREAM_DECK, b)) -> words w0..w3
+      block b = philox(counter = (table_id, hand_serial mod 2^32, STREAM_DECK + b, hand_serial >> 32)) -> words w0..w3
       64-bit words X[2b] = w0 | w1<<32,  X[2b+1] = w2 | w3<<32
       draw i (i = 0,1,...) takes x = X[i // 9] when i % 9 == 0, then
           p = x * (52 - i)  (128-bit);  c_i = p >> 64;  x = p mod 2^64     (chained multiply-high,
@@ -20,8 +22,10 @@ RNG seeds" is defined by THIS counter-based spec instead:
       stops after draw 4+2N; draw i depends on nothing but (seed, table_id, hand_serial, i).
 
   random-agent action of a table's `step_serial`-th Game.step() (0-based, never reset):
-      r = word (step_serial & 3) of philox(counter = (table_id, step_serial >> 2, STREAM_ACTION, 0))
-      n = popcount(valid_mask);  k = (r * n) >> 32;  action = k-th set bit (ascending)
+      one block serves EIGHT consecutive steps: q = step_serial >> 3, j = step_serial & 7,
+      w = philox(counter = (table_id, q mod 2^32, STREAM_ACTION, q >> 32));  r = 16-bit half (j & 1) of word w[j >> 1]
+      n = popcount(valid_mask);  k = (r * n) >> 16;  action = k-th set bit (ascending)
+      (n <= 7, so the bias of the bounded draw is at most 7/65536 per action.)
 
 Pure-Python ints here (small cases only); the C restatement lives in pokerl_oracle.c.
 """
@@ -33,7 +37,7 @@ W1 = 0xBB67AE85
 MASK32 = 0xFFFFFFFF
 
 STREAM_DECK = 0x4445434B    # 'DECK'
-STREAM_ACTION = 0x41435431  # 'ACT1'
+STREAM_ACTION = 0x41435432  # 'ACT2'
 
 DEFAULT_SEED = 0x706F6B65726C  # 'pokerl'
 
@@ -73,7 +77,8 @@ def deck_draws(seed, table_id, hand_serial, ndraws=52):
     words = []
     for i in range(ndraws):
         if i % 18 == 0:
-            w = philox4x32_10((table_id & MASK32, hand_serial & MASK32, STREAM_DECK, i // 18), key)
+            w = philox4x32_10((table_id & MASK32, hand_serial & MASK32, (STREAM_DECK + i // 18) & MASK32,
+                               (hand_serial >> 32) & MASK32), key)
             words = [w[0] | (w[1] << 32), w[2] | (w[3] << 32)]
         if i % 9 == 0:
             x = words[(i // 9) % 2]
@@ -94,9 +99,11 @@ def pick_action(seed, table_id, step_serial, valid_mask_bits, policy=POLICY_RAND
     """Action of the synthetic agents. valid_mask_bits: bit a set iff action a valid."""
     if policy == POLICY_ALLIN:
         return 6
-    r = philox4x32_10((table_id & MASK32, (step_serial >> 2) & MASK32, STREAM_ACTION, 0), seed_key(seed))[step_serial & 3]
+    q, j = step_serial >> 3, step_serial & 7
+    w = philox4x32_10((table_id & MASK32, q & MASK32, STREAM_ACTION, (q >> 32) & MASK32), seed_key(seed))
+    r = (w[j >> 1] >> (16 * (j & 1))) & 0xFFFF
     n = bin(valid_mask_bits).count("1")
-    k = (r * n) >> 32
+    k = (r * n) >> 16
     for a in range(7):
         if (valid_mask_bits >> a) & 1:
             if k == 0:

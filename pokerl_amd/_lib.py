@@ -12,8 +12,9 @@ PK_OK, PK_E_INVALID_ARG, PK_E_NO_DEVICE, PK_E_HIP, PK_E_OOM, PK_E_TABLE = 0, -1,
 TERR_INVALID_ACTION, TERR_NO_WINNER, TERR_HAND_CAP, TERR_ENV_CAP = 1, 2, 4, 8
 FLAG_GAME_OVER, FLAG_HAND_OVER, FLAG_TURN_OVER = 1, 2, 4
 F_CREDITS, F_BETS, F_PENDING_BETS, F_PAYOFFS = 0, 1, 2, 3
-(I_ACTIVE_PLAYER, I_TURN, I_DEALER_IDX, I_SMALL_BLIND_IDX, I_BIG_BLIND_IDX, I_HAND, I_HAND_SERIAL,
- I_STEP_SERIAL) = range(8)
+I_ACTIVE_PLAYER, I_TURN, I_DEALER_IDX, I_SMALL_BLIND_IDX, I_BIG_BLIND_IDX, I_HAND = range(6)
+TF_POT, TF_HIGH_BET, TF_MIN_RAISE = 0, 1, 2
+ABI_VERSION = 2
 NUM_COUNTERS = 4
 MIN_PLAYERS, MAX_PLAYERS = 2, 10
 
@@ -23,7 +24,10 @@ SYMBOLS = ["pk_abi_version", "pk_device_count", "pk_last_error", "pk_create", "p
            "pk_get_min_raise", "pk_get_player_states", "pk_get_i32", "pk_get_cards", "pk_get_hand_ranks",
            "pk_eval_hands", "pk_compare_rankings", "pk_eval7_prefix", "pk_pick_actions", "pk_rollout",
            "pk_env_reset", "pk_env_step", "pk_get_obs", "pk_sync", "pk_time_rollout", "pk_get_obs_d",
-           "pk_get_valid_actions_d", "pk_env_step_d", "pk_env_reset_d", "pk_eval7_d", "pk_make_hands_d", "pk_time_eval7_d"]
+           "pk_get_valid_actions_d", "pk_env_step_d", "pk_env_reset_d", "pk_eval7_d", "pk_make_hands_d", "pk_time_eval7_d",
+           "pk_get_serials", "pk_set_serials", "pk_get_table_f64", "pk_get_game_over", "pk_eval_hands_d",
+           "pk_pick_actions_d", "pk_flush", "pk_get_owed", "pk_set_tuning", "pk_get_stream", "pk_set_stream", "pk_wait_event",
+           "pk_record_event"]
 
 
 class PokerlHipError(RuntimeError):
@@ -55,7 +59,7 @@ def lib():
     L.pk_reset.argtypes = [_vp, _vp, C.c_int]
     L.pk_step.argtypes = [_vp, _vp, _vp, _vp]
     L.pk_step_d.argtypes = [_vp, _vp, _vp, _vp]
-    L.pk_get_valid_actions.argtypes = [_vp, _vp]
+    L.pk_get_valid_actions.argtypes = [_vp, C.c_int, _vp]
     L.pk_get_f64.argtypes = [_vp, C.c_int, _vp]
     L.pk_get_min_raise.argtypes = [_vp, _vp]
     L.pk_get_player_states.argtypes = [_vp, _vp]
@@ -69,20 +73,33 @@ def lib():
     L.pk_rollout.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]
     L.pk_env_reset.argtypes = [_vp, _vp, C.c_int]
     L.pk_env_step.argtypes = [_vp, _vp, C.c_int, _vp, _vp, _vp, _vp]
-    L.pk_get_obs.argtypes = [_vp, _vp]
-    L.pk_get_obs_d.argtypes = [_vp, _vp]
-    L.pk_get_valid_actions_d.argtypes = [_vp, _vp]
+    L.pk_get_obs.argtypes = [_vp, C.c_int, _vp]
+    L.pk_get_obs_d.argtypes = [_vp, C.c_int, _vp]
+    L.pk_get_valid_actions_d.argtypes = [_vp, C.c_int, _vp]
     L.pk_env_step_d.argtypes = [_vp, _vp, C.c_int, _vp, _vp, _vp, _vp]
     L.pk_env_reset_d.argtypes = [_vp, _vp, C.c_int]
     L.pk_eval7_d.argtypes = [C.c_int, _vp, C.c_size_t, _vp, C.c_int]
     L.pk_make_hands_d.argtypes = [C.c_int, C.c_uint64, C.c_size_t, _vp]
     L.pk_time_eval7_d.argtypes = [C.c_int, _vp, C.c_size_t, _vp, C.c_int, C.c_int, C.POINTER(C.c_double)]
     L.pk_sync.argtypes = [_vp]
+    L.pk_get_serials.argtypes = [_vp, _vp, _vp]
+    L.pk_set_serials.argtypes = [_vp, _vp, _vp]
+    L.pk_get_table_f64.argtypes = [_vp, C.c_int, _vp]
+    L.pk_get_game_over.argtypes = [_vp, _vp]
+    L.pk_eval_hands_d.argtypes = [C.c_int, _vp, _vp, C.c_size_t, _vp, _vp, _vp, _vp]
+    L.pk_pick_actions_d.argtypes = [_vp, C.c_int, _vp]
+    L.pk_flush.argtypes = [_vp]
+    L.pk_get_owed.argtypes = [_vp, _vp]
+    L.pk_set_tuning.argtypes = [_vp, C.c_int, C.c_int]
+    L.pk_get_stream.argtypes = [_vp, C.POINTER(_vp)]
+    L.pk_set_stream.argtypes = [_vp, _vp]
+    L.pk_wait_event.argtypes = [_vp, _vp]
+    L.pk_record_event.argtypes = [_vp, _vp]
     L.pk_time_rollout.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), _vp]
     for name in SYMBOLS:
         if name != "pk_last_error":
             getattr(L, name).restype = C.c_int
-    if L.pk_abi_version() != 1:
+    if L.pk_abi_version() != ABI_VERSION:
         raise PokerlHipError("libpokerl_hip.so ABI version mismatch")
     _lib = L
     return L

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -97,14 +98,20 @@ __global__ void __launch_bounds__(PK_TABLE_BLOCK) k_pick(State S, Hot H, int pol
     actions[t] = pick_action(H, rng, H.table_id_base + (uint32_t)t, S.step_serial[t], S.valid[t], policy);
 }
 
-// K steps per table, in-kernel agents, table state in registers for the whole launch (K == 1: the unfused form).
-// Tables are independent, so lanes need not stay in lockstep INSIDE the launch: a lane whose step reaches end_hand
-// parks at LS_END while the other lanes of the wave run ahead on their own step counters; the expensive end_block
-// (showdown + side pots + setup_hand + deal) runs only once `park` lanes are waiting (or nobody else can run), which
-// raises its lane utilisation from ~25 % to ~60 %.  Every table still makes exactly K steps with the actions the RNG
-// spec assigns to (table, step_serial), so the state after the launch is bit-identical to the lockstep order.
+// K more steps per table, in-kernel agents, table state in registers for the whole launch (K == 1, endk == 1: the
+// unfused form).  Tables are independent, so lanes need not stay in lockstep INSIDE the launch: a lane whose step
+// reaches end_hand parks at LS_END while the other lanes of the wave run ahead on their own step counters; the expensive
+// end_block (showdown + side pots + setup_hand + deal) runs only once `park` lanes are waiting (or nobody else can
+// run), which raises its lane utilisation from ~25 % to ~60 %.
+// Nor need they stay in lockstep ACROSS launches: every table carries the number of steps it still owes (State::owed;
+// a launch adds K), and a launch may end while lanes still owe steps or are parked in the middle of one -- as soon as
+// fewer than `endk` of the wave's lanes have work left, i.e. before the stragglers would run alone (the tail that
+// costs a 20-step launch 45 % of its throughput).  What is left is picked up by the next launch or by the flush
+// (endk == 1: run to completion) the host issues before anything can observe the tables.  Every table still makes
+// exactly the requested steps with the actions the RNG spec assigns to (table, step_serial), so the observable state
+// is bit-identical to the lockstep order.
 template <int N>
-__global__ void __launch_bounds__(PK_TABLE_BLOCK) k_rollout(const State *__restrict__ Sp, Hot H, int K, int policy, int auto_reset, int park) {
+__global__ void __launch_bounds__(PK_TABLE_BLOCK) k_rollout(const State *__restrict__ Sp, Hot H, int K, int policy, int auto_reset, int park, int endk, int clear_terr) {
     // Array bases by pointer (loaded only where the table is loaded / stored), loop scalars by value: see pk::Hot.
     const State &S = *Sp;
     __shared__ Lds<N> lds;
@@ -112,24 +119,26 @@ __global__ void __launch_bounds__(PK_TABLE_BLOCK) k_rollout(const State *__restr
     const bool live = t < S.T;
     const uint32_t table_id = H.table_id_base + (uint32_t)t;
     Table<N> tb;
-    if (live) tb.load(S, t); else tb.blank();
-    const uint32_t hs0 = tb.hand_serial;
+    uint32_t owed = 0;
+    if (live) { tb.load(S, t); tb.hands_this_step = (int)S.mid[t]; owed = S.owed[t] + (uint32_t)K; } else tb.blank();
     uint32_t steps = 0;
-    int kdone = 0;
     bool alive = live;
     ActionRng rng;
     double high_bet;
+    // lanes that can work at all in this launch; the launch ends once fewer than `quit` of them still have work
+    const int cap = __popcll(__ballot(live && (owed > 0 || tb.lstate == LS_END)));
+    const int quit = max(1, cap - (PK_WAVE - endk));
     PK_PROF(tb.prof.start();)
     auto retire = [&]() {  // a lane whose Game.step() has returned
         if (tb.stepped && tb.lstate == LS_DONE) {
             tb.finish_step();
-            ++kdone;
-            if (tb.terr) alive = false;  // table keeps its (reference-identical) state; reported through terr
-            else ++steps;
+            --owed;
+            if (tb.terr) { alive = false; owed = 0; }  // table keeps its (reference-identical) state; reported through terr
+            else { ++steps; tb.games += tb.flags & PK_FLAG_GAME_OVER; }
         }
     };
     for (;;) {
-        if (alive && tb.lstate == LS_DONE && kdone < K) {
+        if (alive && tb.lstate == LS_DONE && owed > 0) {
             uint32_t mask = tb.valid_mask(high_bet);
             tb.begin_step(H, pick_action(H, rng, table_id, tb.step_serial, mask, policy), high_bet);
         }
@@ -139,8 +148,8 @@ __global__ void __launch_bounds__(PK_TABLE_BLOCK) k_rollout(const State *__restr
         retire();
         PK_PROF(tb.prof.lap(PF_CURSOR);)
         const int parked = __popcll(__ballot(tb.lstate == LS_END));
-        const int runnable = __popcll(__ballot(alive && tb.lstate == LS_DONE && kdone < K));
-        if (parked == 0 && runnable == 0) break;
+        const int runnable = __popcll(__ballot(alive && tb.lstate == LS_DONE && owed > 0));
+        if (parked + runnable < quit) break;
         if (parked >= park || runnable == 0) {
             tb.end_block(H, t, table_id, lds, auto_reset != 0);
             retire();
@@ -148,10 +157,11 @@ __global__ void __launch_bounds__(PK_TABLE_BLOCK) k_rollout(const State *__restr
     }
     if (live) {
         tb.store(S, t);
+        S.owed[t] = owed; S.mid[t] = (uint32_t)tb.hands_this_step;
         S.valid[t] = (uint8_t)tb.valid_mask(high_bet);
-        S.terr[t] = (uint8_t)(tb.terr | tb.seen);
+        S.terr[t] = (uint8_t)((clear_terr ? 0 : S.terr[t]) | tb.terr | tb.seen);
     }
-    wave_add_counters(S, steps, tb.hand_serial - hs0, tb.evals, tb.games);  // every lane takes part in the shuffles
+    wave_add_counters(S, steps, tb.hands, tb.evals, tb.games);  // every lane takes part in the shuffles
     PK_PROF(tb.prof.flush(S.prof);)
 }
 
@@ -280,8 +290,6 @@ __global__ void k_export_i32(State S, int field, int32_t *out) {
         case PK_I_SMALL_BLIND_IDX: v = (cur >> 8) & 0xf; break;
         case PK_I_BIG_BLIND_IDX: v = (cur >> 12) & 0xf; break;
         case PK_I_HAND: v = S.hand[t]; break;
-        case PK_I_HAND_SERIAL: v = (int32_t)S.hand_serial[t]; break;
-        case PK_I_STEP_SERIAL: v = (int32_t)S.step_serial[t]; break;
     }
     out[t] = v;
 }
@@ -299,30 +307,80 @@ __global__ void k_export_show(const uint32_t *show, int T, int N, uint8_t *rank,
     rank[i] = (uint8_t)(v >> 20);
     kick[i] = v & 0xFFFFF;
 }
-__global__ void k_export_valid(const uint8_t *valid, int T, uint8_t *out) {  // bitmask -> one-hot [T][7]
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= T * PK_NUM_MOVES) return;
-    int t = i / PK_NUM_MOVES, a = i - t * PK_NUM_MOVES;
-    out[i] = (valid[t] >> a) & 1;
+// Game.get_valid_actions(player), game.py:339-383, of ANY seat as a bitmask (runtime N: export kernels are not
+// templated).  Same expressions, in the same order, as Table::valid_mask.
+__device__ inline uint32_t valid_bits_of(const State &S, int t, int N, int player) {
+    const size_t T = (size_t)S.T;
+    double high_bet = S.pending[t];                                               // :365 np.max
+    for (int p = 1; p < N; ++p) { double x = S.pending[(size_t)p * T + t]; high_bet = (x > high_bet) ? x : high_bet; }
+    const double credit = S.credits[(size_t)player * T + t], min_raise = S.min_raise[t];   // :366
+    uint32_t mask = (1u << MV_FOLD) | (1u << MV_ALL_IN);                          // :367
+    const double d = credit - high_bet;
+    const double rv0 = 0.1 * d, rv1 = 0.25 * d, rv2 = 0.5 * d;                    // :370
+    mask |= (rv0 > min_raise && (high_bet + rv0) < credit) ? (1u << 3) : 0;       // :371
+    mask |= (rv1 > min_raise && (high_bet + rv1) < credit) ? (1u << 4) : 0;
+    mask |= (rv2 > min_raise && (high_bet + rv2) < credit) ? (1u << 5) : 0;
+    mask |= (high_bet == 0.0) ? (1u << MV_CHECK) : 0;                             // :375
+    mask |= (high_bet < credit) ? (1u << MV_CALL) : 0;                            // :376
+    return mask;
 }
-// Game.StateView(active player), game.py:117-131, as one dense f64 row per table (layout: pokerl_hip.h PK_OBS_DIM).
-__global__ void k_obs(State S, int N, double *out) {
+// player < 0: each table's active player (the cached mask); else that seat on every table.  out: one-hot [T][7]
+__global__ void k_export_valid(State S, int N, int player, uint8_t *out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= S.T * PK_NUM_MOVES) return;
+    int t = i / PK_NUM_MOVES, a = i - t * PK_NUM_MOVES;
+    uint32_t m = player < 0 ? S.valid[t] : valid_bits_of(S, t, N, player);
+    out[i] = (m >> a) & 1;
+}
+// Game.StateView(game, player), game.py:117-131, as one dense f64 row per table (layout: pokerl_hip.h PK_OBS_DIM).
+// player < 0: the active player of each table (what `game.active_state` is, game.py:323-332).
+__global__ void k_obs(State S, int N, int player, double *out) {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= S.T) return;
     const int T = S.T, D = PK_OBS_DIM(N);
     double *o = out + (size_t)t * D;
     uint32_t cur = S.cursors[t];
     int active = cur & 0xf, turn = (cur >> 16) & 0xf;
+    const int who = player < 0 ? active : player;
+    const uint32_t vm = player < 0 ? S.valid[t] : valid_bits_of(S, t, N, who);
     auto card = [&](int c) { return (double)((S.cards[(size_t)(c >> 2) * T + t] >> (8 * (c & 3))) & 0xff); };
-    o[0] = active; o[1] = turn; o[2] = S.min_raise[t];
-    for (int a = 0; a < PK_NUM_MOVES; ++a) o[3 + a] = (S.valid[t] >> a) & 1;
-    o[10] = card(5 + 2 * active); o[11] = card(6 + 2 * active);                    // game.py:385-389
+    o[0] = who; o[1] = turn; o[2] = S.min_raise[t];
+    for (int a = 0; a < PK_NUM_MOVES; ++a) o[3 + a] = (vm >> a) & 1;
+    o[10] = card(5 + 2 * who); o[11] = card(6 + 2 * who);                          // game.py:385-389
     for (int c = 0; c < 5; ++c) o[12 + c] = (turn != 0 && c < turn + 2) ? card(c) : -1.0;  // game.py:278
     for (int p = 0; p < N; ++p) {
         o[17 + p] = S.credits[(size_t)p * T + t];
         o[17 + N + p] = S.bets[(size_t)p * T + t];
         o[17 + 2 * N + p] = S.pending[(size_t)p * T + t];
     }
+}
+// Game.pot (np.sum(bets) in numpy's association order, game.py:281-284 + SURVEY A.5) / Game.high_bet
+// (np.max(pending_bets), game.py:287-290) per table; Game.game_over (game.py:317-320).
+__global__ void k_table_f64(State S, int N, int field, double *out) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= S.T) return;
+    const size_t T = (size_t)S.T;
+    double r;
+    if (field == PK_TF_POT) {
+        const double *a = S.bets;
+        if (N < 8) {
+            r = a[t];
+            for (int p = 1; p < N; ++p) r = r + a[(size_t)p * T + t];
+        } else {
+            r = ((a[t] + a[T + t]) + (a[2 * T + t] + a[3 * T + t])) + ((a[4 * T + t] + a[5 * T + t]) + (a[6 * T + t] + a[7 * T + t]));
+            for (int p = 8; p < N; ++p) r = r + a[(size_t)p * T + t];
+        }
+    } else if (field == PK_TF_HIGH_BET) {
+        r = S.pending[t];
+        for (int p = 1; p < N; ++p) { double x = S.pending[(size_t)p * T + t]; r = (x > r) ? x : r; }
+    } else r = S.min_raise[t];
+    out[t] = r;
+}
+__global__ void k_game_over(const uint64_t *ss, int T, int N, uint8_t *out) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    uint32_t broken = (uint32_t)(ss[t] >> 48) & 0xffff;
+    out[t] = __popc(~broken & ((1u << N) - 1)) == 1;
 }
 
 // pokerl.judger.eval_hand batched: one hand per lane, cards[M][7] bytes
@@ -356,9 +414,10 @@ __global__ void k_compare(const uint8_t *rank, const uint32_t *kick, int n, size
     for (int p = 0; p < n; ++p) onehot[i * n + p] = (win >> p) & 1;
 }
 // Streaming evaluator: two hands per lane per iteration (one 16-byte load, one 8-byte store), grid-stride.
-template <bool DISTINCT>
+// VEC: hands 16-byte and out 8-byte aligned (any hipMalloc'ed base); otherwise one hand per lane per iteration.
+template <bool DISTINCT, bool VEC>
 __global__ void __launch_bounds__(256) k_eval7_stream(const uint64_t *__restrict__ hands, size_t m, uint32_t *__restrict__ out) {
-    const size_t pairs = m / 2, stride = (size_t)gridDim.x * blockDim.x;
+    const size_t pairs = VEC ? m / 2 : 0, stride = (size_t)gridDim.x * blockDim.x;
     auto eval1 = [](uint64_t w) {
         uint32_t lo = (uint32_t)w, hi = (uint32_t)(w >> 32);
         uint32_t c[7] = {lo & 0xff, (lo >> 8) & 0xff, (lo >> 16) & 0xff, lo >> 24, hi & 0xff, (hi >> 8) & 0xff, (hi >> 16) & 0xff};
@@ -371,7 +430,11 @@ __global__ void __launch_bounds__(256) k_eval7_stream(const uint64_t *__restrict
         r.x = eval1(w.x); r.y = eval1(w.y);
         reinterpret_cast<uint2 *>(out)[i] = r;
     }
-    if ((m & 1) && blockIdx.x == 0 && threadIdx.x == 0) out[m - 1] = eval1(hands[m - 1]);
+    if constexpr (VEC) {
+        if ((m & 1) && blockIdx.x == 0 && threadIdx.x == 0) out[m - 1] = eval1(hands[m - 1]);
+    } else {
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride) out[i] = eval1(hands[i]);
+    }
 }
 // hand i = first 7 cards of the RNG-spec deck of (table_id = i, hand_serial = 0): the deal of a 1-seat table
 __global__ void __launch_bounds__(256) k_make_hands(Hot H, size_t m, uint64_t *out) {
@@ -418,19 +481,26 @@ static thread_local std::string g_err;
 struct pk_handle {
     int device = 0, T = 0, N = 0, block = 64, dealer = 0;
     int park = 40;  // lanes parked at end_hand before a wave runs end_block (k_rollout); tuning knob PK_PARK
-    hipStream_t stream = nullptr;
+    int endk = 48;  // a deferred rollout launch ends once fewer than this many of a wave's lanes have work; knob PK_ENDK
+                    // (measured optimum 44..52 at 20 and at 512 steps per launch: tools/tune_sweep.py)
+    // Deferred rollout work: steps requested by pk_rollout that no launch has executed yet may exist on the device
+    // (State::owed, steps in flight).  Every entry point that reads or changes table state flushes first.
+    bool pending = false;
+    int pend_policy = 0, pend_auto = 0;
+    hipStream_t stream = nullptr, own_stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     State S{};
     State *d_S = nullptr;  // device copy of S (kernels that take the state by pointer)
     Hot hot{};             // loop scalars, passed by value
     unsigned long long *d_totals = nullptr;  // [PK_NUM_COUNTERS] output of k_sum_counters
     void *arena = nullptr;
-    // staging (device)
+    // staging (device) + pinned staging (host) of the host-buffer entry points
     int32_t *d_actions = nullptr;
     uint8_t *d_flags = nullptr, *d_terr = nullptr, *d_mask = nullptr, *d_done = nullptr, *d_handf = nullptr;
     double *d_reward = nullptr;
     void *d_export = nullptr;
     size_t export_bytes = 0;
+    uint8_t *h_pinned = nullptr;  // [T] pinned: per-table error bytes of pk_step / pk_env_step
     std::string err;
     int fail(int code, const char *what, hipError_t e = hipSuccess) {
         err = what;
@@ -480,9 +550,31 @@ struct DeviceGuard {
 static inline int table_grid(const pk_handle *h) { return (h->T + h->block - 1) / h->block; }
 static inline int flat_grid(size_t n) { return (int)((n + 255) / 256); }
 
+// One fused rollout launch: every table owes k_steps more steps; the launch ends once fewer than `endk` lanes of a
+// wave have work left (endk == 1: runs to completion).
+static int launch_rollout(pk_handle *h, int k_steps, int policy, int auto_reset, int endk) {
+    DISPATCH_N(h, k_rollout, table_grid(h), (const State *)h->d_S, h->hot, k_steps, policy, auto_reset, h->park, endk,
+               h->pending ? 0 : 1);
+    HIPCHK(h, hipGetLastError());
+    h->pending = endk > 1;
+    h->pend_policy = policy; h->pend_auto = auto_reset;
+    return PK_OK;
+}
+// Completes whatever deferred rollout launches left undone.  Called by every entry point that reads or mutates tables.
+static int flush(pk_handle *h) {
+    if (!h->pending) return PK_OK;
+    return launch_rollout(h, 0, h->pend_policy, h->pend_auto, 1);
+}
+#define FLUSH(h)                   \
+    do {                           \
+        int rc_ = flush(h);        \
+        if (rc_) return rc_;       \
+    } while (0)
+
 template <typename F>
 static int export_to_host(pk_handle *h, void *out, size_t bytes, F launch) {
     ON_DEVICE(h);
+    FLUSH(h);
     if (bytes > h->export_bytes) return h->fail(PK_E_INVALID_ARG, "export buffer too small");
     launch();
     HIPCHK(h, hipGetLastError());
@@ -524,19 +616,24 @@ int pk_create(pk_handle **out, int device, int num_tables, int num_players, cons
     h->device = device; h->T = num_tables; h->N = num_players; h->dealer = dealer;
     h->block = PK_TABLE_BLOCK;
     if (const char *pk = getenv("PK_PARK")) { int v = atoi(pk); if (v >= 1 && v <= 64) h->park = v; }
+    if (const char *pk = getenv("PK_ENDK")) { int v = atoi(pk); if (v >= 1 && v <= 64) h->endk = v; }
     auto bail = [&](int code) { g_err = h->err; pk_destroy(h); return code; };
     DeviceGuard guard(device);
     if (!guard.ok) return bail(h->fail(PK_E_HIP, "hipSetDevice"));
-    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return bail(h->fail(PK_E_HIP, "hipStreamCreate"));
+    if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) return bail(h->fail(PK_E_HIP, "hipStreamCreate"));
+    h->stream = h->own_stream;
     if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) return bail(h->fail(PK_E_HIP, "hipEventCreate"));
+    if (hipHostMalloc((void **)&h->h_pinned, (size_t)num_tables, hipHostMallocDefault) != hipSuccess) return bail(h->fail(PK_E_OOM, "hipHostMalloc"));
 
     const size_t T = (size_t)num_tables, N = (size_t)num_players;
     const size_t K = 5 + 2 * N, W = (K + 3) / 4;
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     size_t obs = (size_t)PK_OBS_DIM(N) * 8;
     h->export_bytes = al(T * (obs > N * 8 ? obs : N * 8));
-    size_t total = 4 * al(T * N * 8) + al(T * 8) + al(T * 8) + 4 * al(T * 4) + al(W * T * 4) + al(N * T * 4) + 2 * al(T) +
-                   al(((T + PK_TABLE_BLOCK - 1) / PK_TABLE_BLOCK) * PK_NUM_COUNTERS * 8) + al(PK_NUM_COUNTERS * 8) + al(PF_SLOTS * 8) + al(sizeof(State)) + al(PK_MAX_PLAYERS * 8) + al(T * 4) + 5 * al(T) + al(T * 8) + h->export_bytes;
+    const size_t nwaves = (T + PK_TABLE_BLOCK - 1) / PK_TABLE_BLOCK;
+    size_t total = 4 * al(T * N * 8) + 4 * al(T * 8) + 4 * al(T * 4) + al(W * T * 4) + al(N * T * 4) + 2 * al(T) +
+                   al(nwaves * PK_NUM_COUNTERS * 8) + al(PK_NUM_COUNTERS * 8) + al(PF_SLOTS * 8) + al(sizeof(State)) +
+                   al(PK_MAX_PLAYERS * 8) + al(T * 4) + 5 * al(T) + al(T * 8) + h->export_bytes;
     e = hipMalloc(&h->arena, total);
     if (e != hipSuccess) return bail(h->fail(PK_E_OOM, "hipMalloc(table state)", e));
     if (hipMemsetAsync(h->arena, 0, total, h->stream) != hipSuccess) return bail(h->fail(PK_E_HIP, "hipMemset"));
@@ -547,12 +644,13 @@ int pk_create(pk_handle **out, int device, int num_tables, int num_players, cons
     S.pending = (double *)take(T * N * 8); S.payoffs = (double *)take(T * N * 8);
     S.min_raise = (double *)take(T * 8);
     S.seat_states = (uint64_t *)take(T * 8);
+    S.hand_serial = (uint64_t *)take(T * 8); S.step_serial = (uint64_t *)take(T * 8);
     S.cursors = (uint32_t *)take(T * 4); S.hand = (int32_t *)take(T * 4);
-    S.hand_serial = (uint32_t *)take(T * 4); S.step_serial = (uint32_t *)take(T * 4);
+    S.owed = (uint32_t *)take(T * 4); S.mid = (uint32_t *)take(T * 4);
     S.cards = (uint32_t *)take(W * T * 4);
     S.show = (uint32_t *)take(N * T * 4);
     S.valid = (uint8_t *)take(T); S.terr = (uint8_t *)take(T);
-    S.counters = (unsigned long long *)take(((T + PK_TABLE_BLOCK - 1) / PK_TABLE_BLOCK) * PK_NUM_COUNTERS * 8);
+    S.counters = (unsigned long long *)take(nwaves * PK_NUM_COUNTERS * 8);
     h->d_totals = (unsigned long long *)take(PK_NUM_COUNTERS * 8);
     S.prof = (unsigned long long *)take(PF_SLOTS * 8);
     h->d_S = (State *)take(sizeof(State));
@@ -599,15 +697,50 @@ int pk_destroy(pk_handle *h) {
     DeviceGuard guard(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->arena) (void)hipFree(h->arena);
+    if (h->h_pinned) (void)hipHostFree(h->h_pinned);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
-    if (h->stream) (void)hipStreamDestroy(h->stream);
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
     return PK_OK;
 }
 
 int pk_num_tables(const pk_handle *h) { return h ? h->T : PK_E_INVALID_ARG; }
 int pk_num_players(const pk_handle *h) { return h ? h->N : PK_E_INVALID_ARG; }
+
+// ---- stream control: how a caller with its own stream (a learner on the same GPU) orders its work against ours
+int pk_get_stream(pk_handle *h, void **stream_out) {
+    if (!h || !stream_out) return PK_E_INVALID_ARG;
+    *stream_out = (void *)h->stream;
+    return PK_OK;
+}
+int pk_set_stream(pk_handle *h, void *stream) {
+    if (!h) return PK_E_INVALID_ARG;
+    ON_DEVICE(h);
+    HIPCHK(h, hipStreamSynchronize(h->stream));  // nothing of ours may still be running on the stream we leave
+    h->stream = stream ? (hipStream_t)stream : h->own_stream;
+    return PK_OK;
+}
+int pk_wait_event(pk_handle *h, void *event) {
+    if (!h || !event) return PK_E_INVALID_ARG;
+    ON_DEVICE(h);
+    HIPCHK(h, hipStreamWaitEvent(h->stream, (hipEvent_t)event, 0));
+    return PK_OK;
+}
+int pk_record_event(pk_handle *h, void *event) {
+    if (!h || !event) return PK_E_INVALID_ARG;
+    ON_DEVICE(h);
+    FLUSH(h);  // "everything requested so far" includes deferred rollout steps
+    HIPCHK(h, hipEventRecord((hipEvent_t)event, h->stream));
+    return PK_OK;
+}
+
+int pk_set_tuning(pk_handle *h, int park, int endk) {
+    if (!h) return PK_E_INVALID_ARG;
+    if (park >= 1 && park <= 64) h->park = park;
+    if (endk >= 1 && endk <= 64) h->endk = endk;
+    return PK_OK;
+}
 
 static int upload_mask(pk_handle *h, const uint8_t *mask, const uint8_t **dmask) {
     *dmask = nullptr;
@@ -621,6 +754,7 @@ static int upload_mask(pk_handle *h, const uint8_t *mask, const uint8_t **dmask)
 int pk_reset(pk_handle *h, const uint8_t *mask, int dealer) {
     if (!h) return PK_E_INVALID_ARG;
     ON_DEVICE(h);
+    FLUSH(h);
     const uint8_t *dmask;
     int rc = upload_mask(h, mask, &dmask);
     if (rc) return rc;
@@ -634,6 +768,7 @@ int pk_reset(pk_handle *h, const uint8_t *mask, int dealer) {
 int pk_step_d(pk_handle *h, const int32_t *actions_d, uint8_t *flags_d, uint8_t *terr_d) {
     if (!h || !actions_d || !flags_d) return h ? h->fail(PK_E_INVALID_ARG, "pk_step_d: NULL buffer") : PK_E_INVALID_ARG;
     ON_DEVICE(h);
+    FLUSH(h);
     DISPATCH_N(h, k_step, table_grid(h), h->S, h->hot, actions_d, flags_d, terr_d);
     HIPCHK(h, hipGetLastError());
     return PK_OK;
@@ -651,20 +786,21 @@ int pk_step(pk_handle *h, const int32_t *actions, uint8_t *flags, uint8_t *terr)
     HIPCHK(h, hipMemcpyAsync(h->d_actions, actions, T * 4, hipMemcpyHostToDevice, h->stream));
     int rc = pk_step_d(h, h->d_actions, h->d_flags, h->d_terr);
     if (rc) return rc;
-    std::vector<uint8_t> te(T);
     HIPCHK(h, hipMemcpyAsync(flags, h->d_flags, T, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipMemcpyAsync(te.data(), h->d_terr, T, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->h_pinned, h->d_terr, T, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (terr) memcpy(terr, te.data(), T);
-    if (any_terr(te.data(), h->T)) return h->fail(PK_E_TABLE, "pk_step: per-table error(s), see terr");
+    if (terr) memcpy(terr, h->h_pinned, T);
+    if (any_terr(h->h_pinned, h->T)) return h->fail(PK_E_TABLE, "pk_step: per-table error(s), see terr");
     return PK_OK;
 }
 
-int pk_get_valid_actions(pk_handle *h, uint8_t *out) {
-    if (!h || !out) return PK_E_INVALID_ARG;
+static int bad_player(const pk_handle *h, int player) { return player >= h->N; }
+
+int pk_get_valid_actions(pk_handle *h, int player, uint8_t *out) {
+    if (!h || !out || bad_player(h, player)) return h ? h->fail(PK_E_INVALID_ARG, "pk_get_valid_actions: bad argument") : PK_E_INVALID_ARG;
     size_t n = (size_t)h->T * PK_NUM_MOVES;
     return export_to_host(h, out, n, [&] {
-        hipLaunchKernelGGL(k_export_valid, dim3(flat_grid(n)), dim3(256), 0, h->stream, h->S.valid, h->T, (uint8_t *)h->d_export);
+        hipLaunchKernelGGL(k_export_valid, dim3(flat_grid(n)), dim3(256), 0, h->stream, h->S, h->N, player, (uint8_t *)h->d_export);
     });
 }
 
@@ -677,12 +813,20 @@ int pk_get_f64(pk_handle *h, int field, double *out) {
     });
 }
 
-int pk_get_min_raise(pk_handle *h, double *out) {
+int pk_get_table_f64(pk_handle *h, int field, double *out) {
+    if (!h || !out || field < 0 || field > PK_TF_MIN_RAISE) return h ? h->fail(PK_E_INVALID_ARG, "pk_get_table_f64: bad field") : PK_E_INVALID_ARG;
+    return export_to_host(h, out, (size_t)h->T * 8, [&] {
+        hipLaunchKernelGGL(k_table_f64, dim3(flat_grid(h->T)), dim3(256), 0, h->stream, h->S, h->N, field, (double *)h->d_export);
+    });
+}
+
+int pk_get_min_raise(pk_handle *h, double *out) { return pk_get_table_f64(h, PK_TF_MIN_RAISE, out); }
+
+int pk_get_game_over(pk_handle *h, uint8_t *out) {
     if (!h || !out) return PK_E_INVALID_ARG;
-    ON_DEVICE(h);
-    HIPCHK(h, hipMemcpyAsync(out, h->S.min_raise, (size_t)h->T * 8, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    return PK_OK;
+    return export_to_host(h, out, (size_t)h->T, [&] {
+        hipLaunchKernelGGL(k_game_over, dim3(flat_grid(h->T)), dim3(256), 0, h->stream, h->S.seat_states, h->T, h->N, (uint8_t *)h->d_export);
+    });
 }
 
 int pk_get_player_states(pk_handle *h, uint8_t *out) {
@@ -694,10 +838,30 @@ int pk_get_player_states(pk_handle *h, uint8_t *out) {
 }
 
 int pk_get_i32(pk_handle *h, int field, int32_t *out) {
-    if (!h || !out || field < 0 || field > PK_I_STEP_SERIAL) return h ? h->fail(PK_E_INVALID_ARG, "pk_get_i32: bad field") : PK_E_INVALID_ARG;
+    if (!h || !out || field < 0 || field > PK_I_HAND) return h ? h->fail(PK_E_INVALID_ARG, "pk_get_i32: bad field") : PK_E_INVALID_ARG;
     return export_to_host(h, out, (size_t)h->T * 4, [&] {
         hipLaunchKernelGGL(k_export_i32, dim3(flat_grid(h->T)), dim3(256), 0, h->stream, h->S, field, (int32_t *)h->d_export);
     });
+}
+
+int pk_get_serials(pk_handle *h, uint64_t *hand_serial, uint64_t *step_serial) {
+    if (!h) return PK_E_INVALID_ARG;
+    ON_DEVICE(h);
+    FLUSH(h);
+    if (hand_serial) HIPCHK(h, hipMemcpyAsync(hand_serial, h->S.hand_serial, (size_t)h->T * 8, hipMemcpyDeviceToHost, h->stream));
+    if (step_serial) HIPCHK(h, hipMemcpyAsync(step_serial, h->S.step_serial, (size_t)h->T * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return PK_OK;
+}
+
+int pk_set_serials(pk_handle *h, const uint64_t *hand_serial, const uint64_t *step_serial) {
+    if (!h) return PK_E_INVALID_ARG;
+    ON_DEVICE(h);
+    FLUSH(h);
+    if (hand_serial) HIPCHK(h, hipMemcpyAsync(h->S.hand_serial, hand_serial, (size_t)h->T * 8, hipMemcpyHostToDevice, h->stream));
+    if (step_serial) HIPCHK(h, hipMemcpyAsync(h->S.step_serial, step_serial, (size_t)h->T * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return PK_OK;
 }
 
 int pk_get_cards(pk_handle *h, uint8_t *out) {
@@ -712,6 +876,7 @@ int pk_get_cards(pk_handle *h, uint8_t *out) {
 int pk_get_hand_ranks(pk_handle *h, uint8_t *rank, uint32_t *kick) {
     if (!h || !rank || !kick) return PK_E_INVALID_ARG;
     ON_DEVICE(h);
+    FLUSH(h);
     size_t n = (size_t)h->T * h->N;
     uint32_t *dk = (uint32_t *)h->d_export;
     uint8_t *dr = (uint8_t *)h->d_export + n * 4;
@@ -724,27 +889,29 @@ int pk_get_hand_ranks(pk_handle *h, uint8_t *rank, uint32_t *kick) {
     return PK_OK;
 }
 
-int pk_get_obs(pk_handle *h, double *out) {
-    if (!h || !out) return PK_E_INVALID_ARG;
+int pk_get_obs(pk_handle *h, int player, double *out) {
+    if (!h || !out || bad_player(h, player)) return h ? h->fail(PK_E_INVALID_ARG, "pk_get_obs: bad argument") : PK_E_INVALID_ARG;
     size_t bytes = (size_t)h->T * PK_OBS_DIM(h->N) * 8;
     return export_to_host(h, out, bytes, [&] {
-        hipLaunchKernelGGL(k_obs, dim3(flat_grid(h->T)), dim3(256), 0, h->stream, h->S, h->N, (double *)h->d_export);
+        hipLaunchKernelGGL(k_obs, dim3(flat_grid(h->T)), dim3(256), 0, h->stream, h->S, h->N, player, (double *)h->d_export);
     });
 }
 
-int pk_get_obs_d(pk_handle *h, double *out_d) {
-    if (!h || !out_d) return PK_E_INVALID_ARG;
+int pk_get_obs_d(pk_handle *h, int player, double *out_d) {
+    if (!h || !out_d || bad_player(h, player)) return h ? h->fail(PK_E_INVALID_ARG, "pk_get_obs_d: bad argument") : PK_E_INVALID_ARG;
     ON_DEVICE(h);
-    hipLaunchKernelGGL(k_obs, dim3(flat_grid(h->T)), dim3(256), 0, h->stream, h->S, h->N, out_d);
+    FLUSH(h);
+    hipLaunchKernelGGL(k_obs, dim3(flat_grid(h->T)), dim3(256), 0, h->stream, h->S, h->N, player, out_d);
     HIPCHK(h, hipGetLastError());
     return PK_OK;
 }
 
-int pk_get_valid_actions_d(pk_handle *h, uint8_t *out_d) {
-    if (!h || !out_d) return PK_E_INVALID_ARG;
+int pk_get_valid_actions_d(pk_handle *h, int player, uint8_t *out_d) {
+    if (!h || !out_d || bad_player(h, player)) return h ? h->fail(PK_E_INVALID_ARG, "pk_get_valid_actions_d: bad argument") : PK_E_INVALID_ARG;
     ON_DEVICE(h);
+    FLUSH(h);
     size_t n = (size_t)h->T * PK_NUM_MOVES;
-    hipLaunchKernelGGL(k_export_valid, dim3(flat_grid(n)), dim3(256), 0, h->stream, h->S.valid, h->T, out_d);
+    hipLaunchKernelGGL(k_export_valid, dim3(flat_grid(n)), dim3(256), 0, h->stream, h->S, h->N, player, out_d);
     HIPCHK(h, hipGetLastError());
     return PK_OK;
 }
@@ -752,6 +919,7 @@ int pk_get_valid_actions_d(pk_handle *h, uint8_t *out_d) {
 int pk_env_reset_d(pk_handle *h, const uint8_t *mask_d, int opp_policy) {
     if (!h || opp_policy < 0 || opp_policy > 1) return h ? h->fail(PK_E_INVALID_ARG, "pk_env_reset_d: bad argument") : PK_E_INVALID_ARG;
     ON_DEVICE(h);
+    FLUSH(h);
     DISPATCH_N(h, k_env_reset, table_grid(h), h->S, h->hot, mask_d, opp_policy);
     HIPCHK(h, hipGetLastError());
     return PK_OK;
@@ -762,7 +930,17 @@ int pk_env_step_d(pk_handle *h, const int32_t *actions_d, int opp_policy, double
     if (!h || !actions_d || !reward_d || !done_d || !hand_d || !terr_d || opp_policy < 0 || opp_policy > 1)
         return h ? h->fail(PK_E_INVALID_ARG, "pk_env_step_d: bad argument") : PK_E_INVALID_ARG;
     ON_DEVICE(h);
+    FLUSH(h);
     DISPATCH_N(h, k_env_step, table_grid(h), h->S, h->hot, actions_d, opp_policy, reward_d, done_d, hand_d, terr_d);
+    HIPCHK(h, hipGetLastError());
+    return PK_OK;
+}
+
+int pk_pick_actions_d(pk_handle *h, int policy, int32_t *actions_d) {
+    if (!h || !actions_d || policy < 0 || policy > 1) return h ? h->fail(PK_E_INVALID_ARG, "pk_pick_actions_d: bad argument") : PK_E_INVALID_ARG;
+    ON_DEVICE(h);
+    FLUSH(h);
+    DISPATCH_N(h, k_pick, table_grid(h), h->S, h->hot, policy, actions_d);
     HIPCHK(h, hipGetLastError());
     return PK_OK;
 }
@@ -770,19 +948,10 @@ int pk_env_step_d(pk_handle *h, const int32_t *actions_d, int opp_policy, double
 int pk_pick_actions(pk_handle *h, int policy, int32_t *actions) {
     if (!h || !actions || policy < 0 || policy > 1) return h ? h->fail(PK_E_INVALID_ARG, "pk_pick_actions: bad argument") : PK_E_INVALID_ARG;
     ON_DEVICE(h);
-    DISPATCH_N(h, k_pick, table_grid(h), h->S, h->hot, policy, h->d_actions);
-    HIPCHK(h, hipGetLastError());
+    int rc = pk_pick_actions_d(h, policy, h->d_actions);
+    if (rc) return rc;
     HIPCHK(h, hipMemcpyAsync(actions, h->d_actions, (size_t)h->T * 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    return PK_OK;
-}
-
-static int launch_rollout(pk_handle *h, int k_steps, int policy, int auto_reset, int fused) {
-    if (k_steps <= 0) return PK_OK;  // nothing to run (callers use k_steps == 0 to just fetch the counters)
-    const int launches = fused ? 1 : k_steps, k_each = fused ? k_steps : 1;
-    for (int k = 0; k < launches; ++k)
-        DISPATCH_N(h, k_rollout, table_grid(h), (const State *)h->d_S, h->hot, k_each, policy, auto_reset, h->park);
-    HIPCHK(h, hipGetLastError());
     return PK_OK;
 }
 
@@ -796,24 +965,59 @@ static int fetch_counters(pk_handle *h, uint64_t *counters) {
     return PK_OK;
 }
 
+// fused: one launch that may leave work for later (counters == NULL) or must complete it (counters != NULL);
+// unfused: k_steps complete single-step launches (state round-trips HBM every step).
+static int enqueue_rollout(pk_handle *h, int k_steps, int policy, int auto_reset, int fused, bool complete) {
+    if (h->pending && (policy != h->pend_policy || auto_reset != h->pend_auto)) FLUSH(h);  // owed steps keep THEIR agents
+    if (!fused) {
+        FLUSH(h);
+        for (int k = 0; k < k_steps; ++k) {
+            int rc = launch_rollout(h, 1, policy, auto_reset, 1);
+            if (rc) return rc;
+        }
+        return PK_OK;
+    }
+    if (k_steps == 0) return complete ? flush(h) : PK_OK;
+    // deferral only in the throughput mode: without auto_reset a table that reports an error stops for the rest of THIS
+    // call (and is retried by the next), so calls must not be merged
+    return launch_rollout(h, k_steps, policy, auto_reset, (complete || !auto_reset) ? 1 : h->endk);
+}
+
 int pk_rollout(pk_handle *h, int k_steps, int policy, int auto_reset, int fused, uint64_t *counters) {
     if (!h || k_steps < 0 || policy < 0 || policy > 1) return h ? h->fail(PK_E_INVALID_ARG, "pk_rollout: bad argument") : PK_E_INVALID_ARG;
     ON_DEVICE(h);
-    int rc = launch_rollout(h, k_steps, policy, auto_reset, fused);
+    int rc = enqueue_rollout(h, k_steps, policy, auto_reset ? 1 : 0, fused, counters != nullptr);
     if (rc) return rc;
     if (counters) return fetch_counters(h, counters);
     return PK_OK;
 }
 
+int pk_get_owed(pk_handle *h, uint32_t *out) {
+    if (!h || !out) return PK_E_INVALID_ARG;
+    ON_DEVICE(h);
+    HIPCHK(h, hipMemcpyAsync(out, h->S.owed, (size_t)h->T * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return PK_OK;
+}
+
+int pk_flush(pk_handle *h) {
+    if (!h) return PK_E_INVALID_ARG;
+    ON_DEVICE(h);
+    return flush(h);
+}
+
 int pk_time_rollout(pk_handle *h, int k_steps, int policy, int auto_reset, int fused, int reps, double *ms_per_launch,
                     uint64_t *counters) {
-    if (!h || !ms_per_launch || reps < 1) return h ? h->fail(PK_E_INVALID_ARG, "pk_time_rollout: bad argument") : PK_E_INVALID_ARG;
+    if (!h || !ms_per_launch || reps < 1 || k_steps < 1 || policy < 0 || policy > 1)
+        return h ? h->fail(PK_E_INVALID_ARG, "pk_time_rollout: bad argument") : PK_E_INVALID_ARG;
     ON_DEVICE(h);
+    FLUSH(h);
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
     for (int r = 0; r < reps; ++r) {
-        int rc = launch_rollout(h, k_steps, policy, auto_reset, fused);
+        int rc = enqueue_rollout(h, k_steps, policy, auto_reset ? 1 : 0, fused, false);
         if (rc) return rc;
     }
+    FLUSH(h);  // what the deferred launches left is part of the work that is being timed
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));
     HIPCHK(h, hipEventSynchronize(h->ev1));
     float ms = 0.f;
@@ -830,8 +1034,8 @@ int pk_env_reset(pk_handle *h, const uint8_t *mask, int opp_policy) {
     const uint8_t *dmask;
     int rc = upload_mask(h, mask, &dmask);
     if (rc) return rc;
-    DISPATCH_N(h, k_env_reset, table_grid(h), h->S, h->hot, dmask, opp_policy);
-    HIPCHK(h, hipGetLastError());
+    rc = pk_env_reset_d(h, dmask, opp_policy);
+    if (rc) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return PK_OK;
 }
@@ -843,16 +1047,15 @@ int pk_env_step(pk_handle *h, const int32_t *actions, int opp_policy, double *re
     ON_DEVICE(h);
     const size_t T = (size_t)h->T;
     HIPCHK(h, hipMemcpyAsync(h->d_actions, actions, T * 4, hipMemcpyHostToDevice, h->stream));
-    DISPATCH_N(h, k_env_step, table_grid(h), h->S, h->hot, (const int32_t *)h->d_actions, opp_policy, h->d_reward, h->d_done, h->d_handf, h->d_terr);
-    HIPCHK(h, hipGetLastError());
-    std::vector<uint8_t> te(T);
+    int rc = pk_env_step_d(h, h->d_actions, opp_policy, h->d_reward, h->d_done, h->d_handf, h->d_terr);
+    if (rc) return rc;
     HIPCHK(h, hipMemcpyAsync(reward, h->d_reward, T * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(done, h->d_done, T, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(hand, h->d_handf, T, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipMemcpyAsync(te.data(), h->d_terr, T, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->h_pinned, h->d_terr, T, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (terr) memcpy(terr, te.data(), T);
-    if (any_terr(te.data(), h->T)) return h->fail(PK_E_TABLE, "pk_env_step: per-table error(s), see terr");
+    if (terr) memcpy(terr, h->h_pinned, T);
+    if (any_terr(h->h_pinned, h->T)) return h->fail(PK_E_TABLE, "pk_env_step: per-table error(s), see terr");
     return PK_OK;
 }
 
@@ -861,6 +1064,7 @@ int pk_env_step(pk_handle *h, const int32_t *actions, int opp_policy, double *re
 int pk_prof_read(pk_handle *h, unsigned long long *out) {
     if (!h || !out) return PK_E_INVALID_ARG;
     ON_DEVICE(h);
+    FLUSH(h);
     HIPCHK(h, hipMemcpyAsync(out, h->S.prof, PF_SLOTS * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemsetAsync(h->S.prof, 0, PF_SLOTS * 8, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -871,6 +1075,7 @@ int pk_prof_read(pk_handle *h, unsigned long long *out) {
 int pk_sync(pk_handle *h) {
     if (!h) return PK_E_INVALID_ARG;
     ON_DEVICE(h);
+    FLUSH(h);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return PK_OK;
 }
@@ -886,29 +1091,59 @@ static int check_device(int device) {
     return PK_OK;
 }
 
-int pk_eval_hands(int device, const uint8_t *cards, const uint8_t *ncards, size_t m, uint8_t *rank, uint32_t *kick,
-                  uint8_t *nkick) {
-    if (!cards || !rank || !kick) { g_err = "pk_eval_hands: NULL buffer"; return PK_E_INVALID_ARG; }
+// Grow-only device scratch of the host-buffer judger calls, one per device: no hipMalloc / hipFree per call.
+static std::mutex g_scratch_mu;
+static struct { void *p; size_t cap; } g_scratch[PK_MAX_DEVICES];
+static void *scratch(int device, size_t bytes) {  // caller holds g_scratch_mu and has the device current
+    auto &s = g_scratch[device];
+    if (s.cap < bytes) {
+        if (s.p) (void)hipFree(s.p);
+        s.p = nullptr; s.cap = 0;
+        size_t want = bytes < (1u << 20) ? (1u << 20) : bytes + bytes / 2;
+        if (hipMalloc(&s.p, want) != hipSuccess) { s.p = nullptr; return nullptr; }
+        s.cap = want;
+    }
+    return s.p;
+}
+
+int pk_eval_hands_d(int device, const uint8_t *cards_d, const uint8_t *ncards_d, size_t m, uint8_t *rank_d, uint32_t *kick_d,
+                    uint8_t *nkick_d, void *stream) {
+    if (!cards_d || !rank_d || !kick_d) { g_err = "pk_eval_hands_d: NULL buffer"; return PK_E_INVALID_ARG; }
     int rc = check_device(device);
     if (rc) return rc;
     DeviceGuard guard(device);
     if (!guard.ok) { g_err = "hipSetDevice failed"; return PK_E_HIP; }
     if (m == 0) return PK_OK;
-    tmp_handle th, *h = &th;
-    uint8_t *d = nullptr;
+    hipLaunchKernelGGL(k_eval_hands, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, (hipStream_t)stream, cards_d, ncards_d, m, rank_d, kick_d, nkick_d);
+    if (hipGetLastError() != hipSuccess) { g_err = "pk_eval_hands_d: launch failed"; return PK_E_HIP; }
+    return PK_OK;
+}
+
+int pk_eval_hands(int device, const uint8_t *cards, const uint8_t *ncards, size_t m, uint8_t *rank, uint32_t *kick,
+                  uint8_t *nkick) {
+    if (!cards || !rank || !kick) { g_err = "pk_eval_hands: NULL buffer"; return PK_E_INVALID_ARG; }
+    int rc = check_device(device);
+    if (rc) return rc;
+    if (device >= PK_MAX_DEVICES) { g_err = "pk_eval_hands: device index beyond PK_MAX_DEVICES"; return PK_E_INVALID_ARG; }
+    DeviceGuard guard(device);
+    if (!guard.ok) { g_err = "hipSetDevice failed"; return PK_E_HIP; }
+    if (m == 0) return PK_OK;
+    tmp_handle th;
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
     size_t off_n = m * 7, off_r = off_n + m, off_nk = off_r + m, off_k = (off_nk + m + 3) & ~(size_t)3, total = off_k + m * 4;
-    HIPCHK(h, hipMalloc((void **)&d, total));
-    hipError_t e = hipMemcpy(d, cards, m * 7, hipMemcpyHostToDevice);
-    if (e == hipSuccess && ncards) e = hipMemcpy(d + off_n, ncards, m, hipMemcpyHostToDevice);
+    uint8_t *d = (uint8_t *)scratch(device, total);
+    if (!d) { g_err = "pk_eval_hands: out of device memory"; return PK_E_OOM; }
+    hipError_t e = hipMemcpyAsync(d, cards, m * 7, hipMemcpyHostToDevice, 0);
+    if (e == hipSuccess && ncards) e = hipMemcpyAsync(d + off_n, ncards, m, hipMemcpyHostToDevice, 0);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(k_eval_hands, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, 0, d, ncards ? d + off_n : nullptr, m,
                            d + off_r, (uint32_t *)(d + off_k), d + off_nk);
         e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipMemcpy(rank, d + off_r, m, hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemcpy(kick, d + off_k, m * 4, hipMemcpyDeviceToHost);
-    if (e == hipSuccess && nkick) e = hipMemcpy(nkick, d + off_nk, m, hipMemcpyDeviceToHost);
-    (void)hipFree(d);
+    if (e == hipSuccess) e = hipMemcpyAsync(rank, d + off_r, m, hipMemcpyDeviceToHost, 0);
+    if (e == hipSuccess) e = hipMemcpyAsync(kick, d + off_k, m * 4, hipMemcpyDeviceToHost, 0);
+    if (e == hipSuccess && nkick) e = hipMemcpyAsync(nkick, d + off_nk, m, hipMemcpyDeviceToHost, 0);
+    if (e == hipSuccess) e = hipStreamSynchronize(0);
     if (e != hipSuccess) return th.fail(PK_E_HIP, "pk_eval_hands", e);
     return PK_OK;
 }
@@ -917,35 +1152,43 @@ int pk_compare_rankings(int device, const uint8_t *rank, const uint32_t *kick, i
     if (!rank || !kick || !onehot || n < 1 || n > 32) { g_err = "pk_compare_rankings: bad argument (1 <= n <= 32)"; return PK_E_INVALID_ARG; }
     int rc = check_device(device);
     if (rc) return rc;
+    if (device >= PK_MAX_DEVICES) { g_err = "pk_compare_rankings: device index beyond PK_MAX_DEVICES"; return PK_E_INVALID_ARG; }
     DeviceGuard guard(device);
     if (!guard.ok) { g_err = "hipSetDevice failed"; return PK_E_HIP; }
     if (m == 0) return PK_OK;
-    tmp_handle th, *h = &th;
+    tmp_handle th;
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
     size_t cnt = m * (size_t)n;
-    uint8_t *d = nullptr;
     size_t off_r = cnt * 4, off_o = off_r + cnt, total = off_o + cnt;
-    HIPCHK(h, hipMalloc((void **)&d, total));
-    hipError_t e = hipMemcpy(d, kick, cnt * 4, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(d + off_r, rank, cnt, hipMemcpyHostToDevice);
+    uint8_t *d = (uint8_t *)scratch(device, total);
+    if (!d) { g_err = "pk_compare_rankings: out of device memory"; return PK_E_OOM; }
+    hipError_t e = hipMemcpyAsync(d, kick, cnt * 4, hipMemcpyHostToDevice, 0);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + off_r, rank, cnt, hipMemcpyHostToDevice, 0);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(k_compare, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, 0, d + off_r, (const uint32_t *)d, n, m, d + off_o);
         e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipMemcpy(onehot, d + off_o, cnt, hipMemcpyDeviceToHost);
-    (void)hipFree(d);
+    if (e == hipSuccess) e = hipMemcpyAsync(onehot, d + off_o, cnt, hipMemcpyDeviceToHost, 0);
+    if (e == hipSuccess) e = hipStreamSynchronize(0);
     if (e != hipSuccess) return th.fail(PK_E_HIP, "pk_compare_rankings", e);
     return PK_OK;
 }
 
 static int launch_eval7(const uint64_t *hands_d, size_t m, uint32_t *out_d, int distinct) {
     const unsigned grid = 256 * 16;  // 16 workgroups per CU, grid-stride over the rest
-    if (distinct) hipLaunchKernelGGL(k_eval7_stream<true>, dim3(grid), dim3(256), 0, 0, hands_d, m, out_d);
-    else hipLaunchKernelGGL(k_eval7_stream<false>, dim3(grid), dim3(256), 0, 0, hands_d, m, out_d);
+    const bool vec = (((uintptr_t)hands_d & 15) | ((uintptr_t)out_d & 7)) == 0;  // 16-byte loads / 8-byte stores need it
+    if (distinct) {
+        if (vec) hipLaunchKernelGGL((k_eval7_stream<true, true>), dim3(grid), dim3(256), 0, 0, hands_d, m, out_d);
+        else hipLaunchKernelGGL((k_eval7_stream<true, false>), dim3(grid), dim3(256), 0, 0, hands_d, m, out_d);
+    } else {
+        if (vec) hipLaunchKernelGGL((k_eval7_stream<false, true>), dim3(grid), dim3(256), 0, 0, hands_d, m, out_d);
+        else hipLaunchKernelGGL((k_eval7_stream<false, false>), dim3(grid), dim3(256), 0, 0, hands_d, m, out_d);
+    }
     return hipGetLastError() == hipSuccess ? PK_OK : PK_E_HIP;
 }
 
 int pk_eval7_d(int device, const uint64_t *hands_d, size_t m, uint32_t *out_d, int distinct) {
-    if (!hands_d || !out_d) { g_err = "pk_eval7_d: NULL buffer"; return PK_E_INVALID_ARG; }
+    if (!hands_d || !out_d || ((uintptr_t)hands_d & 7) || ((uintptr_t)out_d & 3)) { g_err = "pk_eval7_d: NULL or misaligned buffer"; return PK_E_INVALID_ARG; }
     int rc = check_device(device);
     if (rc) return rc;
     DeviceGuard guard(device);
@@ -996,19 +1239,20 @@ int pk_eval7_prefix(int device, int a, int b, int fast, uint32_t *out, size_t *c
     if (!out || a < 0 || b <= a || b > 51) { g_err = "pk_eval7_prefix: bad argument"; return PK_E_INVALID_ARG; }
     int rc = check_device(device);
     if (rc) return rc;
+    if (device >= PK_MAX_DEVICES) { g_err = "pk_eval7_prefix: device index beyond PK_MAX_DEVICES"; return PK_E_INVALID_ARG; }
     DeviceGuard guard(device);
     if (!guard.ok) { g_err = "hipSetDevice failed"; return PK_E_HIP; }
     int n = 51 - b;
     size_t count = n >= 5 ? (size_t)n * (n - 1) * (n - 2) * (n - 3) * (n - 4) / 120 : 0;
     if (count_out) *count_out = count;
     if (!count) return PK_OK;
-    tmp_handle th, *h = &th;
-    uint32_t *d = nullptr;
-    HIPCHK(h, hipMalloc((void **)&d, count * 4));
+    tmp_handle th;
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    uint32_t *d = (uint32_t *)scratch(device, count * 4);
+    if (!d) { g_err = "pk_eval7_prefix: out of device memory"; return PK_E_OOM; }
     hipLaunchKernelGGL(k_eval7_prefix, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, 0, a, b, fast, (uint32_t)count, d);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpy(out, d, count * 4, hipMemcpyDeviceToHost);
-    (void)hipFree(d);
     if (e != hipSuccess) return th.fail(PK_E_HIP, "pk_eval7_prefix", e);
     return PK_OK;
 }

@@ -18,7 +18,7 @@ namespace pk {
 enum : int { HR_SF = 1, HR_POKER = 2, HR_FULL = 3, HR_FLUSH = 4, HR_STRAIGHT = 5, HR_TRIS = 6, HR_TWO_PAIR = 7, HR_PAIR = 8, HR_HIGH = 9, HR_NONE = 10 };
 enum : int { MV_FOLD = 0, MV_CHECK = 1, MV_CALL = 2, MV_RAISE_ANY = 3, MV_ALL_IN = 6 };
 enum : int { PS_FOLDED = 0, PS_ACTIVE = 1, PS_CALLED = 2, PS_ALL_IN = 3, PS_BROKEN = 4 };
-constexpr uint32_t STREAM_DECK = 0x4445434Bu, STREAM_ACTION = 0x41435431u;
+constexpr uint32_t STREAM_DECK = 0x4445434Bu, STREAM_ACTION = 0x41435432u;  // 'DECK', 'ACT2' (RNG spec: DESIGN.md section 3)
 constexpr uint32_t NONE_V = (uint32_t)HR_NONE << 20;  // ranking value (rank<<20 | kickers) of judger's (NONE, [])
 
 // ---------------------------------------------------------------------------------------------- HBM layout
@@ -29,10 +29,13 @@ struct State {
     double *min_raise;                           // [T]      Game.minimum_raise_value (game.py:263)
     uint64_t *seat_states;                       // [T]      ACTIVE | CALLED<<16 | ALL_IN<<32 | BROKEN<<48 seat bitmasks (FOLDED = in none)
     uint32_t *cursors;                           // [T]      active | dealer<<4 | sb<<8 | bb<<12 | turn<<16 (game.py:251-258)
+                                                 //          | step-in-flight bits 20..30 (Table::store), 0 for an idle table
     int32_t *hand;                               // [T]      Game.hand
-    uint32_t *hand_serial, *step_serial;         // [T]      RNG-spec counters
+    uint64_t *hand_serial, *step_serial;         // [T]      RNG-spec counters (64-bit: a table's streams never repeat)
     uint32_t *cards;                             // [W][T]   4 Card.value bytes per word, deck[0:5+2N] (game.py:385-395)
     uint32_t *show;                              // [N][T]   last showdown: HandRanking<<20 | kickers value
+    uint32_t *owed;                              // [T]      Game.step()s requested by pk_rollout and not executed yet (deferred launches)
+    uint32_t *mid;                               // [T]      hands rolled so far by a step that is in flight across launches
     uint8_t *valid;                              // [T]      valid-action bitmask of the active player (game.py:339-383)
     uint8_t *terr;                               // [T]      PK_TERR_* of the last call
     unsigned long long *counters;                // [waves][PK_NUM_COUNTERS]: one slot per wavefront, no atomics (4 096
@@ -358,26 +361,34 @@ struct Lds {  // per workgroup (= one wavefront); ~10 KB at N = 10
     uint32_t res[64 * N];      // dest = lane*N + seat -> HandRanking<<20 | kickers
 };
 
-struct ActionRng {  // one Philox block serves four consecutive steps of a table (RNG spec)
-    uint32_t idx = 0xffffffffu, w[4];
-    __device__ __forceinline__ uint32_t word(const Hot &S, uint32_t table_id, uint32_t step_serial) {
-        if ((step_serial >> 2) != idx) {
-            idx = step_serial >> 2;
-            philox4x32_10(table_id, idx, STREAM_ACTION, 0u, S.key0, S.key1, w);
+struct ActionRng {  // one Philox block serves EIGHT consecutive steps of a table: 16-bit draws (RNG spec)
+    uint64_t idx = ~0ull;
+    uint32_t w[4];
+    __device__ __forceinline__ uint32_t draw16(const Hot &S, uint32_t table_id, uint64_t step_serial) {
+        const uint64_t q = step_serial >> 3;
+        if (q != idx) {
+            idx = q;
+            philox4x32_10(table_id, (uint32_t)q, STREAM_ACTION, (uint32_t)(q >> 32), S.key0, S.key1, w);
         }
-        uint32_t lo = (step_serial & 1) ? w[1] : w[0], hi = (step_serial & 1) ? w[3] : w[2];
-        return (step_serial & 2) ? hi : lo;
+        const uint32_t j = (uint32_t)step_serial & 7;
+        uint32_t lo = (j & 2) ? w[1] : w[0], hi = (j & 2) ? w[3] : w[2];
+        uint32_t x = (j & 4) ? hi : lo;
+        return (j & 1) ? (x >> 16) : (x & 0xffffu);
     }
 };
-
-// Synthetic agents (RandomAgent semantics of pokerl/agents/random.py:12-16 under the RNG spec).
-__device__ __forceinline__ int pick_action(const Hot &S, ActionRng &rng, uint32_t table_id, uint32_t step_serial, uint32_t mask, int policy) {
-    if (policy == PK_POLICY_ALLIN) return MV_ALL_IN;
-    uint32_t k = __umulhi(rng.word(S, table_id, step_serial), (uint32_t)__popc(mask));
+// k-th (0-based) valid action of the mask for a 16-bit draw r: k = (r * popcount(mask)) >> 16 (RNG spec)
+__device__ __forceinline__ int action_from_draw(uint32_t r16, uint32_t mask) {
+    uint32_t k = __umul24(r16, (uint32_t)__popc(mask)) >> 16;
     uint32_t m = mask;
 #pragma unroll
     for (uint32_t i = 0; i < 6; ++i) m = (i < k) ? (m & (m - 1)) : m;  // drop the k lowest set bits (k <= 6)
     return __ffs(m) - 1;
+}
+
+// Synthetic agents (RandomAgent semantics of pokerl/agents/random.py:12-16 under the RNG spec).
+__device__ __forceinline__ int pick_action(const Hot &S, ActionRng &rng, uint32_t table_id, uint64_t step_serial, uint32_t mask, int policy) {
+    if (policy == PK_POLICY_ALLIN) return MV_ALL_IN;
+    return action_from_draw(rng.draw16(S, table_id, step_serial), mask);
 }
 
 template <int N>
@@ -389,14 +400,14 @@ struct Table {
     double min_raise;
     uint32_t st_active, st_called, st_allin, st_broken;  // seat bitmasks; FOLDED = in none of them
     int active, dealer, sb, bb, turn, hand;
-    uint32_t hand_serial, step_serial;
+    uint64_t hand_serial, step_serial;
     uint32_t cards[W];
     // per-step machine state
     int lstate, current, hands_this_step;
     uint32_t flags, terr, stepped;  // stepped: 1 while a Game.step is in flight on this lane
     bool foldout;
     // counters since load
-    uint32_t evals, games, seen;
+    uint32_t evals, games, hands, seen;
     PK_PROF(Prof prof;)
 
     __device__ __forceinline__ void load(const State &S, int t) {
@@ -413,8 +424,11 @@ struct Table {
         hand = S.hand[t];
         hand_serial = S.hand_serial[t]; step_serial = S.step_serial[t];
         PK_FOR(w, W) cards[w] = S.cards[(size_t)w * S.T + t]; PK_END
-        idle();
-        evals = 0; games = 0; seen = 0;
+        // A step left in flight by a deferred rollout launch (all-zero bits = idle table; only k_rollout ever finds
+        // anything else: the host flushes deferred work before every other kernel).
+        current = (cur >> 20) & 0xf; lstate = (cur >> 24) & 3; foldout = (cur >> 26) & 1; stepped = (cur >> 27) & 1;
+        flags = (cur >> 28) & 7; hands_this_step = 0; terr = 0;
+        evals = 0; games = 0; hands = 0; seen = 0;
     }
     // A lane with no table (t >= T) still walks the wave-uniform control flow: give it inert, well-defined state.
     __device__ __forceinline__ void blank() {
@@ -423,7 +437,7 @@ struct Table {
         active = dealer = sb = bb = turn = hand = 0; hand_serial = step_serial = 0;
         PK_FOR(w, W) cards[w] = 0; PK_END
         idle();
-        evals = 0; games = 0; seen = 0;
+        evals = 0; games = 0; hands = 0; seen = 0;
     }
     __device__ __forceinline__ void idle() { lstate = LS_DONE; current = 0; hands_this_step = 0; flags = 0; terr = 0; stepped = 0; foldout = false; }
     __device__ __forceinline__ void store(const State &S, int t) const {
@@ -433,7 +447,9 @@ struct Table {
          PK_END
         S.min_raise[t] = min_raise;
         S.seat_states[t] = (uint64_t)st_active | ((uint64_t)st_called << 16) | ((uint64_t)st_allin << 32) | ((uint64_t)st_broken << 48);
-        S.cursors[t] = (uint32_t)active | ((uint32_t)dealer << 4) | ((uint32_t)sb << 8) | ((uint32_t)bb << 12) | ((uint32_t)turn << 16);
+        const uint32_t inflight = ((uint32_t)current << 20) | ((uint32_t)lstate << 24) | ((uint32_t)foldout << 26) | (stepped << 27) | (flags << 28);
+        S.cursors[t] = (uint32_t)active | ((uint32_t)dealer << 4) | ((uint32_t)sb << 8) | ((uint32_t)bb << 12) | ((uint32_t)turn << 16) |
+                       (lstate == LS_DONE ? 0u : inflight);
         S.hand[t] = hand;
         S.hand_serial[t] = hand_serial; S.step_serial[t] = step_serial;
         PK_FOR(w, W) S.cards[(size_t)w * S.T + t] = cards[w]; PK_END
@@ -479,7 +495,7 @@ struct Table {
         constexpr int NB = (K + 17) / 18;
         PK_FOR(b, NB)
             uint32_t w[4];
-            philox4x32_10(table_id, hand_serial, STREAM_DECK, (uint32_t)b, S.key0, S.key1, w);
+            philox4x32_10(table_id, (uint32_t)hand_serial, STREAM_DECK + (uint32_t)b, (uint32_t)(hand_serial >> 32), S.key0, S.key1, w);
             PK_FOR(h, 2)
                 uint32_t xlo = w[2 * h], xhi = w[2 * h + 1];
                 PK_FOR(j, 9)
@@ -728,6 +744,7 @@ struct Table {
                 terr |= PK_TERR_NO_WINNER; lstate = LS_DONE;
             } else {
                 uint32_t broke = 0;
+                hands += 1;                                                        // an end_hand() ran to its end
                 PK_FOR(p, N)
                     payoffs[p] = payoffs[p] - bets[p];                             // :531
                     broke |= (credits[p] <= 0.0) ? (1u << p) : 0;                  // :536
@@ -752,8 +769,7 @@ struct Table {
                 }
                 if (auto_reset && lstate == LS_DONE && (go || (terr & PK_TERR_HAND_CAP))) {
                     seen |= terr; terr = 0;
-                    flags |= PK_FLAG_GAME_OVER;
-                    games += 1;
+                    flags |= PK_FLAG_GAME_OVER;   // counted as a finished game by the caller (k_rollout's retire)
                     hand_serial += 1;      // the deck setup_hand() shuffled for the dead game is never looked at
                     reset_state(S, 0);
                 }

@@ -24,23 +24,35 @@ class VecPokerGameEnv:
         """game_env.py:20-29 on all tables (or where mask != 0); returns the observation rows (StateView fields)."""
         g = self.game
         m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        if m is not None and m.shape != (g.num_tables,):
+            raise ValueError('mask must have shape (num_tables,)')
         L.check(g._lib.pk_env_reset(g._h, L.ptr(m), self.opp_policy), g._h)
         return g.observations
 
-    def step(self, actions):
-        """game_env.py:31-53: returns (obs, reward f64[T], done bool[T], hand bool[T]) -- the reference's 4-tuple."""
+    def step(self, actions, strict=True):
+        """game_env.py:31-53: returns (obs, reward f64[T], done bool[T], hand bool[T]) -- the reference's 4-tuple.
+
+        strict=True mirrors the reference for the batch: seat 0's action is checked against the valid mask first and a
+        ValueError (game.py:649-651) is raised BEFORE any table is mutated.  strict=False steps the tables whose action
+        is valid, leaves the others untouched and returns per-table error bits as a 5th array."""
         g = self.game
         a = g._actions(actions)
         T = g.num_tables
+        if strict:
+            valid = g.get_valid_actions()[0]
+            ok = (a >= 0) & (a < valid.shape[1])
+            ok[ok] = valid[np.nonzero(ok)[0], a[ok]] != 0
+            if not ok.all():
+                t = int(np.argmin(ok))
+                raise ValueError('Player %d invalid move: `%d` (table %d)' % (int(g.active_player[t]), int(a[t]), t))
         reward = np.zeros(T, np.float64)
         done = np.zeros(T, np.uint8)
         hand = np.zeros(T, np.uint8)
         terr = np.zeros(T, np.uint8)
         rc = g._lib.pk_env_step(g._h, L.ptr(a), self.opp_policy, L.ptr(reward), L.ptr(done), L.ptr(hand), L.ptr(terr))
         L.check(rc, g._h, allow_table_errors=True)
-        if (terr & L.TERR_INVALID_ACTION).any():
-            t = int(np.argmax(terr & L.TERR_INVALID_ACTION))
-            raise ValueError('Player 0 invalid move (table %d); tables with a valid action were stepped' % t)
+        if not strict:
+            return g.observations, reward, done != 0, hand != 0, terr
         if terr.any():
             raise L.PokerlHipError('table error bits %s' % np.unique(terr))
         return g.observations, reward, done != 0, hand != 0

@@ -9,7 +9,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib as L
-from .enums import PlayerState, PokerMoves
+from .enums import PokerMoves
 
 DEFAULT_SEED = 0x706F6B65726C  # 'pokerl'
 
@@ -107,11 +107,20 @@ class VecGame:
             return out
         return out + (terr,)
 
-    def get_valid_actions(self):
-        """`Game.get_valid_actions()` (game.py:339-383) of each table's active player: (onehot f64 [T,7], list of
-        index arrays)."""
+    def _seat(self, player):
+        """None -> -1 (each table's active player); else a seat index valid for every table."""
+        if player is None:
+            return -1
+        p = int(player)
+        if not (0 <= p < self.num_players):
+            raise IndexError('player %d out of range' % p)   # the reference's credits[player] would raise the same way
+        return p
+
+    def get_valid_actions(self, player=None):
+        """`Game.get_valid_actions(player=None)` (game.py:339-383): (onehot f64 [T,7], generator of index arrays).
+        player=None: each table's active player; an int: that seat on every table (0 IS seat 0 here, game.py:363)."""
         out = np.zeros((self.num_tables, PokerMoves.NUM_MOVES), np.uint8)
-        L.check(self._lib.pk_get_valid_actions(self._h, L.ptr(out)), self._h)
+        L.check(self._lib.pk_get_valid_actions(self._h, self._seat(player), L.ptr(out)), self._h)
         onehot = out.astype(np.float64)
         return onehot, (np.nonzero(row)[0] for row in out)
 
@@ -139,7 +148,54 @@ class VecGame:
         return ms.value, dict(steps=int(c[0]), hands=int(c[1]), evals=int(c[2]), games=int(c[3]))
 
     def sync(self):
+        """Completes deferred rollout steps and waits for the handle's stream."""
         L.check(self._lib.pk_sync(self._h), self._h)
+
+    def flush(self):
+        L.check(self._lib.pk_flush(self._h), self._h)
+
+    @property
+    def owed(self):
+        """Diagnostic: steps each table still owes after the launches queued so far (deferred work is NOT completed)."""
+        out = np.zeros(self.num_tables, np.uint32)
+        L.check(self._lib.pk_get_owed(self._h, L.ptr(out)), self._h)
+        return out
+
+    def set_tuning(self, park=0, endk=0):
+        L.check(self._lib.pk_set_tuning(self._h, int(park), int(endk)), self._h)
+
+    # ------------------------------------------------------------------ streams (callers with their own HIP stream)
+    @property
+    def stream(self):
+        s = C.c_void_p()
+        L.check(self._lib.pk_get_stream(self._h, C.byref(s)), self._h)
+        return s.value
+
+    def set_stream(self, stream):
+        """Run on the caller's hipStream_t (int / c_void_p; None: back to the handle's own stream)."""
+        L.check(self._lib.pk_set_stream(self._h, C.c_void_p(stream) if isinstance(stream, int) else stream), self._h)
+
+    def wait_event(self, event):
+        L.check(self._lib.pk_wait_event(self._h, C.c_void_p(event) if isinstance(event, int) else event), self._h)
+
+    def record_event(self, event):
+        L.check(self._lib.pk_record_event(self._h, C.c_void_p(event) if isinstance(event, int) else event), self._h)
+
+    # ------------------------------------------------------------------ RNG-spec serials (checkpoint / resume)
+    def _serials(self):
+        hs = np.zeros(self.num_tables, np.uint64)
+        ss = np.zeros(self.num_tables, np.uint64)
+        L.check(self._lib.pk_get_serials(self._h, L.ptr(hs), L.ptr(ss)), self._h)
+        return hs, ss
+
+    hand_serial = property(lambda self: self._serials()[0])
+    step_serial = property(lambda self: self._serials()[1])
+
+    def set_serials(self, hand_serial=None, step_serial=None):
+        def arr(v):
+            return None if v is None else np.ascontiguousarray(np.broadcast_to(np.asarray(v, np.uint64), (self.num_tables,)))
+        hs, ss = arr(hand_serial), arr(step_serial)
+        L.check(self._lib.pk_set_serials(self._h, L.ptr(hs), L.ptr(ss)), self._h)
 
     # ------------------------------------------------------------------ state reads (Game attributes)
     def _f64(self, field):
@@ -162,14 +218,15 @@ class VecGame:
     small_blind_idx = property(lambda self: self._i32(L.I_SMALL_BLIND_IDX))
     big_blind_idx = property(lambda self: self._i32(L.I_BIG_BLIND_IDX))
     hand = property(lambda self: self._i32(L.I_HAND))
-    hand_serial = property(lambda self: self._i32(L.I_HAND_SERIAL).view(np.uint32))
-    step_serial = property(lambda self: self._i32(L.I_STEP_SERIAL).view(np.uint32))
 
-    @property
-    def minimum_raise_value(self):
+    def _table_f64(self, field):
         out = np.zeros(self.num_tables, np.float64)
-        L.check(self._lib.pk_get_min_raise(self._h, L.ptr(out)), self._h)
+        L.check(self._lib.pk_get_table_f64(self._h, field, L.ptr(out)), self._h)
         return out
+
+    minimum_raise_value = property(lambda self: self._table_f64(L.TF_MIN_RAISE))
+    pot = property(lambda self: self._table_f64(L.TF_POT))            # game.py:281-284, np.sum order kept on the device
+    high_bet = property(lambda self: self._table_f64(L.TF_HIGH_BET))  # game.py:287-290
 
     @property
     def player_states(self):
@@ -213,31 +270,28 @@ class VecGame:
         return rank, kick
 
     @property
-    def pot(self):
-        return np.array([np.sum(b) for b in self.bets])  # game.py:281-284 (np.sum per table keeps numpy's order)
-
-    @property
-    def high_bet(self):
-        return np.max(self.pending_bets, axis=1)  # game.py:287-290
-
-    @property
     def game_over(self):
-        return np.sum(self.player_states != PlayerState.BROKEN, axis=1) == 1  # game.py:317-320
+        out = np.zeros(self.num_tables, np.uint8)                     # game.py:317-320
+        L.check(self._lib.pk_get_game_over(self._h, L.ptr(out)), self._h)
+        return out != 0
 
-    @property
-    def observations(self):
-        """Dense `StateView(active player)` rows (game.py:117-131), f64 [T, PK_OBS_DIM(N)]; layout in pokerl_hip.h."""
+    def observations_of(self, player=None):
+        """Dense `StateView(game, player)` rows (game.py:117-131), f64 [T, PK_OBS_DIM(N)]; layout in pokerl_hip.h.
+        player=None or 0: each table's active player (`player or game.active_player`, game.py:122)."""
+        seat = -1 if not player else self._seat(player)
         out = np.zeros((self.num_tables, 17 + 3 * self.num_players), np.float64)
-        L.check(self._lib.pk_get_obs(self._h, L.ptr(out)), self._h)
+        L.check(self._lib.pk_get_obs(self._h, seat, L.ptr(out)), self._h)
         return out
 
-    def state_views(self):
+    observations = property(lambda self: self.observations_of(None))
+
+    def state_views(self, player=None):
         """One `StateView` (the reference's observation object, game.py:39-240) per table, for host-side policies."""
         from .state_view import StateView
-        return [StateView(row, self.num_players) for row in self.observations]
+        return [StateView(row, self.num_players) for row in self.observations_of(player)]
 
-    def state_view(self, table=0):
+    def state_view(self, table=0, player=None):
         from .state_view import StateView
-        return StateView(self.observations[table], self.num_players)
+        return StateView(self.observations_of(player)[table], self.num_players)
 
     active_state = observations

@@ -15,10 +15,19 @@ def _lib():
 
 
 class DeviceBuffer:
-    def __init__(self, nbytes):
+    """hipMalloc'ed bytes on `device` (the caller's current device is left as it was)."""
+
+    def __init__(self, nbytes, device=0):
         self.nbytes = int(nbytes)
+        self.device = int(device)
         self.ptr = C.c_void_p()
+        prev = C.c_int(-1)
+        _lib().hipGetDevice(C.byref(prev))
+        if _lib().hipSetDevice(self.device) != 0:
+            raise RuntimeError("hipSetDevice(%d) failed" % self.device)
         rc = _lib().hipMalloc(C.byref(self.ptr), C.c_size_t(self.nbytes))
+        if prev.value >= 0:
+            _lib().hipSetDevice(prev.value)
         if rc != 0:
             raise MemoryError("hipMalloc(%d) failed: %d" % (self.nbytes, rc))
 

@@ -34,6 +34,12 @@ def eval_hands(cards, ncards=None, device=0):
     return rank, kick, nk
 
 
+def eval_hands_d(cards_d, ncards_d, m, rank_d, kick_d, nkick_d=None, device=0, stream=None):
+    """pk_eval_hands_d: the same op on device-resident buffers (device pointers as ints / c_void_p), asynchronous on
+    `stream` -- e.g. the rank feature of examples/q_learning.py:29-33 for a learner that lives on the GPU."""
+    L.check(L.lib().pk_eval_hands_d(int(device), cards_d, ncards_d, int(m), rank_d, kick_d, nkick_d, stream))
+
+
 def eval_hand(hand, device=0):
     """judger.eval_hand(hand) -> (HandRanking, [kickers]) for one hand of 0..7 cards (judger.py:7-99)."""
     vals = [card_value(c) for c in hand]

@@ -92,10 +92,9 @@ G.eval_hand = _recording_eval
 class Table:
     """One reference Game plus the per-table serials of the RNG spec."""
 
-    def __init__(self, seed, table_id, n, game=None, **cfg):
+    def __init__(self, seed, table_id, n, game=None, serial_base=(0, 0), **cfg):
         self.seed, self.table_id, self.n = seed, table_id, n
-        self.hand_serial = 0
-        self.step_serial = 0
+        self.hand_serial, self.step_serial = serial_base  # RNG-spec serials (64-bit); non-zero = a resumed stream
         self.game = game if game is not None else G.Game(num_players=n, **cfg)
         self.canon = list(self.game.deck)
         _injector.by_deck[id(self.game.deck)] = self
@@ -145,8 +144,8 @@ class Table:
 _DT = dict(active=np.uint8, turn=np.uint8, dealer=np.uint8, sb=np.uint8, bb=np.uint8,
            hand=np.int32, states=np.uint8, credits=np.float64, bets=np.float64,
            pending=np.float64, payoffs=np.float64, min_raise=np.float64, cards=np.uint8,
-           srank=np.uint8, skick=np.uint32, valid=np.uint8, hand_serial=np.uint32,
-           step_serial=np.uint32)
+           srank=np.uint8, skick=np.uint32, valid=np.uint8, hand_serial=np.uint64,
+           step_serial=np.uint64)
 
 
 def _stack(snaps, prefix):
@@ -161,20 +160,45 @@ def snap_digest(snaps_by_table):
     return h.hexdigest()
 
 
+# --------------------------------------------------------------------------- StateView records (f4)
+def _hex(a):
+    return [float(x).hex() for x in np.asarray(a, np.float64).ravel()]
+
+
+def _state_tuple(sv):
+    """StateView.__getstate__() (game.py:208-223) as JSON-able data; floats as hex strings (bit-exact)."""
+    st = sv.__getstate__()
+    return dict(player=int(st[0]), valid_actions=_hex(st[1]), num_players=int(st[2]), turn=int(st[3]),
+                player_cards=[int(c.value) for c in st[4]], community_cards=[int(c.value) for c in st[5]],
+                credits=_hex(st[6]), bets=_hex(st[7]), pending_bets=_hex(st[8]), minimum_raise_value=float(st[9]).hex())
+
+
+def view_record(game):
+    """What the reference exposes about one table to ANY seat: active_state (game.py:323-332), StateView(game, p)
+    for every p (game.py:117-131; p = 0 means the active player, `player or game.active_player`), get_valid_actions(p)
+    (game.py:339-383; p = 0 IS seat 0 there), and the properties pot / high_bet / game_over (game.py:281-320)."""
+    n = game.num_players
+    return dict(active=_state_tuple(game.active_state),
+                per_player=[_state_tuple(G.Game.StateView(game, p)) for p in range(n)],
+                valid_for=[_hex(game.get_valid_actions(p)[0]) for p in range(n)],
+                pot=float(game.pot).hex(), high_bet=float(game.high_bet).hex(), game_over=bool(game.game_over))
+
+
 # --------------------------------------------------------------------------- Game trajectories
 def game_trajectory(n, policy, seed, tables, steps, table_id_base=0, cfg=None, full=True, digest_every=0,
-                    auto_reset=True, dealer=0):
+                    auto_reset=True, dealer=0, serial_base=(0, 0), views=None):
     """auto_reset=False: finished games are NOT reset (the lone survivor keeps being stepped, which the
     reference allows); a survivor's FOLD then trips `assert num_potential_winners > 0` (game.py:473):
     recorded as err=2 with the partially mutated state, after which that table is reset."""
     cfg = cfg or dict(start_credits=100, big_blind=2, small_blind=1)
-    ts = [Table(seed, table_id_base + i, n, **cfg) for i in range(tables)]
+    ts = [Table(seed, table_id_base + i, n, serial_base=serial_base, **cfg) for i in range(tables)]
     for t in ts:
         t.game.reset(dealer=dealer)          # only the FIRST reset takes the dealer; auto-resets use the default (0)
     init = [t.snapshot() for t in ts]
     out = {}
     meta = dict(kind="game", n=n, policy=policy, seed=seed, tables=tables, steps=steps,
-                table_id_base=table_id_base, cfg=cfg, auto_reset=auto_reset, dealer=dealer)
+                table_id_base=table_id_base, cfg=cfg, auto_reset=auto_reset, dealer=dealer,
+                serial_base=list(serial_base))
     actions = np.zeros((steps, tables), np.int8)
     flags = np.zeros((steps, tables), np.uint8)
     errs = np.zeros((steps, tables), np.uint8)
@@ -191,6 +215,8 @@ def game_trajectory(n, policy, seed, tables, steps, table_id_base=0, cfg=None, f
                 assert not auto_reset
                 errs[s, i] = 2
             row.append(t.snapshot())
+        if views is not None:
+            views.append([view_record(t.game) for t in ts])
         if full:
             post.append(row)
         if digest_every and (s + 1) % digest_every == 0:
@@ -405,6 +431,15 @@ GAME_SETS = {
     "game_n10_random": (10, R.POLICY_RANDOM, 99, 4, 150, 5, None),
 }
 # odd configurations found worth pinning by tests/golden/fuzz_oracle_vs_reference.py: (n, policy, seed, tables, steps, base, cfg, dealer)
+# resumed RNG streams: hand_serial crosses 2^32 and the action block index (step_serial >> 3) crosses 2^32 mid-run
+SERIAL_SETS = {
+    "game_n6_serial_hi": (6, R.POLICY_RANDOM, SEED, 6, 120, 70000, None, ((1 << 32) - 9, (1 << 35) - 37)),
+}
+# observation contract: StateView.__getstate__ tuples of the reference itself, every seat
+VIEW_SETS = {
+    "views_n6_random": (6, R.POLICY_RANDOM, SEED ^ 0x77, 4, 60, 0, None),
+    "views_n3_percredits": (3, R.POLICY_RANDOM, 7, 4, 60, 77, dict(start_credits=[30, 100, 5], big_blind=4, small_blind=2)),
+}
 ODD_SETS = {
     "game_n5_zero_blinds": (5, R.POLICY_RANDOM, 21, 6, 150, 9, dict(start_credits=10, big_blind=0, small_blind=0), 3),
     "game_n4_sb_gt_bb_fractional": (4, R.POLICY_RANDOM, 22, 6, 150, 0, dict(start_credits=[37.5, 3, 1000, 0.5], big_blind=0.25, small_blind=7.5), 1),
@@ -422,6 +457,7 @@ DIGEST_SETS = {
     "digest_n9_random": (9, R.POLICY_RANDOM, SEED, 32, 1500, 0, None),
     "digest_n9_allin": (9, R.POLICY_ALLIN, SEED, 32, 1000, 0, None),
     "digest_n6_shard1": (6, R.POLICY_RANDOM, SEED, 32, 1000, 65536, None),  # table_id_base of rank 1 at C4
+    "digest_n6_shard7": (6, R.POLICY_RANDOM, SEED, 32, 1000, 7 * 65536, None),  # ... of rank 7 (last shard of 524 288)
 }
 ENV_SETS = {
     "env_n4_random": (4, R.POLICY_RANDOM, R.POLICY_RANDOM, SEED, 8, 200, 0, None),
@@ -455,6 +491,22 @@ def main():
             out = game_trajectory(n, pol, seed, tables, steps, base, cfg, dealer=dealer)
             np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
             print(name, "resets:", len(out["reset_idx"]), "hands:", int(out["post_hand_serial"].max()))
+    for name, (n, pol, seed, tables, steps, base, cfg, sbase) in SERIAL_SETS.items():
+        if want(name):
+            out = game_trajectory(n, pol, seed, tables, steps, base, cfg, serial_base=sbase)
+            np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+            print(name, "resets:", len(out["reset_idx"]), "hand_serial max: %#x" % int(out["post_hand_serial"].max()))
+    for name, (n, pol, seed, tables, steps, base, cfg) in VIEW_SETS.items():
+        if want(name):
+            views = []
+            out = game_trajectory(n, pol, seed, tables, steps, base, cfg, full=False, views=views)
+            meta = json.loads(str(out["meta"]))
+            meta["actions"] = out["actions"].tolist()
+            meta["flags"] = out["flags"].tolist()
+            meta["views"] = views            # [step][table] -> view_record, taken right after the step (before auto-reset)
+            with open(os.path.join(HERE, name + ".json"), "w") as f:
+                json.dump(meta, f)
+            print(name, "view records:", len(views) * tables)
     for name, (n, pol, seed, tables, steps, base, cfg) in NORESET_SETS.items():
         if want(name):
             out = game_trajectory(n, pol, seed, tables, steps, base, cfg, auto_reset=False)

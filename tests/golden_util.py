@@ -61,6 +61,9 @@ def replay_game(make_backend, name, loaded=None):
     """name: fixture under tests/golden/; or loaded=(dict of arrays, meta) straight from the generator."""
     z, meta = loaded if loaded is not None else load_npz(name)
     b = make_backend(meta)
+    sbase = meta.get("serial_base", [0, 0])
+    if any(sbase):
+        b.set_serials(sbase[0], sbase[1])   # a resumed RNG stream (64-bit serials)
     b.reset(dealer=meta.get("dealer", 0))
     assert_snap(b.snapshot(), gold_snap(z, "init_"), name + " init")
     ridx = z["reset_idx"]
@@ -150,6 +153,9 @@ def replay_env(make_backend, name):
 
 GAME_SETS = ["game_n2_random", "game_n6_random", "game_n9_random", "game_n6_allin", "game_n9_allin",
              "game_n4_example_cfg", "game_n3_percredits", "game_n10_random", "game_n2_noreset", "game_n3_noreset",
-             "game_n5_zero_blinds", "game_n4_sb_gt_bb_fractional", "game_n7_blinds_gt_stacks", "game_n8_mixed_allin"]
-DIGEST_SETS = ["digest_n2_random", "digest_n6_random", "digest_n9_random", "digest_n9_allin", "digest_n6_shard1"]
+             "game_n5_zero_blinds", "game_n4_sb_gt_bb_fractional", "game_n7_blinds_gt_stacks", "game_n8_mixed_allin",
+             "game_n6_serial_hi"]
+DIGEST_SETS = ["digest_n2_random", "digest_n6_random", "digest_n9_random", "digest_n9_allin", "digest_n6_shard1",
+               "digest_n6_shard7"]
+VIEW_SETS = ["views_n6_random", "views_n3_percredits"]
 ENV_SETS = ["env_n4_random", "env_n6_random", "env_n6_vs_allin", "env_n2_random"]

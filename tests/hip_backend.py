@@ -19,6 +19,9 @@ class HipBackend:
         return cls(meta["tables"], meta["n"], cfg["start_credits"], cfg["big_blind"], cfg["small_blind"],
                    seed=meta["seed"], table_id_base=meta["table_id_base"])
 
+    def set_serials(self, hand_serial, step_serial):
+        self.g.set_serials(hand_serial, step_serial)
+
     def reset(self, mask=None, dealer=0):
         self.g.reset(mask=mask, dealer=dealer)
 

@@ -164,6 +164,82 @@ def test_fused_rollout_vs_oracle(HB, O, T, N, policy, K):
     assert_same(h.snapshot(), h2.snapshot(), "fused vs unfused")
 
 
+def test_config3_all_eight_shards(HB, O):
+    """BASELINE configs[3] (524 288 tables x 6 seats over 8 GPUs) on one GPU: each rank's full 65 536-table shard
+    (table_id_base = r * 65 536) against the oracle, then the whole 524 288-table batch in ONE handle: its counters are
+    the sum of the shards' and its state is their concatenation (placement invariance of the global table ids)."""
+    T, N, K = 65536, 6, 32
+    total = np.zeros(4, np.uint64)
+    digests = []
+    for r in range(8):
+        o = O.OracleGame(T, N, table_id_base=r * T)
+        h = HB(T, N, table_id_base=r * T)
+        o.reset(); h.reset()
+        co, eo = o.rollout(K, 0, True)
+        ch = h.rollout(K, 0, True)
+        assert eo == 0 and co.tolist() == ch.tolist(), "shard %d counters" % r
+        snap = h.snapshot()
+        assert_same(o.snapshot(), snap, "shard %d" % r)
+        total += ch
+        digests.append({k: np.ascontiguousarray(snap[k]).copy() for k in ("credits", "payoffs", "cards", "states", "step_serial", "hand_serial")})
+        h.g.close()
+    whole = HB(8 * T, N)
+    whole.reset()
+    cw = whole.rollout(K, 0, True)
+    assert cw.tolist() == total.tolist() and cw[0] == 8 * T * K
+    g = whole.g
+    for k, got in (("credits", g.credits), ("payoffs", g.payoffs), ("cards", g.deck), ("states", g.player_states),
+                   ("step_serial", g.step_serial), ("hand_serial", g.hand_serial)):
+        assert GU.bits_equal(np.concatenate([d[k] for d in digests]), got), k
+    whole.g.close()
+
+
+def test_deferred_launches_are_invisible(HB, O):
+    """Asynchronous fused rollouts may defer their stragglers to later launches (State::owed, steps in flight across
+    launches).  Whatever the split and the tuning, an observer sees exactly the requested steps: many short deferred
+    launches == one complete launch == the oracle, at BASELINE's headline size and on a ragged batch."""
+    for T, N, policy, auto in [(65536, 6, 0, True), (1000, 9, 1, True), (3000, 3, 0, True), (700, 2, 0, False)]:
+        for endk, park, plan in [(64, 40, [20] * 12), (48, 40, [1, 7, 32, 200]), (33, 20, [60] * 4), (1, 40, [240]), (64, 64, [3] * 80)]:
+            o = O.OracleGame(T, N, seed=5)
+            o.reset()
+            co = np.zeros(4, np.uint64)
+            # with auto-reset the split is invisible; without it a table that reports an error stops for the rest of
+            # ITS call only, so the oracle makes the same calls
+            for k in ([240] if auto else plan):
+                co += o.rollout(k, policy, auto)[0]
+            h = HB(T, N, seed=5)
+            h.g.set_tuning(park, endk)
+            h.reset()
+            for k in plan:
+                h.g.rollout(k, policy, auto, True, counters=False)      # asynchronous, may defer
+            c = h.rollout(0, policy, auto)                              # completes everything, fetches the counters
+            assert c.tolist() == co.tolist(), (T, N, endk, park)
+            snap = h.snapshot()
+            assert_same(o.snapshot(), snap, "T=%d N=%d endk=%d park=%d" % (T, N, endk, park))
+            if auto:
+                assert (snap["step_serial"] == 240).all()
+            h.g.close()
+    # deferred work is completed by ANY observer, not only by counters: a getter right after asynchronous launches
+    h = HB(4096, 6); h.reset()
+    o = O.OracleGame(4096, 6); o.reset()
+    for _ in range(10):
+        h.g.rollout(17, 0, True, True, counters=False)
+    o.rollout(170, 0, True)
+    assert GU.bits_equal(o.f64(0), h.g.credits)        # first call after the launches is a getter
+    h.g.rollout(5, 0, True, True, counters=False)
+    o.rollout(5, 0, True)
+    acts = o.pick_actions(0)
+    assert np.array_equal(acts, h.pick_actions(0))     # ... or pick / step
+    fo, eo = o.step(acts); fh, eh = h.step(acts)
+    assert np.array_equal(fo, fh) and np.array_equal(eo, eh)
+    # a change of agents flushes first: owed steps keep the policy they were requested with
+    o2 = O.OracleGame(4096, 6); h2 = HB(4096, 6)
+    o2.reset(); h2.reset()
+    h2.g.rollout(30, 0, True, True, counters=False); h2.g.rollout(30, 1, True, True, counters=False)
+    o2.rollout(30, 0, True); o2.rollout(30, 1, True)
+    assert_same(o2.snapshot(), h2.snapshot(), "policy switch between deferred launches")
+
+
 def test_no_autoreset_and_assert_path(HB, O):
     """Without auto-reset the lone survivor keeps acting; its FOLD trips game.py:473 -> PK_TERR_NO_WINNER."""
     T, N = 512, 2
@@ -405,8 +481,8 @@ def test_device_resident_env_loop(HB, O):
     L.check(lib.pk_env_reset_d(g._h, None, 0), g._h)
     o.env_reset(None, 0)
     for s in range(60):
-        L.check(lib.pk_get_obs_d(g._h, d_obs), g._h)
-        L.check(lib.pk_get_valid_actions_d(g._h, d_valid), g._h)
+        L.check(lib.pk_get_obs_d(g._h, -1, d_obs), g._h)
+        L.check(lib.pk_get_valid_actions_d(g._h, -1, d_valid), g._h)
         g.sync()
         obs = d2h(d_obs, np.zeros((T, D), np.float64))
         valid = d2h(d_valid, np.zeros((T, 7), np.uint8))
@@ -454,7 +530,7 @@ def test_launch_splitting_and_determinism(HB):
         h.reset()
     ca = a.rollout(600, 0)
     cb = b.rollout(1, 0) + b.rollout(299, 0) + b.rollout(300, 0)
-    cc = c.rollout(600, 0, fused=False) if False else c.rollout(37, 0) + c.rollout(563, 0)
+    cc = c.rollout(37, 0) + c.rollout(563, 0)
     assert ca.tolist() == cb.tolist() == cc.tolist()
     sa, sb, sc = a.snapshot(), b.snapshot(), c.snapshot()
     for k in GU.SNAP_FIELDS:
@@ -463,7 +539,6 @@ def test_launch_splitting_and_determinism(HB):
     # a different seed gives different decks (the streams really are keyed by the seed)
     d = HB(T, N, seed=12345)
     d.reset()
-    assert not np.array_equal(d.snapshot()["cards"], HB(T, N).snapshot()["cards"]) or True
     assert not np.array_equal(d.snapshot()["cards"][:64], sa["cards"][:64])
 
 

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     L = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(L, name), name
-    assert _lib.lib().pk_abi_version() == 1
+    assert _lib.lib().pk_abi_version() == _lib.ABI_VERSION == 2
 
 
 def test_no_device_fails_loudly():

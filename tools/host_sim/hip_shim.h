@@ -17,6 +17,7 @@ static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x
 static inline int __ffs(unsigned x) { return __builtin_ffs((int)x); }
 static inline int __clz(int x) { return x ? __builtin_clz((unsigned)x) : 32; }  // device: v_ffbh_u32 -> 32 (as -1 -> clamped) for 0
 static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
+static inline unsigned __umul24(unsigned a, unsigned b) { return (a & 0xffffffu) * (b & 0xffffffu); }
 static inline unsigned long long __ballot(int p) { return p ? 1ull : 0ull; }
 static inline int __any(int p) { return p; }
 static inline void __syncthreads() {}

@@ -21,14 +21,16 @@ static int run(int T, int K, int policy, uint64_t seed, Cfg cfg = default_cfg(),
     const int KK = 5 + 2 * N, W = (KK + 3) / 4;
     std::vector<double> cr(N * T), be(N * T), pe(N * T), pa(N * T), mr(T);
     std::vector<uint64_t> ss(T, (1u << N) - 1);
-    std::vector<uint32_t> cur(T), hs(T), st(T), cards(W * T), show(N * T, NONE_V);
+    std::vector<uint32_t> cur(T), cards(W * T), show(N * T, NONE_V);
+    std::vector<uint64_t> hs(T), st(T);
     std::vector<int32_t> hand(T);
     std::vector<uint8_t> valid(T), terr(T);
+    std::vector<uint32_t> owed(T), mid(T);
     unsigned long long counters[4] = {0}, prof[16] = {0};
     State S{};
     S.credits = cr.data(); S.bets = be.data(); S.pending = pe.data(); S.payoffs = pa.data(); S.min_raise = mr.data();
     S.seat_states = ss.data(); S.cursors = cur.data(); S.hand = hand.data(); S.hand_serial = hs.data(); S.step_serial = st.data();
-    S.cards = cards.data(); S.show = show.data(); S.valid = valid.data(); S.terr = terr.data(); S.counters = counters; S.prof = prof;
+    S.owed = owed.data(); S.mid = mid.data(); S.cards = cards.data(); S.show = show.data(); S.valid = valid.data(); S.terr = terr.data(); S.counters = counters; S.prof = prof;
     for (int p = 0; p < N; ++p) S.start_credits[p] = cfg.start[p];
     S.big_blind = cfg.bb; S.small_blind = cfg.sb; S.key0 = (uint32_t)seed; S.key1 = (uint32_t)(seed >> 32); S.table_id_base = cfg.base; S.T = T;
     double *sc = cfg.start;

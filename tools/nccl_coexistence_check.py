@@ -26,7 +26,7 @@ assert x.item() == 65536 * 256 and t.sum().item() == 4
 # a torch tensor's memory handed to the device-pointer entry points
 obs = torch.empty((65536, 17 + 18), dtype=torch.float64, device="cuda")
 from pokerl_amd import _lib as L
-L.check(L.lib().pk_get_obs_d(g._h, obs.data_ptr()), g._h)
+L.check(L.lib().pk_get_obs_d(g._h, -1, obs.data_ptr()), g._h)
 g.sync()
 assert torch.equal(obs.cpu(), torch.from_numpy(g.observations))
 dist.destroy_process_group()
