@@ -9,7 +9,8 @@ LIB = os.path.join(HERE, "libpokerl_hip.so")
 SOURCES = ["pk_api.hip"]
 HEADERS = [os.path.join(CSRC, "pk_device.hpp"), os.path.join(os.path.dirname(HERE), "include", "pokerl_hip.h")]
 # -ffp-contract=off: numpy never fuses multiply-add, so neither may we (bit-exact f64 money).
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared",
+# -fno-honor-nans: money is never NaN, so `x > m ? x : m` may become v_max_f64 (-4 % VALU); signed zeros stay honoured.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-ffp-contract=off", "-fno-fast-math", "-fno-honor-nans", "-fPIC", "-shared",
          "-fgpu-rdc=0" if False else "-Wall", "-Wno-unused-function"]
 
 

@@ -62,8 +62,24 @@ __global__ void __launch_bounds__(PK_TABLE_BLOCK) k_reset(State S, Hot H, const 
     S.terr[t] = 0;
 }
 
+// The table Game.reset(dealer = 0) produces before its deal, for this handle's configuration (see pk::Fresh).
 template <int N>
-__global__ void __launch_bounds__(PK_TABLE_BLOCK) k_step(State S, Hot H, const int32_t *actions, uint8_t *flags, uint8_t *terr) {  // Game.step, game.py:621-700
+__global__ void k_make_fresh(Hot H, Fresh *out) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    Table<N> tb;
+    tb.blank();
+    tb.reset_state(H, 0);
+    Fresh f{};
+    PK_FOR(p, N) f.credits[p] = tb.credits[p]; f.pending[p] = tb.pending[p]; PK_END
+    f.min_raise = tb.min_raise;
+    f.st_active = tb.st_active; f.st_called = tb.st_called; f.st_allin = tb.st_allin; f.st_broken = tb.st_broken;
+    f.active = tb.active; f.dealer = tb.dealer; f.sb = tb.sb; f.bb = tb.bb;
+    *out = f;
+}
+
+template <int N>
+__global__ void __launch_bounds__(PK_TABLE_BLOCK) k_step(const State *__restrict__ Sp, Hot H, const int32_t *actions, uint8_t *flags, uint8_t *terr) {  // Game.step, game.py:621-700
+    const State &S = *Sp;
     __shared__ Lds<N> lds;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = t < S.T;
@@ -74,9 +90,16 @@ __global__ void __launch_bounds__(PK_TABLE_BLOCK) k_step(State S, Hot H, const i
     uint32_t mask = tb.valid_mask(high_bet);                                       // :648
     const int action = live ? actions[t] : -1;
     const bool ok = live && action >= 0 && action < PK_NUM_MOVES && ((mask >> action) & 1);
-    if (ok) tb.begin_step(H, action, high_bet);
-    tb.run(H, t, table_id, lds, false);
+    bool todo = ok;
+    for (;;) {  // same flat shape as k_rollout / k_env_step: one instantiation of cursor and end_block
+        if (todo) { tb.begin_step(H, action, high_bet); todo = false; }
+        tb.cursor();
+        if (!__any(tb.lstate == LS_END)) break;
+        tb.end_block(H, t, table_id, lds, false);
+    }
+    tb.finish_step();
     if (!live) return;
+    tb.store_show(S.show, S.T, t, lds);
     if (!ok) {                                                                     // :649-651: no mutation
         flags[t] = 0;
         S.terr[t] = PK_TERR_INVALID_ACTION;
@@ -120,10 +143,11 @@ __global__ void __launch_bounds__(PK_TABLE_BLOCK) k_rollout(const State *__restr
     const uint32_t table_id = H.table_id_base + (uint32_t)t;
     Table<N> tb;
     uint32_t owed = 0;
+    Table<N>::stage_fresh(lds, H.fresh);
     if (live) { tb.load(S, t); tb.hands_this_step = (int)S.mid[t]; owed = S.owed[t] + (uint32_t)K; } else tb.blank();
     uint32_t steps = 0;
     bool alive = live;
-    ActionRng rng;
+    ActionRing ring;
     double high_bet;
     // lanes that can work at all in this launch; the launch ends once fewer than `quit` of them still have work
     const int cap = __popcll(__ballot(live && (owed > 0 || tb.lstate == LS_END)));
@@ -138,9 +162,13 @@ __global__ void __launch_bounds__(PK_TABLE_BLOCK) k_rollout(const State *__restr
         }
     };
     for (;;) {
-        if (alive && tb.lstate == LS_DONE && owed > 0) {
+        const bool go = alive && tb.lstate == LS_DONE && owed > 0;
+        uint32_t word = 0;
+        if (policy == PK_POLICY_RANDOM) word = ring.draw16(lds, H, table_id, tb.step_serial, go);   // wave-uniform
+        if (go) {
             uint32_t mask = tb.valid_mask(high_bet);
-            tb.begin_step(H, pick_action(H, rng, table_id, tb.step_serial, mask, policy), high_bet);
+            tb.begin_step(H, policy == PK_POLICY_ALLIN ? (int)MV_ALL_IN
+                                                       : action_from_draw(ActionRing::half_of(word, tb.step_serial), mask), high_bet);
         }
         PK_PROF(tb.prof.lap(PF_ACTION);)
         tb.cursor();
@@ -157,6 +185,7 @@ __global__ void __launch_bounds__(PK_TABLE_BLOCK) k_rollout(const State *__restr
     }
     if (live) {
         tb.store(S, t);
+        tb.store_show(S.show, S.T, t, lds);
         S.owed[t] = owed; S.mid[t] = (uint32_t)tb.hands_this_step;
         S.valid[t] = (uint8_t)tb.valid_mask(high_bet);
         S.terr[t] = (uint8_t)((clear_terr ? 0 : S.terr[t]) | tb.terr | tb.seen);
@@ -165,43 +194,66 @@ __global__ void __launch_bounds__(PK_TABLE_BLOCK) k_rollout(const State *__restr
     PK_PROF(tb.prof.flush(S.prof);)
 }
 
-// PokerGameEnv.reset, envs/game_env.py:20-29
+// PokerGameEnv.reset / .step (envs/game_env.py:20-29, :31-53) share k_rollout's shape: ONE flat loop in which every
+// lane owns a small phase machine, begins its next Game.step() as soon as the previous one has returned, and the wave
+// runs end_block (end_hand + setup_hand + deal) once for all lanes parked at it.  The step machine is instantiated once
+// per kernel (three inlined copies of run() cost k_env_step 256 VGPRs + AGPR spills), table bases come by pointer.
+
+// PokerGameEnv.reset: Game.reset() (:23), then opponents play until seat 0 is to act (:24-26); a game that ends before
+// seat 0 ever acts is reset again (:27).
 template <int N>
-__global__ void __launch_bounds__(PK_TABLE_BLOCK) k_env_reset(State S, Hot H, const uint8_t *mask, int opp_policy) {
+__global__ void __launch_bounds__(PK_TABLE_BLOCK) k_env_reset(const State *__restrict__ Sp, Hot H, const uint8_t *mask, int opp_policy, int park) {
+    const State &S = *Sp;
     __shared__ Lds<N> lds;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = t < S.T && (!mask || mask[t < S.T ? t : 0]);
     const uint32_t table_id = H.table_id_base + (uint32_t)t;
     Table<N> tb;
-    if (live) { tb.load(S, t); tb.reset_state(H, 0); tb.deal(H, table_id); } else tb.blank();   // :23
+    if (live) tb.load(S, t); else tb.blank();
     ActionRng rng;
-    double high_bet;
-    uint32_t vm = tb.valid_mask(high_bet);
-    bool more = live && tb.active != 0;                                            // :24
+    double high_bet = 0.0;
+    bool more = live, due_reset = live;
     int budget = PK_ENV_STEP_CAP;  // every wave-uniform loop in this file has an exit all lanes reach
-    while (__any(more)) {
-        if (more) tb.begin_step(H, pick_action(H, rng, table_id, tb.step_serial, vm, opp_policy), high_bet);  // :25-26
-        tb.run(H, t, table_id, lds, false);
-        if (more) {
+    auto retire = [&]() {          // an opponent's Game.step() has returned
+        if (tb.stepped && tb.lstate == LS_DONE) {
+            tb.finish_step();
             if (--budget < 0) tb.terr |= PK_TERR_ENV_CAP;
             if (tb.terr) more = false;
-            else {
-                if (tb.flags & PK_FLAG_GAME_OVER) { tb.reset_state(H, 0); tb.deal(H, table_id); }  // :27
-                more = tb.active != 0;
+            else due_reset = (tb.flags & PK_FLAG_GAME_OVER) != 0;                  // :27
+        }
+    };
+    for (;;) {
+        if (more && tb.lstate == LS_DONE) {                                        // no step in flight on this lane
+            if (due_reset) { tb.reset_state(H, 0); tb.deal(H, table_id); due_reset = false; }   // :23 / :27
+            more = tb.active != 0;                                                 // :24
+            if (more) {
+                uint32_t vm = tb.valid_mask(high_bet);
+                tb.begin_step(H, pick_action(H, rng, table_id, tb.step_serial, vm, opp_policy), high_bet);  // :25-26
             }
         }
-        vm = tb.valid_mask(high_bet);
+        tb.cursor();
+        retire();
+        const int parked = __popcll(__ballot(tb.lstate == LS_END));
+        const int runnable = __popcll(__ballot(more && tb.lstate == LS_DONE));
+        if (parked == 0 && runnable == 0) break;
+        if (parked >= park || runnable == 0) {
+            tb.end_block(H, t, table_id, lds, false);
+            retire();
+        }
     }
     if (live) {
         tb.store(S, t);
-        S.valid[t] = (uint8_t)vm;
+        tb.store_show(S.show, S.T, t, lds);
+        S.valid[t] = (uint8_t)tb.valid_mask(high_bet);
         S.terr[t] = (uint8_t)tb.terr;
     }
 }
 
-// PokerGameEnv.step, envs/game_env.py:31-53
+// PokerGameEnv.step: seat 0's own step (:35), the opponents until the hand ends or seat 0 is to act (:41-44), the
+// opponents until seat 0 is to act or the game is over (:49-52) -- three phases of one lane-level machine.
 template <int N>
-__global__ void __launch_bounds__(PK_TABLE_BLOCK) k_env_step(State S, Hot H, const int32_t *actions, int opp_policy, double *reward, uint8_t *done_out, uint8_t *hand_out, uint8_t *terr) {
+__global__ void __launch_bounds__(PK_TABLE_BLOCK) k_env_step(const State *__restrict__ Sp, Hot H, const int32_t *actions, int opp_policy, double *reward, uint8_t *done_out, uint8_t *hand_out, uint8_t *terr, int park) {
+    const State &S = *Sp;
     __shared__ Lds<N> lds;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = t < S.T;
@@ -210,42 +262,55 @@ __global__ void __launch_bounds__(PK_TABLE_BLOCK) k_env_step(State S, Hot H, con
     if (live) tb.load(S, t); else tb.blank();
     ActionRng rng;
     double high_bet;
-    uint32_t vm = tb.valid_mask(high_bet);
+    const uint32_t vm0 = tb.valid_mask(high_bet);
     const int action = live ? actions[t] : -1;
-    const bool ok = live && action >= 0 && action < PK_NUM_MOVES && ((vm >> action) & 1);
+    const bool ok = live && action >= 0 && action < PK_NUM_MOVES && ((vm0 >> action) & 1);   // game.py:648-651
+    enum { PH_SEAT0 = 0, PH_HAND = 1, PH_TURN = 2, PH_FIN = 3 };
+    int phase = ok ? PH_SEAT0 : PH_FIN;
     double rew = 0.0;                                                              // :34
-    if (ok) tb.begin_step(H, action, high_bet);                                    // :35
-    tb.run(H, t, table_id, lds, false);
-    bool done = tb.flags & PK_FLAG_GAME_OVER, hand = tb.flags & PK_FLAG_HAND_OVER;
-    bool fin = !ok || tb.terr != 0;
-    if (!fin && (done || (tb.st_broken & 1))) { rew = tb.payoffs[0]; done = true; hand = true; fin = true; }  // :37-39
-    vm = tb.valid_mask(high_bet);
-    bool more = !fin && !hand && tb.active != 0;                                   // :41
+    bool done = false, hand = false;
     int budget = PK_ENV_STEP_CAP;
-    while (__any(more)) {
-        if (more) tb.begin_step(H, pick_action(H, rng, table_id, tb.step_serial, vm, opp_policy), high_bet);  // :43-44
-        tb.run(H, t, table_id, lds, false);
-        if (more) {
-            if (--budget < 0) tb.terr |= PK_TERR_ENV_CAP;
-            if (tb.terr) { fin = true; more = false; }
-            else {
-                done = tb.flags & PK_FLAG_GAME_OVER; hand = tb.flags & PK_FLAG_HAND_OVER;
-                more = !hand && tb.active != 0;
+    auto retire = [&]() {  // a Game.step() of this lane has returned: the reference's control flow between two steps
+        if (tb.stepped && tb.lstate == LS_DONE) {
+            tb.finish_step();
+            if (phase != PH_SEAT0 && --budget < 0) tb.terr |= PK_TERR_ENV_CAP;
+            if (tb.terr) { phase = PH_FIN; return; }
+            const bool over = (tb.flags & PK_FLAG_GAME_OVER) != 0, hand_now = (tb.flags & PK_FLAG_HAND_OVER) != 0;
+            const bool seat0 = tb.active == 0;
+            bool leave_hand_stretch = false;                                       // :41's loop is over (or never entered)
+            if (phase == PH_SEAT0) {
+                done = over; hand = hand_now;
+                if (done || (tb.st_broken & 1)) { rew = tb.payoffs[0]; done = true; hand = true; phase = PH_FIN; }  // :37-39
+                else if (!hand && !seat0) phase = PH_HAND;                         // :41
+                else leave_hand_stretch = true;
+            } else if (phase == PH_HAND) {
+                done = over; hand = hand_now;                                      // :44
+                leave_hand_stretch = hand || seat0;
+            } else {                                                               // PH_TURN: only `done` is re-read (:52)
+                done = over;
+                if (done || seat0) phase = PH_FIN;
+            }
+            if (leave_hand_stretch) {
+                if (hand) rew = tb.payoffs[0];                                     // :47
+                phase = (!done && !seat0) ? PH_TURN : PH_FIN;                      // :49
             }
         }
-        vm = tb.valid_mask(high_bet);
-    }
-    if (!fin && hand) rew = tb.payoffs[0];                                         // :47
-    more = !fin && !done && tb.active != 0;                                        // :49
-    while (__any(more)) {
-        if (more) tb.begin_step(H, pick_action(H, rng, table_id, tb.step_serial, vm, opp_policy), high_bet);  // :51-52
-        tb.run(H, t, table_id, lds, false);
-        if (more) {
-            if (--budget < 0) tb.terr |= PK_TERR_ENV_CAP;
-            if (tb.terr) { fin = true; more = false; }
-            else { done = tb.flags & PK_FLAG_GAME_OVER; more = !done && tb.active != 0; }
+    };
+    for (;;) {
+        if (phase != PH_FIN && tb.lstate == LS_DONE) {                             // begin this lane's next Game.step()
+            const uint32_t vm = tb.valid_mask(high_bet);
+            const int a = phase == PH_SEAT0 ? action : pick_action(H, rng, table_id, tb.step_serial, vm, opp_policy);
+            tb.begin_step(H, a, high_bet);                                         // :35 / :43-44 / :51-52
         }
-        vm = tb.valid_mask(high_bet);
+        tb.cursor();
+        retire();
+        const int parked = __popcll(__ballot(tb.lstate == LS_END));
+        const int runnable = __popcll(__ballot(phase != PH_FIN && tb.lstate == LS_DONE));
+        if (parked == 0 && runnable == 0) break;
+        if (parked >= park || runnable == 0) {
+            tb.end_block(H, t, table_id, lds, false);
+            retire();
+        }
     }
     if (!live) return;
     if (!ok) {
@@ -254,8 +319,9 @@ __global__ void __launch_bounds__(PK_TABLE_BLOCK) k_env_step(State S, Hot H, con
         return;
     }
     tb.store(S, t);
+    tb.store_show(S.show, S.T, t, lds);
     reward[t] = rew; done_out[t] = done; hand_out[t] = hand;                       // :53
-    S.valid[t] = (uint8_t)vm;
+    S.valid[t] = (uint8_t)tb.valid_mask(high_bet);
     S.terr[t] = (uint8_t)tb.terr; terr[t] = (uint8_t)tb.terr;
 }
 
@@ -633,7 +699,7 @@ int pk_create(pk_handle **out, int device, int num_tables, int num_players, cons
     const size_t nwaves = (T + PK_TABLE_BLOCK - 1) / PK_TABLE_BLOCK;
     size_t total = 4 * al(T * N * 8) + 4 * al(T * 8) + 4 * al(T * 4) + al(W * T * 4) + al(N * T * 4) + 2 * al(T) +
                    al(nwaves * PK_NUM_COUNTERS * 8) + al(PK_NUM_COUNTERS * 8) + al(PF_SLOTS * 8) + al(sizeof(State)) +
-                   al(PK_MAX_PLAYERS * 8) + al(T * 4) + 5 * al(T) + al(T * 8) + h->export_bytes;
+                   al(PK_MAX_PLAYERS * 8) + al(sizeof(Fresh)) + al(T * 4) + 5 * al(T) + al(T * 8) + h->export_bytes;
     e = hipMalloc(&h->arena, total);
     if (e != hipSuccess) return bail(h->fail(PK_E_OOM, "hipMalloc(table state)", e));
     if (hipMemsetAsync(h->arena, 0, total, h->stream) != hipSuccess) return bail(h->fail(PK_E_HIP, "hipMemset"));
@@ -655,6 +721,7 @@ int pk_create(pk_handle **out, int device, int num_tables, int num_players, cons
     S.prof = (unsigned long long *)take(PF_SLOTS * 8);
     h->d_S = (State *)take(sizeof(State));
     double *d_start = (double *)take(PK_MAX_PLAYERS * 8);
+    Fresh *d_fresh = (Fresh *)take(sizeof(Fresh));
     h->d_actions = (int32_t *)take(T * 4);
     h->d_flags = (uint8_t *)take(T); h->d_terr = (uint8_t *)take(T); h->d_mask = (uint8_t *)take(T);
     h->d_done = (uint8_t *)take(T); h->d_handf = (uint8_t *)take(T);
@@ -675,6 +742,7 @@ int pk_create(pk_handle **out, int device, int num_tables, int num_players, cons
         // get_valid_actions on the un-reset state (all credits and pending bets 0): raises invalid (0 > 0 is false),
         // CHECK valid (high_bet == 0), CALL invalid (0 < 0 is false) -> FOLD | CHECK | ALL_IN
         std::vector<uint8_t> valid(T, (uint8_t)((1u << MV_FOLD) | (1u << MV_CHECK) | (1u << MV_ALL_IN)));
+        h->hot.fresh = d_fresh;
         h->hot.big_blind = big_blind; h->hot.small_blind = small_blind; h->hot.start_credits = d_start; h->hot.show = S.show;
         h->hot.key0 = S.key0; h->hot.key1 = S.key1; h->hot.table_id_base = table_id_base; h->hot.T = num_tables;
         h->hot.start_uniform = S.start_credits[0]; h->hot.start_is_uniform = 1;
@@ -687,6 +755,9 @@ int pk_create(pk_handle **out, int device, int num_tables, int num_players, cons
             hipMemcpyAsync(S.valid, valid.data(), T, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
             hipStreamSynchronize(h->stream) != hipSuccess)
             return bail(h->fail(PK_E_HIP, "initial state upload"));
+        DISPATCH_N(h, k_make_fresh, 1, h->hot, d_fresh);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess)
+            return bail(h->fail(PK_E_HIP, "k_make_fresh"));
     }
     *out = h;
     return PK_OK;
@@ -769,7 +840,7 @@ int pk_step_d(pk_handle *h, const int32_t *actions_d, uint8_t *flags_d, uint8_t 
     if (!h || !actions_d || !flags_d) return h ? h->fail(PK_E_INVALID_ARG, "pk_step_d: NULL buffer") : PK_E_INVALID_ARG;
     ON_DEVICE(h);
     FLUSH(h);
-    DISPATCH_N(h, k_step, table_grid(h), h->S, h->hot, actions_d, flags_d, terr_d);
+    DISPATCH_N(h, k_step, table_grid(h), (const State *)h->d_S, h->hot, actions_d, flags_d, terr_d);
     HIPCHK(h, hipGetLastError());
     return PK_OK;
 }
@@ -920,7 +991,7 @@ int pk_env_reset_d(pk_handle *h, const uint8_t *mask_d, int opp_policy) {
     if (!h || opp_policy < 0 || opp_policy > 1) return h ? h->fail(PK_E_INVALID_ARG, "pk_env_reset_d: bad argument") : PK_E_INVALID_ARG;
     ON_DEVICE(h);
     FLUSH(h);
-    DISPATCH_N(h, k_env_reset, table_grid(h), h->S, h->hot, mask_d, opp_policy);
+    DISPATCH_N(h, k_env_reset, table_grid(h), (const State *)h->d_S, h->hot, mask_d, opp_policy, h->park);
     HIPCHK(h, hipGetLastError());
     return PK_OK;
 }
@@ -931,7 +1002,7 @@ int pk_env_step_d(pk_handle *h, const int32_t *actions_d, int opp_policy, double
         return h ? h->fail(PK_E_INVALID_ARG, "pk_env_step_d: bad argument") : PK_E_INVALID_ARG;
     ON_DEVICE(h);
     FLUSH(h);
-    DISPATCH_N(h, k_env_step, table_grid(h), h->S, h->hot, actions_d, opp_policy, reward_d, done_d, hand_d, terr_d);
+    DISPATCH_N(h, k_env_step, table_grid(h), (const State *)h->d_S, h->hot, actions_d, opp_policy, reward_d, done_d, hand_d, terr_d, h->park);
     HIPCHK(h, hipGetLastError());
     return PK_OK;
 }
@@ -1008,13 +1079,15 @@ int pk_flush(pk_handle *h) {
 
 int pk_time_rollout(pk_handle *h, int k_steps, int policy, int auto_reset, int fused, int reps, double *ms_per_launch,
                     uint64_t *counters) {
-    if (!h || !ms_per_launch || reps < 1 || k_steps < 1 || policy < 0 || policy > 1)
+    if (!h || !ms_per_launch || reps < 1 || k_steps < 0 || policy < 0 || policy > 1)
         return h ? h->fail(PK_E_INVALID_ARG, "pk_time_rollout: bad argument") : PK_E_INVALID_ARG;
     ON_DEVICE(h);
     FLUSH(h);
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
     for (int r = 0; r < reps; ++r) {
-        int rc = enqueue_rollout(h, k_steps, policy, auto_reset ? 1 : 0, fused, false);
+        // k_steps == 0: empty launches (load the tables, store them) -- the fixed cost of a launch, for diagnostics
+        int rc = k_steps ? enqueue_rollout(h, k_steps, policy, auto_reset ? 1 : 0, fused, false)
+                         : launch_rollout(h, 0, policy, auto_reset ? 1 : 0, 1);
         if (rc) return rc;
     }
     FLUSH(h);  // what the deferred launches left is part of the work that is being timed

@@ -51,7 +51,18 @@ struct State {
 // State are taken by pointer and s_load-ed only where a table is loaded / stored.  (All of State by value kept ~35 SGPR
 // pairs live across the loop and spilled 66 SGPRs into VGPR lanes; all of it by pointer made the compiler re-issue
 // scalar loads inside the loop.)
+// A table right after Game.reset(dealer = 0) minus the deal: it depends on the configuration only (seats, start
+// credits, blinds), so the auto-reset of a finished game inside k_rollout is a copy of these constants (computed once
+// per handle by k_make_fresh with the ordinary reset_state) instead of a second inlined copy of setup_hand.
+struct Fresh {
+    double credits[PK_MAX_PLAYERS], pending[PK_MAX_PLAYERS];
+    double min_raise;
+    uint32_t st_active, st_called, st_allin, st_broken;
+    int active, dealer, sb, bb;
+};
+
 struct Hot {
+    const Fresh *fresh;           // device memory
     double big_blind, small_blind;
     const double *start_credits;  // [N], device memory: per-seat start credits (read on Game.reset only)
     double start_uniform;         // the common case, every seat starts with the same credits: no memory read at all
@@ -359,6 +370,10 @@ template <int N>
 struct Lds {  // per workgroup (= one wavefront); ~10 KB at N = 10
     uint32_t item[64 * N][2];  // [0] = community cards 0..3 (bytes); [1] = card4 | hole0<<6 | hole1<<12 | dest<<18
     uint32_t res[64 * N];      // dest = lane*N + seat -> HandRanking<<20 | kickers
+    uint32_t act[8][64];       // k_rollout's action draws: two Philox blocks per lane, [slot * 4 + word][lane]
+    uint32_t show[N][64];      // rankings of each lane's last showdown; written back by Table::store_show at kernel end
+                               // (keeps global stores, and the vmcnt waits they drag along, out of the step loop)
+    Fresh fresh;               // workgroup copy of *Hot::fresh (Table::stage_fresh), read with broadcast ds_reads
 };
 
 struct ActionRng {  // one Philox block serves EIGHT consecutive steps of a table: 16-bit draws (RNG spec)
@@ -374,6 +389,45 @@ struct ActionRng {  // one Philox block serves EIGHT consecutive steps of a tabl
         uint32_t lo = (j & 2) ? w[1] : w[0], hi = (j & 2) ? w[3] : w[2];
         uint32_t x = (j & 4) ? hi : lo;
         return (j & 1) ? (x >> 16) : (x & 0xffffu);
+    }
+};
+// The same draws for k_rollout, where the lanes of a wave sit at different step serials: on demand, the Philox block
+// of a lane that crosses a block boundary would be computed by the whole wave at 1/8 occupancy nearly every iteration.
+// Instead every lane keeps TWO blocks in LDS (its current one and the next), and all lanes refill their free slot
+// together, in wave-uniform control flow, only when some lane has run out: one Philox pass per ~8 iterations at
+// ~3/4 occupancy.  Lanes only ever read what they wrote themselves (no cross-lane traffic, no barrier).
+struct ActionRing {
+    uint32_t filled = 0;  // (low 32 bits of) the first block index NOT yet in LDS; blocks filled-2, filled-1 are
+    bool primed = false;
+    // `need`: this lane picks an action now.  Must be called from wave-uniform control flow.
+    template <typename LDS>
+    __device__ __forceinline__ uint32_t draw16(LDS &lds, const Hot &S, uint32_t table_id, uint64_t step_serial, bool need) {
+        const int lane = threadIdx.x & (PK_WAVE - 1);
+        const uint64_t qfull = step_serial >> 3;
+        const uint32_t q = (uint32_t)qfull;
+        if (!primed || (int32_t)(filled - q) < 0) filled = q;       // nothing useful held (start, or the table idled)
+        primed = true;
+        if (__any(need && filled == q)) {                           // some lane's current block is missing
+#pragma unroll 1
+            for (int r = 0; r < 2; ++r) {                           // every lane fills its free slot(s)
+                const bool fill = (int32_t)(filled - q) < 2;
+                if (!__any(fill)) break;
+                if (fill) {
+                    const uint64_t b = qfull + (uint64_t)(filled - q);
+                    uint32_t w[4];
+                    philox4x32_10(table_id, (uint32_t)b, STREAM_ACTION, (uint32_t)(b >> 32), S.key0, S.key1, w);
+                    const int slot = (filled & 1) * 4;
+                    lds.act[slot + 0][lane] = w[0]; lds.act[slot + 1][lane] = w[1];
+                    lds.act[slot + 2][lane] = w[2]; lds.act[slot + 3][lane] = w[3];
+                    filled += 1;
+                }
+            }
+        }
+        const uint32_t j = (uint32_t)step_serial & 7;
+        return lds.act[(q & 1) * 4 + (j >> 1)][lane];   // the word holding draw j; half_of() picks the 16 bits at the use site,
+    }                                                    // so that the LDS latency hides behind the valid-mask arithmetic
+    __device__ __forceinline__ static uint32_t half_of(uint32_t word, uint64_t step_serial) {
+        return ((uint32_t)step_serial & 1) ? (word >> 16) : (word & 0xffffu);
     }
 };
 // k-th (0-based) valid action of the mask for a 16-bit draw r: k = (r * popcount(mask)) >> 16 (RNG spec)
@@ -408,6 +462,7 @@ struct Table {
     bool foldout;
     // counters since load
     uint32_t evals, games, hands, seen;
+    bool showed;  // lds.show holds a showdown of this launch
     PK_PROF(Prof prof;)
 
     __device__ __forceinline__ void load(const State &S, int t) {
@@ -428,7 +483,7 @@ struct Table {
         // anything else: the host flushes deferred work before every other kernel).
         current = (cur >> 20) & 0xf; lstate = (cur >> 24) & 3; foldout = (cur >> 26) & 1; stepped = (cur >> 27) & 1;
         flags = (cur >> 28) & 7; hands_this_step = 0; terr = 0;
-        evals = 0; games = 0; hands = 0; seen = 0;
+        evals = 0; games = 0; hands = 0; seen = 0; showed = false;
     }
     // A lane with no table (t >= T) still walks the wave-uniform control flow: give it inert, well-defined state.
     __device__ __forceinline__ void blank() {
@@ -437,7 +492,7 @@ struct Table {
         active = dealer = sb = bb = turn = hand = 0; hand_serial = step_serial = 0;
         PK_FOR(w, W) cards[w] = 0; PK_END
         idle();
-        evals = 0; games = 0; hands = 0; seen = 0;
+        evals = 0; games = 0; hands = 0; seen = 0; showed = false;
     }
     __device__ __forceinline__ void idle() { lstate = LS_DONE; current = 0; hands_this_step = 0; flags = 0; terr = 0; stepped = 0; foldout = false; }
     __device__ __forceinline__ void store(const State &S, int t) const {
@@ -566,6 +621,33 @@ struct Table {
         }
         st_active = FULL; st_called = st_allin = st_broken = 0;                    // :409
         setup_state(S);                                                            // :412
+    }
+
+    // Rankings of the last showdown (game.py:488-489) -> State::show; every kernel that runs end_block calls this last.
+    __device__ __forceinline__ void store_show(uint32_t *show, int T, int t, const Lds<N> &lds) const {
+        if (showed) {
+            const int lane = threadIdx.x & (PK_WAVE - 1);
+            PK_FOR(p, N) show[(size_t)p * T + t] = lds.show[p][lane]; PK_END
+        }
+    }
+    // Workgroup copy of the fresh-table constants; call once, from wave-uniform control flow, before the first end_block.
+    __device__ __forceinline__ static void stage_fresh(Lds<N> &lds, const Fresh *src) {
+        const int lane = threadIdx.x & (PK_WAVE - 1);
+        constexpr int words = (int)(sizeof(Fresh) / 4);
+        const uint32_t *s32 = reinterpret_cast<const uint32_t *>(src);
+        uint32_t *d32 = reinterpret_cast<uint32_t *>(&lds.fresh);
+        for (int i = lane; i < words; i += PK_WAVE) d32[i] = s32[i];
+        __syncthreads();
+    }
+    // Game.reset(dealer = 0) minus the shuffle as a copy of the per-handle constants (see Fresh); payoffs are kept,
+    // as reset() keeps them.
+    __device__ __forceinline__ void load_fresh(const Fresh &f) {
+        PK_FOR(p, N) credits[p] = f.credits[p]; bets[p] = 0.0; pending[p] = f.pending[p]; PK_END
+        min_raise = f.min_raise;
+        st_active = f.st_active; st_called = f.st_called; st_allin = f.st_allin; st_broken = f.st_broken;
+        active = f.active; dealer = f.dealer; sb = f.sb; bb = f.bb;
+        hand = 1; turn = 0;
+        hands_this_step += 1;
     }
 
     // Game.step up to the call of next_player (game.py:656-699) for an action already checked against the mask.
@@ -699,8 +781,9 @@ struct Table {
             PK_FOR(p, N)
                 wb[p] = bets[p];
                 hv[p] = ((showdown >> p) & 1) ? hv[p] : NONE_V;
-                S.show[(size_t)p * S.T + t] = hv[p];
+                lds.show[p][lane] = hv[p];
              PK_END
+            showed = true;
             uint32_t todo = showdown;                                              // :495-496 argsort(bets) filtered, stable
             while (todo) {                                                         // :498
                 PK_PROF(prof.count(PF_N_SIDEPOT);)
@@ -771,7 +854,7 @@ struct Table {
                     seen |= terr; terr = 0;
                     flags |= PK_FLAG_GAME_OVER;   // counted as a finished game by the caller (k_rollout's retire)
                     hand_serial += 1;      // the deck setup_hand() shuffled for the dead game is never looked at
-                    reset_state(S, 0);
+                    load_fresh(lds.fresh);
                 }
                 PK_PROF(prof.lap(PF_SETUP);)
                 deal(S, table_id);                                                 // :424

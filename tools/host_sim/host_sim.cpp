@@ -38,9 +38,18 @@ static int run(int T, int K, int policy, uint64_t seed, Cfg cfg = default_cfg(),
     H.key0 = S.key0; H.key1 = S.key1; H.table_id_base = cfg.base; H.T = T;
     H.start_uniform = sc[0]; H.start_is_uniform = 1;
     for (int p = 1; p < N; ++p) if (sc[p] != sc[0]) H.start_is_uniform = 0;
+    Fresh fr{};
+    {
+        Table<N> f0; f0.blank(); f0.reset_state(H, 0);
+        for (int p = 0; p < N; ++p) { fr.credits[p] = f0.credits[p]; fr.pending[p] = f0.pending[p]; }
+        fr.min_raise = f0.min_raise; fr.st_active = f0.st_active; fr.st_called = f0.st_called; fr.st_allin = f0.st_allin; fr.st_broken = f0.st_broken;
+        fr.active = f0.active; fr.dealer = f0.dealer; fr.sb = f0.sb; fr.bb = f0.bb;
+    }
+    H.fresh = &fr;
     orc_game *o = orc_create(T, N, sc, cfg.bb, cfg.sb, seed, cfg.base);
     orc_reset(o, nullptr, cfg.dealer);
     static Lds<N> lds;
+    Table<N>::stage_fresh(lds, H.fresh);
     std::vector<Table<N>> tb(T);
     for (int t = 0; t < T; ++t) { tb[t].load(S, t); tb[t].reset_state(H, cfg.dealer % N); tb[t].deal(H, cfg.base + (uint32_t)t); tb[t].store(S, t); }
     std::vector<double> oc(N * T), ob(N * T), op(N * T), oy(N * T);
@@ -53,8 +62,9 @@ static int run(int T, int K, int policy, uint64_t seed, Cfg cfg = default_cfg(),
             Table<N> &x = tb[t];
             x.load(S, t);
             double hb; uint32_t mask = x.valid_mask(hb);
-            ActionRng rng;
-            x.begin_step(H, pick_action(H, rng, cfg.base + (uint32_t)t, x.step_serial, mask, policy), hb);
+            ActionRing ring;   // the LDS ring of k_rollout (one lane)
+            uint32_t draw = policy == 0 ? ActionRing::half_of(ring.draw16(lds, H, cfg.base + (uint32_t)t, x.step_serial, true), x.step_serial) : 0;
+            x.begin_step(H, policy == 1 ? (int)MV_ALL_IN : action_from_draw(draw, mask), hb);
             x.run(H, t, cfg.base + (uint32_t)t, lds, true);
             x.store(S, t);
         }

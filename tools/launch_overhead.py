@@ -13,7 +13,9 @@ g = pokerl_amd.VecGame(T, num_players=N)
 g.reset()
 g.rollout(2048, 0)
 print("N=%d T=%d" % (N, T))
-for endk in (64, 56, 48, 1):
+ms, _ = g.time_rollout(0, 0, True, True, 2000)
+print("empty launch (load + store all tables, no step): %.2f us" % (ms * 1e3))
+for endk in (48, 1):
     g.set_tuning(0, endk)
     for K in (1, 2, 5, 10, 20, 40, 80, 160, 512, 2048):
         reps = max(2, 8192 // K)
