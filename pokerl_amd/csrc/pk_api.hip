@@ -133,8 +133,11 @@ __global__ void __launch_bounds__(PK_TABLE_BLOCK) k_pick(State S, Hot H, int pol
 // (endk == 1: run to completion) the host issues before anything can observe the tables.  Every table still makes
 // exactly the requested steps with the actions the RNG spec assigns to (table, step_serial), so the observable state
 // is bit-identical to the lockstep order.
+#ifndef PK_ROLLOUT_ATTR
+#define PK_ROLLOUT_ATTR
+#endif
 template <int N>
-__global__ void __launch_bounds__(PK_TABLE_BLOCK) k_rollout(const State *__restrict__ Sp, Hot H, int K, int policy, int auto_reset, int park, int endk, int clear_terr) {
+__global__ void __launch_bounds__(PK_TABLE_BLOCK) PK_ROLLOUT_ATTR k_rollout(const State *__restrict__ Sp, Hot H, int K, int policy, int auto_reset, int park, int endk, int clear_terr) {
     // Array bases by pointer (loaded only where the table is loaded / stored), loop scalars by value: see pk::Hot.
     const State &S = *Sp;
     __shared__ Lds<N> lds;
