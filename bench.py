@@ -119,11 +119,12 @@ VALU_PEAK_WAVE_INSTS_PER_S = 256 * 4 * 2.4e9 / 2.0   # 256 CUs x 4 SIMDs, one wa
 #   SIMD that 65 536 tables give, 0.5 of this peak is the ceiling; tools/microbench/valu_rates.hip measures both)
 
 
-def profile_summary(tables, players, policy):
+def profile_summary(tables, players, policy, kern_steps=None):
     """The committed rocprofv3 summary (profiles/*_summary.json: kernel trace + separate PMC passes of THIS bench command,
-    made by tools/profile_gpu.sh + tools/summarize_profile.py) for this workload, newest round first; None if none."""
+    made by tools/profile_gpu.sh + tools/summarize_profile.py) for this workload -- the one profiled at the same launch
+    length if there is one, else the latest; None if none."""
     import glob
-    best = None
+    best, exact = None, None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_summary.json"))):
         try:
             d = json.load(open(f))
@@ -132,7 +133,9 @@ def profile_summary(tables, players, policy):
         w = d.get("workload", {})
         if (w.get("tables"), w.get("players"), w.get("policy")) == (tables, players, policy) and w.get("fused", True):
             best = (d, os.path.basename(f))
-    return best
+            if w.get("steps_per_launch") == kern_steps:
+                exact = best
+    return exact or best
 
 
 def evaluator_leg(device, log2_m=None, reps=5):
@@ -316,7 +319,7 @@ def main():
         alg_bytes = b_step(args.players) * n_local * kern_steps
         achieved = alg_bytes / (ms_launch * 1e-3) / 1e9
         cfg_idx = baseline_config_index(args.tables, args.players, args.policy, ctx.world)
-        prof = profile_summary(args.tables, args.players, args.policy) if fused else None
+        prof = profile_summary(args.tables, args.players, args.policy, kern_steps) if fused else None
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                 "traffic_unit": "bytes per launch (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE, KiB)",

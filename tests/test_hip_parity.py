@@ -648,10 +648,16 @@ def test_bench_json_contract():
     assert r["scaling"] == "weak" and r["vs_baseline"] is None and r["dtype"] == "f64" and r["data"] == "synthetic"
     assert "workload" in r["config"] and "model" not in r["config"] and "BASELINE configs[2]" in r["config"]["workload"]
     assert abs(r["value"] - 65536 * 256 / (r["ms_per_step"] * 256 / 1e3)) / r["value"] < 1e-6
+    assert r["reps"] == 16 and r["samples"] == 5 and len(r["sample_seconds"]) == 5   # 16 blocks of 256 steps >= 4096 per sample
     rf = r["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
-    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and "traffic" in rf
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
     assert abs(rf["achieved"] - rf["algorithmic_bytes_per_launch"] / (rf["kernel_ms"] * 1e-3) / 1e9) / rf["achieved"] < 1e-6
+    # measured HBM traffic and the binding (VALU issue) roofline come from the committed rocprofv3 PMC summary of this workload
+    assert rf["traffic"] and 0.5 < rf["traffic"] / (65536 * 2 * 290) < 1.5 and rf["traffic_source"].endswith("_summary.json")
+    va = rf["valu"]
+    assert va["bound"] == "valu-issue" and 0.0 < va["frac"] <= 0.5 and abs(va["frac"] - va["achieved"] / va["peak"]) < 1e-9
+    assert va["peak"] == 256 * 4 * 2.4e9 / 2 and va["waves_per_simd"] == 1.0 and 0.3 < va["lanes_active"] <= 1.0
     cb = r["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and cb["unit"] == "env-steps/s" and cb["sample"]
     ev = r["evaluator"]

@@ -21,7 +21,11 @@ shutil.copy(stats, os.path.join(dst, tag + "_kernel_stats.csv"))
 trace = glob.glob(os.path.join(src, "trace", "*", "*_kernel_trace.csv"))[0]
 rows = [r for r in csv.DictReader(open(trace)) if kname in r["Kernel_Name"]]
 durs = sorted((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in rows)
-big = [d for d in durs if d > 0.5 * durs[-1]]          # the full-size launches (512 steps); the rest are warm-up tails / K=0
+# the launches of the profiled length: with few long launches they are the longest ones; with hundreds of short ones
+# (--steps 20) they are the bulk, and the longest are the cold first launch / the flushes of deferred work
+med = durs[len(durs) // 2]
+big = [d for d in durs if 0.6 * med <= d <= 1.6 * med] if len(durs) >= 50 else [d for d in durs if d > 0.5 * durs[-1]]
+lo, hi = big[0], big[-1]
 summary = {
     "tag": tag, "kernel": rows[0]["Kernel_Name"], "launches_total": len(durs), "launches_full": len(big),
     "avg_full_launch_ms": sum(big) / len(big) / 1e6, "min_full_launch_ms": big[0] / 1e6, "max_full_launch_ms": big[-1] / 1e6,
@@ -41,8 +45,12 @@ for f in sorted(glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in agg.items():
         v = sorted(v)
-        full = [x for x in v if x > 0.5 * v[-1]]
-        counters[k] = sum(full) / len(full)             # per full-size launch
+        if len(v) >= 50:                                # many short launches: the bulk around the median
+            m = v[len(v) // 2]
+            full = [x for x in v if 0.5 * m <= x <= 2.0 * m] or v
+        else:
+            full = [x for x in v if x > 0.5 * v[-1]]
+        counters[k] = sum(full) / len(full)             # per launch of the profiled length
 summary["pmc_per_full_launch"] = counters
 if "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
     # guides/MI355X_MICROARCH.md, HBM: FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports 1/2 of the bytes
@@ -53,6 +61,18 @@ if "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
 if "SQ_INSTS_VALU" in counters and "SQ_WAVES" in counters:
     summary["valu_insts_per_wave"] = counters["SQ_INSTS_VALU"] / counters["SQ_WAVES"]
     summary["salu_insts_per_wave"] = counters.get("SQ_INSTS_SALU", 0) / counters["SQ_WAVES"]
+    k = summary.get("workload", {}).get("steps_per_launch")
+    if k:
+        summary["valu_insts_per_wave_step"] = summary["valu_insts_per_wave"] / k
+        summary["salu_insts_per_wave_step"] = summary["salu_insts_per_wave"] / k
+        # chip VALU issue: wave-instructions per second vs 256 CU x 4 SIMD x 2.4 GHz / 2 cycles (guides/MI355X_MICROARCH.md)
+        rate = counters["SQ_INSTS_VALU"] / (summary["avg_full_launch_ms"] * 1e-3)
+        summary["valu_issue_rate_wave_insts_per_s"] = rate
+        summary["valu_issue_frac_of_peak"] = rate / (256 * 4 * 2.4e9 / 2)
+if "SQ_THREAD_CYCLES_VALU" in counters and counters.get("SQ_ACTIVE_INST_VALU"):
+    summary["lanes_active"] = counters["SQ_THREAD_CYCLES_VALU"] / (64.0 * counters["SQ_ACTIVE_INST_VALU"])
+if "SQ_WAVES" in counters:
+    summary["waves_per_simd"] = counters["SQ_WAVES"] / 1024.0
 if "SQ_ACTIVE_INST_VALU" in counters and "SQ_WAVE_CYCLES" in counters:
     summary["valu_active_frac_of_wave_cycles"] = counters["SQ_ACTIVE_INST_VALU"] / counters["SQ_WAVE_CYCLES"]
     summary["wait_any_frac_of_wave_cycles"] = counters.get("SQ_WAIT_ANY", 0) / counters["SQ_WAVE_CYCLES"]
