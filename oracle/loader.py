@@ -44,6 +44,7 @@ def lib():
     L.orc_step.argtypes = [C.c_void_p, _i32p, _u8p, _u8p]
     L.orc_step.restype = C.c_int
     L.orc_valid_actions.argtypes = [C.c_void_p, _u8p]
+    L.orc_valid_actions_for.argtypes = [C.c_void_p, C.c_int, _u8p]
     L.orc_pick_actions.argtypes = [C.c_void_p, C.c_int, _i32p]
     L.orc_rollout.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, _u64p]
     L.orc_rollout.restype = C.c_int
@@ -110,6 +111,11 @@ class OracleGame:
     def valid_actions(self):
         m = np.zeros(self.T, np.uint8)
         self.L.orc_valid_actions(self.h, m)
+        return m
+
+    def valid_actions_for(self, player):
+        m = np.zeros(self.T, np.uint8)
+        self.L.orc_valid_actions_for(self.h, int(player), m)
         return m
 
     def pick_actions(self, policy):

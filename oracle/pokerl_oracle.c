@@ -491,6 +491,10 @@ void orc_valid_actions(const orc_game *g, uint8_t *mask) {
     for (int i = 0; i < g->T; ++i) mask[i] = (uint8_t)valid_actions(g, &g->t[i], g->t[i].active_player);
 }
 
+void orc_valid_actions_for(const orc_game *g, int player, uint8_t *mask) { /* get_valid_actions(player), game.py:339-383 */
+    for (int i = 0; i < g->T; ++i) mask[i] = (uint8_t)valid_actions(g, &g->t[i], player < 0 ? g->t[i].active_player : player);
+}
+
 void orc_pick_actions(const orc_game *g, int policy, int32_t *actions) {
     for (int i = 0; i < g->T; ++i) {
         const table_t *t = &g->t[i];

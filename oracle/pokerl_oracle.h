@@ -42,6 +42,8 @@ void orc_reset(orc_game *g, const uint8_t *mask, int dealer);
 int orc_step(orc_game *g, const int32_t *actions, uint8_t *flags, uint8_t *err);
 /* get_valid_actions() of the active player as a bitmask (bit a = action a). game.py:339-383 */
 void orc_valid_actions(const orc_game *g, uint8_t *mask);
+/* the same for seat `player` of every table (player < 0: the active player), get_valid_actions(player) game.py:339-383 */
+void orc_valid_actions_for(const orc_game *g, int player, uint8_t *mask);
 
 /* Synthetic agents of rng_spec.py: policy 0 random, 1 all-in. Writes the action each table would take now. */
 void orc_pick_actions(const orc_game *g, int policy, int32_t *actions);

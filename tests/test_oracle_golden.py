@@ -99,6 +99,48 @@ def test_env_trajectories(name):
     GU.replay_env(make_oracle, name)
 
 
+@pytest.mark.parametrize("name", GU.VIEW_SETS)
+def test_reference_state_views(name):
+    """The reference's own StateView.__getstate__() tuples, get_valid_actions(p) of every seat, pot / high_bet /
+    game_over (tests/golden/views_*.json, recorded from the imported reference after every step) against the oracle's
+    state: pins the observation contract on the CPU side."""
+    meta = GU.load_json(name)
+    o = make_oracle(meta)
+    o.reset(dealer=meta.get("dealer", 0))
+    n, T = meta["n"], meta["tables"]
+    fh = float.fromhex
+    for s in range(meta["steps"]):
+        acts = np.array(meta["actions"][s], np.int32)
+        assert np.array_equal(o.pick_actions(meta["policy"]), acts)
+        flags, err = o.step(acts)
+        assert not err.any() and flags.tolist() == meta["flags"][s]
+        snap = o.snapshot()
+        masks = [o.valid_actions_for(p) for p in range(n)]
+        for t in range(T):
+            rec = meta["views"][s][t]
+            act = rec["active"]
+            assert act["player"] == snap["active"][t] and act["turn"] == snap["turn"][t] and act["num_players"] == n
+            assert [fh(x) for x in act["credits"]] == snap["credits"][t].tolist()
+            assert [fh(x) for x in act["bets"]] == snap["bets"][t].tolist()
+            assert [fh(x) for x in act["pending_bets"]] == snap["pending"][t].tolist()
+            assert fh(act["minimum_raise_value"]) == snap["min_raise"][t]
+            nvis = 0 if snap["turn"][t] == 0 else snap["turn"][t] + 2
+            assert act["community_cards"] == snap["cards"][t, :nvis].tolist()                       # game.py:266-278
+            a = int(snap["active"][t])
+            assert act["player_cards"] == snap["cards"][t, 5 + 2 * a:7 + 2 * a].tolist()          # game.py:385-389
+            assert [int(fh(x)) for x in act["valid_actions"]] == [(int(snap["valid"][t]) >> k) & 1 for k in range(7)]
+            for p in range(n):
+                assert [int(fh(x)) for x in rec["valid_for"][p]] == [(int(masks[p][t]) >> k) & 1 for k in range(7)], (s, t, p)
+                who = p if p else a                                                             # `player or active_player`, game.py:122
+                assert rec["per_player"][p]["player"] == who
+                assert rec["per_player"][p]["player_cards"] == snap["cards"][t, 5 + 2 * who:7 + 2 * who].tolist()
+            assert fh(rec["pot"]) == np.sum(snap["bets"][t]) and fh(rec["high_bet"]) == np.max(snap["pending"][t])
+            assert rec["game_over"] == bool((snap["states"][t] != 4).sum() == 1)
+        over = (flags & 1).astype(np.uint8)
+        if over.any():
+            o.reset(mask=over)
+
+
 def test_invalid_action_leaves_state_untouched():
     g = O.OracleGame(4, 3)
     g.reset()
