@@ -213,11 +213,14 @@ def env_mode(args, ctx, device):
 
     def loop(k):
         for _ in range(k):
-            L.check(lib.pk_pick_actions_d(g._h, 0, act.ptr), g._h)
-            L.check(lib.pk_env_step_d(g._h, act.ptr, 0, rew.ptr, done.ptr, hand.ptr, terr.ptr), g._h)
-            L.check(lib.pk_env_reset_d(g._h, done.ptr, 0), g._h)   # finished episodes ...
-            L.check(lib.pk_env_reset_d(g._h, terr.ptr, 0), g._h)   # ... and tables the reference would never return from
-            L.check(lib.pk_get_obs_d(g._h, -1, obs.ptr), g._h)     #     (PK_TERR_HAND_CAP: ~1 per 25 M game steps)
+            if args.env_unfused:   # five launches per env step
+                L.check(lib.pk_pick_actions_d(g._h, 0, act.ptr), g._h)
+                L.check(lib.pk_env_step_d(g._h, act.ptr, 0, rew.ptr, done.ptr, hand.ptr, terr.ptr), g._h)
+                L.check(lib.pk_env_reset_d(g._h, done.ptr, 0), g._h)   # finished episodes ...
+                L.check(lib.pk_env_reset_d(g._h, terr.ptr, 0), g._h)   # ... and tables the reference would never return from
+                L.check(lib.pk_get_obs_d(g._h, -1, obs.ptr), g._h)     #     (PK_TERR_HAND_CAP: ~1 per 25 M game steps)
+            else:                  # the same work in ONE launch: seat 0 in-kernel, auto-reset, observation from registers
+                L.check(lib.pk_env_step_fused_d(g._h, None, 0, 0, 1, rew.ptr, done.ptr, hand.ptr, terr.ptr, obs.ptr), g._h)
 
     loop(args.warmup)
     g.sync()
@@ -231,7 +234,8 @@ def env_mode(args, ctx, device):
     capped = int((terr.download(np.uint8, T) != 0).sum())
     if ctx.rank == 0:
         print(json.dumps({
-            "metric": "PokerGameEnv.step seat-0 steps/s (device-resident loop: pick + env_step + env_reset(done) + obs)",
+            "metric": "PokerGameEnv.step seat-0 steps/s (device-resident loop: pick + env_step + env_reset(done) + obs; %s)"
+                      % ("five launches per step" if args.env_unfused else "fused into one launch per step"),
             "value": T * args.steps / dt, "unit": "env.step/s", "n_gpus": ctx.world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
@@ -258,6 +262,7 @@ def main():
     ap.add_argument("--samples", type=int, default=5, help="timed samples; the MEDIAN is reported")
     ap.add_argument("--unfused", action="store_true", help="one launch per step (state round-trips HBM every step)")
     ap.add_argument("--mode", choices=["game", "env"], default="game")
+    ap.add_argument("--env-unfused", action="store_true", help="--mode env with separate pick / step / reset / obs launches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-evaluator", action="store_true", help="skip the stand-alone evaluator kernel leg")
     args = ap.parse_args()

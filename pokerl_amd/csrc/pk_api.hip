@@ -254,8 +254,13 @@ __global__ void __launch_bounds__(PK_TABLE_BLOCK) k_env_reset(const State *__res
 
 // PokerGameEnv.step: seat 0's own step (:35), the opponents until the hand ends or seat 0 is to act (:41-44), the
 // opponents until seat 0 is to act or the game is over (:49-52) -- three phases of one lane-level machine.
+// Fused extras for a learner's loop (all optional, each removes a launch per env step): seat 0 can be played by an
+// in-kernel agent (seat0_policy >= 0; actions == NULL), a finished episode can be reset on the spot
+// (auto_reset: PokerGameEnv.reset(), game_env.py:20-29 -- what the caller would do next for `done` tables; reward /
+// done / hand still describe the step that ended it), and the dense StateView row of the player to act can be
+// written straight from registers (obs != NULL, layout PK_OBS_DIM).
 template <int N>
-__global__ void __launch_bounds__(PK_TABLE_BLOCK) k_env_step(const State *__restrict__ Sp, Hot H, const int32_t *actions, int opp_policy, double *reward, uint8_t *done_out, uint8_t *hand_out, uint8_t *terr, int park) {
+__global__ void __launch_bounds__(PK_TABLE_BLOCK) k_env_step(const State *__restrict__ Sp, Hot H, const int32_t *actions, int seat0_policy, int opp_policy, int auto_reset, double *reward, uint8_t *done_out, uint8_t *hand_out, uint8_t *terr, double *obs, int park) {
     const State &S = *Sp;
     __shared__ Lds<N> lds;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -266,24 +271,37 @@ __global__ void __launch_bounds__(PK_TABLE_BLOCK) k_env_step(const State *__rest
     ActionRng rng;
     double high_bet;
     const uint32_t vm0 = tb.valid_mask(high_bet);
-    const int action = live ? actions[t] : -1;
+    const int action = !live ? -1 : (actions ? actions[t] : pick_action(H, rng, table_id, tb.step_serial, vm0, seat0_policy));
     const bool ok = live && action >= 0 && action < PK_NUM_MOVES && ((vm0 >> action) & 1);   // game.py:648-651
-    enum { PH_SEAT0 = 0, PH_HAND = 1, PH_TURN = 2, PH_FIN = 3 };
-    int phase = ok ? PH_SEAT0 : PH_FIN;
+    enum { PH_SEAT0 = 0, PH_HAND = 1, PH_TURN = 2, PH_RESET = 3, PH_RESET_PLAY = 4, PH_END = 5 };
+    int phase = ok ? PH_SEAT0 : PH_END;
     double rew = 0.0;                                                              // :34
     bool done = false, hand = false;
-    int budget = PK_ENV_STEP_CAP;
+    uint32_t terr_step = 0;
+    int budget = PK_ENV_STEP_CAP, budget_reset = PK_ENV_STEP_CAP;
+    const uint32_t caps = PK_TERR_HAND_CAP | PK_TERR_ENV_CAP;
+    auto step_finished = [&]() {   // PokerGameEnv.step has returned: its outputs are final; maybe reset the episode
+        terr_step = tb.terr;
+        phase = (auto_reset && (done || (tb.terr & caps))) ? PH_RESET : PH_END;
+    };
     auto retire = [&]() {  // a Game.step() of this lane has returned: the reference's control flow between two steps
         if (tb.stepped && tb.lstate == LS_DONE) {
             tb.finish_step();
+            if (phase == PH_RESET_PLAY) {                                          // game_env.py:24-27
+                if (--budget_reset < 0) tb.terr |= PK_TERR_ENV_CAP;
+                if (tb.terr) phase = PH_END;
+                else if (tb.flags & PK_FLAG_GAME_OVER) phase = PH_RESET;           // :27
+                else if (tb.active == 0) phase = PH_END;                           // :24
+                return;
+            }
             if (phase != PH_SEAT0 && --budget < 0) tb.terr |= PK_TERR_ENV_CAP;
-            if (tb.terr) { phase = PH_FIN; return; }
+            if (tb.terr) { step_finished(); return; }
             const bool over = (tb.flags & PK_FLAG_GAME_OVER) != 0, hand_now = (tb.flags & PK_FLAG_HAND_OVER) != 0;
             const bool seat0 = tb.active == 0;
             bool leave_hand_stretch = false;                                       // :41's loop is over (or never entered)
             if (phase == PH_SEAT0) {
                 done = over; hand = hand_now;
-                if (done || (tb.st_broken & 1)) { rew = tb.payoffs[0]; done = true; hand = true; phase = PH_FIN; }  // :37-39
+                if (done || (tb.st_broken & 1)) { rew = tb.payoffs[0]; done = true; hand = true; step_finished(); }  // :37-39
                 else if (!hand && !seat0) phase = PH_HAND;                         // :41
                 else leave_hand_stretch = true;
             } else if (phase == PH_HAND) {
@@ -291,24 +309,30 @@ __global__ void __launch_bounds__(PK_TABLE_BLOCK) k_env_step(const State *__rest
                 leave_hand_stretch = hand || seat0;
             } else {                                                               // PH_TURN: only `done` is re-read (:52)
                 done = over;
-                if (done || seat0) phase = PH_FIN;
+                if (done || seat0) step_finished();
             }
             if (leave_hand_stretch) {
                 if (hand) rew = tb.payoffs[0];                                     // :47
-                phase = (!done && !seat0) ? PH_TURN : PH_FIN;                      // :49
+                if (!done && !seat0) phase = PH_TURN; else step_finished();        // :49
             }
         }
     };
     for (;;) {
-        if (phase != PH_FIN && tb.lstate == LS_DONE) {                             // begin this lane's next Game.step()
-            const uint32_t vm = tb.valid_mask(high_bet);
-            const int a = phase == PH_SEAT0 ? action : pick_action(H, rng, table_id, tb.step_serial, vm, opp_policy);
-            tb.begin_step(H, a, high_bet);                                         // :35 / :43-44 / :51-52
+        if (phase != PH_END && tb.lstate == LS_DONE) {                             // begin this lane's next Game.step()
+            if (phase == PH_RESET) {                                               // game_env.py:23 / :27
+                tb.reset_state(H, 0); tb.deal(H, table_id);
+                phase = tb.active != 0 ? PH_RESET_PLAY : PH_END;                   // :24
+            }
+            if (phase != PH_END) {
+                const uint32_t vm = tb.valid_mask(high_bet);
+                const int a = phase == PH_SEAT0 ? action : pick_action(H, rng, table_id, tb.step_serial, vm, opp_policy);
+                tb.begin_step(H, a, high_bet);                                     // :35 / :43-44 / :51-52 / :25-26
+            }
         }
         tb.cursor();
         retire();
         const int parked = __popcll(__ballot(tb.lstate == LS_END));
-        const int runnable = __popcll(__ballot(phase != PH_FIN && tb.lstate == LS_DONE));
+        const int runnable = __popcll(__ballot(phase != PH_END && tb.lstate == LS_DONE));
         if (parked == 0 && runnable == 0) break;
         if (parked >= park || runnable == 0) {
             tb.end_block(H, t, table_id, lds, false);
@@ -316,16 +340,26 @@ __global__ void __launch_bounds__(PK_TABLE_BLOCK) k_env_step(const State *__rest
         }
     }
     if (!live) return;
-    if (!ok) {
-        reward[t] = 0.0; done_out[t] = 0; hand_out[t] = 0;
-        S.terr[t] = PK_TERR_INVALID_ACTION; terr[t] = PK_TERR_INVALID_ACTION;
-        return;
+    if (ok) {
+        tb.store(S, t);
+        tb.store_show(S.show, S.T, t, lds);
     }
-    tb.store(S, t);
-    tb.store_show(S.show, S.T, t, lds);
-    reward[t] = rew; done_out[t] = done; hand_out[t] = hand;                       // :53
-    S.valid[t] = (uint8_t)tb.valid_mask(high_bet);
-    S.terr[t] = (uint8_t)tb.terr; terr[t] = (uint8_t)tb.terr;
+    const uint32_t vmask = tb.valid_mask(high_bet);
+    const uint32_t te = ok ? (terr_step | tb.terr) : (uint32_t)PK_TERR_INVALID_ACTION;
+    reward[t] = ok ? rew : 0.0; done_out[t] = ok && done; hand_out[t] = ok && hand;  // :53
+    if (ok) S.valid[t] = (uint8_t)vmask;
+    S.terr[t] = (uint8_t)te; terr[t] = (uint8_t)te;
+    if (obs) {  // Game.StateView(active player), game.py:117-131, from registers (same row k_obs builds from HBM)
+        double *o = obs + (size_t)t * PK_OBS_DIM(N);
+        const int who = tb.active;
+        o[0] = who; o[1] = tb.turn; o[2] = tb.min_raise;
+        for (int a = 0; a < PK_NUM_MOVES; ++a) o[3 + a] = (vmask >> a) & 1;
+        double h0 = 0.0, h1 = 0.0;
+        PK_FOR(p, N) h0 = (who == p) ? (double)tb.card(5 + 2 * p) : h0; h1 = (who == p) ? (double)tb.card(6 + 2 * p) : h1; PK_END
+        o[10] = h0; o[11] = h1;                                                    // game.py:385-389
+        PK_FOR(c, 5) o[12 + c] = (tb.turn != 0 && c < tb.turn + 2) ? (double)tb.card(c) : -1.0; PK_END   // game.py:278
+        PK_FOR(p, N) o[17 + p] = tb.credits[p]; o[17 + N + p] = tb.bets[p]; o[17 + 2 * N + p] = tb.pending[p]; PK_END
+    }
 }
 
 // ---- exports: device-side conversion from the SoA/bitmask layout to the reference's table-major arrays
@@ -1005,7 +1039,20 @@ int pk_env_step_d(pk_handle *h, const int32_t *actions_d, int opp_policy, double
         return h ? h->fail(PK_E_INVALID_ARG, "pk_env_step_d: bad argument") : PK_E_INVALID_ARG;
     ON_DEVICE(h);
     FLUSH(h);
-    DISPATCH_N(h, k_env_step, table_grid(h), (const State *)h->d_S, h->hot, actions_d, opp_policy, reward_d, done_d, hand_d, terr_d, h->park);
+    DISPATCH_N(h, k_env_step, table_grid(h), (const State *)h->d_S, h->hot, actions_d, -1, opp_policy, 0, reward_d, done_d, hand_d, terr_d, (double *)nullptr, h->park);
+    HIPCHK(h, hipGetLastError());
+    return PK_OK;
+}
+
+int pk_env_step_fused_d(pk_handle *h, const int32_t *actions_d, int seat0_policy, int opp_policy, int auto_reset,
+                        double *reward_d, uint8_t *done_d, uint8_t *hand_d, uint8_t *terr_d, double *obs_d) {
+    if (!h || !reward_d || !done_d || !hand_d || !terr_d || opp_policy < 0 || opp_policy > 1 ||
+        (!actions_d && (seat0_policy < 0 || seat0_policy > 1)))
+        return h ? h->fail(PK_E_INVALID_ARG, "pk_env_step_fused_d: bad argument") : PK_E_INVALID_ARG;
+    ON_DEVICE(h);
+    FLUSH(h);
+    DISPATCH_N(h, k_env_step, table_grid(h), (const State *)h->d_S, h->hot, actions_d, actions_d ? -1 : seat0_policy, opp_policy,
+               auto_reset ? 1 : 0, reward_d, done_d, hand_d, terr_d, obs_d, h->park);
     HIPCHK(h, hipGetLastError());
     return PK_OK;
 }

@@ -238,3 +238,56 @@ def test_device_pointer_calls_order_against_a_producer_stream(HB, tmp_path):
     script.write_text(STREAM_SCRIPT % (root, os.path.join(root, "tests")))
     out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600, cwd=root)
     assert out.returncode == 0 and "STREAMS-OK" in out.stdout, (out.stdout[-2000:], out.stderr[-3000:])
+
+
+def test_fused_env_step_matches_the_separate_calls(HB, O):
+    """pk_env_step_fused_d = seat 0 picked in-kernel + PokerGameEnv.step + PokerGameEnv.reset() of the episodes that
+    ended + the observation row, in one launch: same rewards / flags / state as the oracle making those calls one after
+    the other, and the row equals pk_get_obs.  Also with the actions supplied (actions_d) and without auto-reset."""
+    import pokerl_amd
+    from pokerl_amd import _lib as L
+    from pokerl_amd.hipmem import DeviceBuffer
+    for T, N, opp in [(4096, 6, 0), (1000, 3, 1), (512, 9, 0)]:
+        D = 17 + 3 * N
+        env = pokerl_amd.VecPokerGameEnv(opp, num_tables=T, num_players=N, seed=91)
+        g, lib = env.game, L.lib()
+        o = O.OracleGame(T, N, seed=91)
+        env.reset(); o.env_reset(None, opp)
+        rew, done, hand, terr, obs, act = (DeviceBuffer(T * 8), DeviceBuffer(T), DeviceBuffer(T), DeviceBuffer(T),
+                                           DeviceBuffer(T * D * 8), DeviceBuffer(T * 4))
+        for s in range(80):
+            a = o.pick_actions(0)
+            ro, do, ho, eo = o.env_step(a, opp)
+            assert not eo.any()
+            if do.any():
+                o.env_reset(do, opp)
+            supplied = s % 3 == 2
+            if supplied:
+                act.upload(a)
+            L.check(lib.pk_env_step_fused_d(g._h, act.ptr if supplied else None, 0, opp, 1, rew.ptr, done.ptr, hand.ptr,
+                                            terr.ptr, obs.ptr), g._h)
+            g.sync()
+            assert GU.bits_equal(ro, rew.download(np.float64, T)), (N, s)
+            assert np.array_equal(do, done.download(np.uint8, T)) and np.array_equal(ho, hand.download(np.uint8, T))
+            assert not terr.download(np.uint8, T).any()
+            row = obs.download(np.float64, T * D).reshape(T, D)
+            assert GU.bits_equal(row, g.observations), (N, s)
+            if s % 10 == 0:
+                snap = o.snapshot()
+                assert GU.bits_equal(snap["credits"], g.credits) and GU.bits_equal(snap["cards"], g.deck)
+                assert np.array_equal(snap["step_serial"], g.step_serial) and np.array_equal(snap["active"], g.active_player)
+        # without auto-reset it is pk_env_step_d: finished episodes stay finished
+        a = o.pick_actions(0)
+        ro, do, ho, eo = o.env_step(a, opp)
+        L.check(lib.pk_env_step_fused_d(g._h, None, 0, opp, 0, rew.ptr, done.ptr, hand.ptr, terr.ptr, None), g._h)
+        g.sync()
+        assert GU.bits_equal(ro, rew.download(np.float64, T)) and np.array_equal(do, done.download(np.uint8, T))
+        assert GU.bits_equal(o.f64(O.F_CREDITS), g.credits) and np.array_equal(o.snapshot()["hand"], g.hand)
+        # an invalid supplied action leaves that table untouched and is reported
+        bad = np.full(T, -1, np.int32)
+        act.upload(bad)
+        before = g.credits.copy()
+        L.check(lib.pk_env_step_fused_d(g._h, act.ptr, 0, opp, 1, rew.ptr, done.ptr, hand.ptr, terr.ptr, None), g._h)
+        g.sync()
+        assert (terr.download(np.uint8, T) == 1).all() and GU.bits_equal(before, g.credits)
+        g.close()
