@@ -258,8 +258,9 @@ def main():
     ap.add_argument("--reps", type=int, default=0,
                     help="blocks of --steps per timed sample (0 = as many as make a sample >= --min-steps steps, so that a "
                          "short --steps is not one launch-latency sample)")
-    ap.add_argument("--min-steps", type=int, default=4096)
-    ap.add_argument("--samples", type=int, default=5, help="timed samples; the MEDIAN is reported")
+    ap.add_argument("--min-steps", type=int, default=131072,
+                    help="a timed sample runs at least this many steps per table (~0.4-0.6 s of GPU work at 65 536 x 6)")
+    ap.add_argument("--samples", type=int, default=7, help="timed samples; the MEDIAN is reported")
     ap.add_argument("--unfused", action="store_true", help="one launch per step (state round-trips HBM every step)")
     ap.add_argument("--mode", choices=["game", "env"], default="game")
     ap.add_argument("--env-unfused", action="store_true", help="--mode env with separate pick / step / reset / obs launches")
@@ -317,7 +318,7 @@ def main():
 
     # roofline leg (rank 0): HIP events on the handle's own stream around back-to-back launches of the dominant kernel
     kern_steps = min(args.chunk, K) if fused else 1
-    ev_reps = max(3, min(256, args.min_steps // kern_steps)) if fused else 1
+    ev_reps = max(3, min(256, 4096 // kern_steps)) if fused else 1
     ms_launch, _ = game.time_rollout(kern_steps if fused else min(K, 64), policy, True, fused, ev_reps)
     ctx.barrier()
     if ctx.rank == 0:

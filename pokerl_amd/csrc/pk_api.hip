@@ -147,6 +147,7 @@ __global__ void __launch_bounds__(PK_TABLE_BLOCK) PK_ROLLOUT_ATTR k_rollout(cons
     Table<N> tb;
     uint32_t owed = 0;
     Table<N>::stage_fresh(lds, H.fresh);
+    stage_nth(lds);
     if (live) { tb.load(S, t); tb.hands_this_step = (int)S.mid[t]; owed = S.owed[t] + (uint32_t)K; } else tb.blank();
     uint32_t steps = 0;
     bool alive = live;
@@ -171,7 +172,7 @@ __global__ void __launch_bounds__(PK_TABLE_BLOCK) PK_ROLLOUT_ATTR k_rollout(cons
         if (go) {
             uint32_t mask = tb.valid_mask(high_bet);
             tb.begin_step(H, policy == PK_POLICY_ALLIN ? (int)MV_ALL_IN
-                                                       : action_from_draw(ActionRing::half_of(word, tb.step_serial), mask), high_bet);
+                                                       : action_from_draw_lds(lds, ActionRing::half_of(word, tb.step_serial), mask), high_bet);
         }
         PK_PROF(tb.prof.lap(PF_ACTION);)
         tb.cursor();

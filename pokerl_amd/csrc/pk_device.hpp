@@ -374,6 +374,7 @@ struct Lds {  // per workgroup (= one wavefront); ~10 KB at N = 10
     uint32_t show[N][64];      // rankings of each lane's last showdown; written back by Table::store_show at kernel end
                                // (keeps global stores, and the vmcnt waits they drag along, out of the step loop)
     Fresh fresh;               // workgroup copy of *Hot::fresh (Table::stage_fresh), read with broadcast ds_reads
+    uint8_t nth[128][8];       // nth[mask][k] = k-th (0-based) set bit of a 7-bit valid-action mask (stage_nth)
 };
 
 struct ActionRng {  // one Philox block serves EIGHT consecutive steps of a table: 16-bit draws (RNG spec)
@@ -430,6 +431,19 @@ struct ActionRing {
         return ((uint32_t)step_serial & 1) ? (word >> 16) : (word & 0xffffu);
     }
 };
+// The same through the workgroup's LDS table (k_rollout): one byte read instead of a six-step select chain.
+template <typename LDS>
+__device__ __forceinline__ void stage_nth(LDS &lds) {  // call once from wave-uniform control flow
+    for (uint32_t m = threadIdx.x & (PK_WAVE - 1); m < 128; m += PK_WAVE) {
+        uint32_t rest = m;
+        for (int k = 0; k < 8; ++k) { lds.nth[m][k] = rest ? (uint8_t)(__ffs(rest) - 1) : 0; rest &= rest - 1; }
+    }
+    __syncthreads();
+}
+template <typename LDS>
+__device__ __forceinline__ int action_from_draw_lds(const LDS &lds, uint32_t r16, uint32_t mask) {
+    return lds.nth[mask & 127][__umul24(r16, (uint32_t)__popc(mask)) >> 16];
+}
 // k-th (0-based) valid action of the mask for a 16-bit draw r: k = (r * popcount(mask)) >> 16 (RNG spec)
 __device__ __forceinline__ int action_from_draw(uint32_t r16, uint32_t mask) {
     uint32_t k = __umul24(r16, (uint32_t)__popc(mask)) >> 16;

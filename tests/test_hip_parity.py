@@ -442,7 +442,7 @@ def test_bench_two_ranks_rehearsal(tmp_path):
     env = dict(os.environ, PK_BENCH_BACKEND="gloo", PK_BENCH_SAME_DEVICE="1", MASTER_ADDR="127.0.0.1")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                           "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"),
-                          "--gpus", "2", "--tables", "8192", "--steps", "256", "--warmup", "64", "--chunk", "64"],
+                          "--gpus", "2", "--tables", "8192", "--steps", "256", "--warmup", "64", "--chunk", "64", "--min-steps", "1024"],
                          capture_output=True, text=True, env=env, timeout=600, cwd=root)
     assert out.returncode == 0, out.stderr[-3000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
@@ -648,7 +648,7 @@ def test_bench_json_contract():
     assert r["scaling"] == "weak" and r["vs_baseline"] is None and r["dtype"] == "f64" and r["data"] == "synthetic"
     assert "workload" in r["config"] and "model" not in r["config"] and "BASELINE configs[2]" in r["config"]["workload"]
     assert abs(r["value"] - 65536 * 256 / (r["ms_per_step"] * 256 / 1e3)) / r["value"] < 1e-6
-    assert r["reps"] == 16 and r["samples"] == 5 and len(r["sample_seconds"]) == 5   # 16 blocks of 256 steps >= 4096 per sample
+    assert r["reps"] == 512 and r["samples"] == 7 and len(r["sample_seconds"]) == 7   # 512 blocks of 256 steps = 131 072 per sample
     rf = r["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
