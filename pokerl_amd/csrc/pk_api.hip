@@ -49,8 +49,8 @@ __global__ void __launch_bounds__(256) k_sum_counters(unsigned long long *slots,
 
 template <int N>
 __global__ void __launch_bounds__(PK_TABLE_BLOCK) k_reset(State S, Hot H, const uint8_t *mask, int dealer) {  // Game.reset, game.py:397-412
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= S.T) return;
+    int t = blockIdx.x * H.tpb + threadIdx.x;
+    if ((int)threadIdx.x >= H.tpb || t >= S.T) return;
     if (mask && !mask[t]) return;
     Table<N> tb;
     tb.load(S, t);
@@ -81,8 +81,8 @@ template <int N>
 __global__ void __launch_bounds__(PK_TABLE_BLOCK) k_step(const State *__restrict__ Sp, Hot H, const int32_t *actions, uint8_t *flags, uint8_t *terr) {  // Game.step, game.py:621-700
     const State &S = *Sp;
     __shared__ Lds<N> lds;
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = t < S.T;
+    const int t = blockIdx.x * H.tpb + threadIdx.x;
+    const bool live = (int)threadIdx.x < H.tpb && t < S.T;
     const uint32_t table_id = H.table_id_base + (uint32_t)t;
     Table<N> tb;
     if (live) tb.load(S, t); else tb.blank();
@@ -115,8 +115,8 @@ __global__ void __launch_bounds__(PK_TABLE_BLOCK) k_step(const State *__restrict
 
 template <int N>
 __global__ void __launch_bounds__(PK_TABLE_BLOCK) k_pick(State S, Hot H, int policy, int32_t *actions) {
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= S.T) return;
+    int t = blockIdx.x * H.tpb + threadIdx.x;
+    if ((int)threadIdx.x >= H.tpb || t >= S.T) return;
     ActionRng rng;
     actions[t] = pick_action(H, rng, H.table_id_base + (uint32_t)t, S.step_serial[t], S.valid[t], policy);
 }
@@ -137,12 +137,12 @@ __global__ void __launch_bounds__(PK_TABLE_BLOCK) k_pick(State S, Hot H, int pol
 #define PK_ROLLOUT_ATTR
 #endif
 template <int N>
-__global__ void __launch_bounds__(PK_TABLE_BLOCK) PK_ROLLOUT_ATTR k_rollout(const State *__restrict__ Sp, Hot H, int K, int policy, int auto_reset, int park, int endk, int clear_terr) {
+__global__ void __launch_bounds__(PK_TABLE_BLOCK) PK_ROLLOUT_ATTR k_rollout(const State *__restrict__ Sp, Hot H, int K, int policy, int auto_reset, int park, int slack, int clear_terr) {
     // Array bases by pointer (loaded only where the table is loaded / stored), loop scalars by value: see pk::Hot.
     const State &S = *Sp;
     __shared__ Lds<N> lds;
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = t < S.T;
+    const int t = blockIdx.x * H.tpb + threadIdx.x;
+    const bool live = (int)threadIdx.x < H.tpb && t < S.T;
     const uint32_t table_id = H.table_id_base + (uint32_t)t;
     Table<N> tb;
     uint32_t owed = 0;
@@ -153,9 +153,10 @@ __global__ void __launch_bounds__(PK_TABLE_BLOCK) PK_ROLLOUT_ATTR k_rollout(cons
     bool alive = live;
     ActionRing ring;
     double high_bet;
-    // lanes that can work at all in this launch; the launch ends once fewer than `quit` of them still have work
+    // lanes that can work at all in this launch; the launch ends once more than `slack` of them have run out of work
+    // (slack >= 64: never, i.e. run to completion)
     const int cap = __popcll(__ballot(live && (owed > 0 || tb.lstate == LS_END)));
-    const int quit = max(1, cap - (PK_WAVE - endk));
+    const int quit = max(1, cap - slack);
     PK_PROF(tb.prof.start();)
     auto retire = [&]() {  // a lane whose Game.step() has returned
         if (tb.stepped && tb.lstate == LS_DONE) {
@@ -209,8 +210,8 @@ template <int N>
 __global__ void __launch_bounds__(PK_TABLE_BLOCK) k_env_reset(const State *__restrict__ Sp, Hot H, const uint8_t *mask, int opp_policy, int park) {
     const State &S = *Sp;
     __shared__ Lds<N> lds;
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = t < S.T && (!mask || mask[t < S.T ? t : 0]);
+    const int t = blockIdx.x * H.tpb + threadIdx.x;
+    const bool live = (int)threadIdx.x < H.tpb && t < S.T && (!mask || mask[t < S.T ? t : 0]);
     const uint32_t table_id = H.table_id_base + (uint32_t)t;
     Table<N> tb;
     if (live) tb.load(S, t); else tb.blank();
@@ -264,8 +265,8 @@ template <int N>
 __global__ void __launch_bounds__(PK_TABLE_BLOCK) k_env_step(const State *__restrict__ Sp, Hot H, const int32_t *actions, int seat0_policy, int opp_policy, int auto_reset, double *reward, uint8_t *done_out, uint8_t *hand_out, uint8_t *terr, double *obs, int park) {
     const State &S = *Sp;
     __shared__ Lds<N> lds;
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = t < S.T;
+    const int t = blockIdx.x * H.tpb + threadIdx.x;
+    const bool live = (int)threadIdx.x < H.tpb && t < S.T;
     const uint32_t table_id = H.table_id_base + (uint32_t)t;
     Table<N> tb;
     if (live) tb.load(S, t); else tb.blank();
@@ -584,6 +585,7 @@ static thread_local std::string g_err;
 
 struct pk_handle {
     int device = 0, T = 0, N = 0, block = 64, dealer = 0;
+    int tpb = 64;   // tables per wavefront (Hot::tpb)
     int park = 40;  // lanes parked at end_hand before a wave runs end_block (k_rollout); tuning knob PK_PARK
     int endk = 48;  // a deferred rollout launch ends once fewer than this many of a wave's lanes have work; knob PK_ENDK
                     // (measured optimum 44..52 at 20 and at 512 steps per launch: tools/tune_sweep.py)
@@ -651,16 +653,19 @@ struct DeviceGuard {
         }                                                                                                        \
     } while (0)
 
-static inline int table_grid(const pk_handle *h) { return (h->T + h->block - 1) / h->block; }
+static inline int table_grid(const pk_handle *h) { return (h->T + h->tpb - 1) / h->tpb; }
+// parking threshold for waves that hold h->tpb tables instead of 64
+static inline int scaled_park(const pk_handle *h) { int p = (h->park * h->tpb + 63) / 64; return p < 1 ? 1 : p; }
 static inline int flat_grid(size_t n) { return (int)((n + 255) / 256); }
 
 // One fused rollout launch: every table owes k_steps more steps; the launch ends once fewer than `endk` lanes of a
 // wave have work left (endk == 1: runs to completion).
 static int launch_rollout(pk_handle *h, int k_steps, int policy, int auto_reset, int endk) {
-    DISPATCH_N(h, k_rollout, table_grid(h), (const State *)h->d_S, h->hot, k_steps, policy, auto_reset, h->park, endk,
+    const int slack = endk <= 1 ? PK_WAVE : ((PK_WAVE - endk) * h->tpb) / PK_WAVE;   // lanes allowed to idle before a launch ends
+    DISPATCH_N(h, k_rollout, table_grid(h), (const State *)h->d_S, h->hot, k_steps, policy, auto_reset, scaled_park(h), slack,
                h->pending ? 0 : 1);
     HIPCHK(h, hipGetLastError());
-    h->pending = endk > 1;
+    h->pending = slack < PK_WAVE;
     h->pend_policy = policy; h->pend_auto = auto_reset;
     return PK_OK;
 }
@@ -719,6 +724,12 @@ int pk_create(pk_handle **out, int device, int num_tables, int num_players, cons
     pk_handle *h = new pk_handle();
     h->device = device; h->T = num_tables; h->N = num_players; h->dealer = dealer;
     h->block = PK_TABLE_BLOCK;
+    {   // small batches: spread the tables over all 1 024 SIMDs of the chip (power of two, 1..64 tables per wave)
+        int tpb = 64;
+        while (tpb > 1 && (long)num_tables <= 1024L * (tpb / 2)) tpb /= 2;
+        if (const char *pk = getenv("PK_TPB")) { int v = atoi(pk); if (v >= 1 && v <= 64) tpb = v; }
+        h->tpb = tpb;
+    }
     if (const char *pk = getenv("PK_PARK")) { int v = atoi(pk); if (v >= 1 && v <= 64) h->park = v; }
     if (const char *pk = getenv("PK_ENDK")) { int v = atoi(pk); if (v >= 1 && v <= 64) h->endk = v; }
     auto bail = [&](int code) { g_err = h->err; pk_destroy(h); return code; };
@@ -734,7 +745,7 @@ int pk_create(pk_handle **out, int device, int num_tables, int num_players, cons
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     size_t obs = (size_t)PK_OBS_DIM(N) * 8;
     h->export_bytes = al(T * (obs > N * 8 ? obs : N * 8));
-    const size_t nwaves = (T + PK_TABLE_BLOCK - 1) / PK_TABLE_BLOCK;
+    const size_t nwaves = (T + (size_t)h->tpb - 1) / (size_t)h->tpb;
     size_t total = 4 * al(T * N * 8) + 4 * al(T * 8) + 4 * al(T * 4) + al(W * T * 4) + al(N * T * 4) + 2 * al(T) +
                    al(nwaves * PK_NUM_COUNTERS * 8) + al(PK_NUM_COUNTERS * 8) + al(PF_SLOTS * 8) + al(sizeof(State)) +
                    al(PK_MAX_PLAYERS * 8) + al(sizeof(Fresh)) + al(T * 4) + 5 * al(T) + al(T * 8) + h->export_bytes;
@@ -782,7 +793,7 @@ int pk_create(pk_handle **out, int device, int num_tables, int num_players, cons
         std::vector<uint8_t> valid(T, (uint8_t)((1u << MV_FOLD) | (1u << MV_CHECK) | (1u << MV_ALL_IN)));
         h->hot.fresh = d_fresh;
         h->hot.big_blind = big_blind; h->hot.small_blind = small_blind; h->hot.start_credits = d_start; h->hot.show = S.show;
-        h->hot.key0 = S.key0; h->hot.key1 = S.key1; h->hot.table_id_base = table_id_base; h->hot.T = num_tables;
+        h->hot.key0 = S.key0; h->hot.key1 = S.key1; h->hot.table_id_base = table_id_base; h->hot.T = num_tables; h->hot.tpb = h->tpb;
         h->hot.start_uniform = S.start_credits[0]; h->hot.start_is_uniform = 1;
         for (int i = 1; i < num_players; ++i) if (S.start_credits[i] != S.start_credits[0]) h->hot.start_is_uniform = 0;
         if (hipMemcpyAsync(d_start, S.start_credits, PK_MAX_PLAYERS * 8, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
@@ -1029,7 +1040,7 @@ int pk_env_reset_d(pk_handle *h, const uint8_t *mask_d, int opp_policy) {
     if (!h || opp_policy < 0 || opp_policy > 1) return h ? h->fail(PK_E_INVALID_ARG, "pk_env_reset_d: bad argument") : PK_E_INVALID_ARG;
     ON_DEVICE(h);
     FLUSH(h);
-    DISPATCH_N(h, k_env_reset, table_grid(h), (const State *)h->d_S, h->hot, mask_d, opp_policy, h->park);
+    DISPATCH_N(h, k_env_reset, table_grid(h), (const State *)h->d_S, h->hot, mask_d, opp_policy, scaled_park(h));
     HIPCHK(h, hipGetLastError());
     return PK_OK;
 }
@@ -1040,7 +1051,7 @@ int pk_env_step_d(pk_handle *h, const int32_t *actions_d, int opp_policy, double
         return h ? h->fail(PK_E_INVALID_ARG, "pk_env_step_d: bad argument") : PK_E_INVALID_ARG;
     ON_DEVICE(h);
     FLUSH(h);
-    DISPATCH_N(h, k_env_step, table_grid(h), (const State *)h->d_S, h->hot, actions_d, -1, opp_policy, 0, reward_d, done_d, hand_d, terr_d, (double *)nullptr, h->park);
+    DISPATCH_N(h, k_env_step, table_grid(h), (const State *)h->d_S, h->hot, actions_d, -1, opp_policy, 0, reward_d, done_d, hand_d, terr_d, (double *)nullptr, scaled_park(h));
     HIPCHK(h, hipGetLastError());
     return PK_OK;
 }
@@ -1053,7 +1064,7 @@ int pk_env_step_fused_d(pk_handle *h, const int32_t *actions_d, int seat0_policy
     ON_DEVICE(h);
     FLUSH(h);
     DISPATCH_N(h, k_env_step, table_grid(h), (const State *)h->d_S, h->hot, actions_d, actions_d ? -1 : seat0_policy, opp_policy,
-               auto_reset ? 1 : 0, reward_d, done_d, hand_d, terr_d, obs_d, h->park);
+               auto_reset ? 1 : 0, reward_d, done_d, hand_d, terr_d, obs_d, scaled_park(h));
     HIPCHK(h, hipGetLastError());
     return PK_OK;
 }

@@ -70,6 +70,8 @@ struct Hot {
     uint32_t *show;               // State::show
     uint32_t key0, key1, table_id_base;
     int T;
+    int tpb;  // tables per wavefront (= per workgroup): 64 when the batch fills the chip, fewer for small batches so that
+              // every SIMD gets a wave (a wave-step costs the same however many lanes are live, idle SIMDs cost nothing)
 };
 
 // ---------------------------------------------------------------------------------------------- helpers

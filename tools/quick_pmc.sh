@@ -7,7 +7,7 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/qpmc_$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 2048 --warmup 512 --chunk 2048 --samples 2 --no-cpu-baseline --no-evaluator $*"
+ARGS="--steps 2048 --warmup 512 --chunk 2048 --samples 2 --min-steps 2048 --no-cpu-baseline --no-evaluator $*"
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_THREAD_CYCLES_VALU SQ_INSTS_LDS --kernel-trace --output-format csv -d $OUT/pmc -- python3 $ROOT/bench.py $ARGS > $OUT/pmc.log 2>&1 || echo "pmc failed"
 python3 - $OUT <<'PY'
 import csv, glob, sys, collections
