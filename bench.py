@@ -345,8 +345,8 @@ def main():
             k_prof = w.get("steps_per_launch")
             if "SQ_INSTS_VALU" in pmc and "SQ_WAVES" in pmc and k_prof:
                 waves = pmc["SQ_WAVES"]
-                per_wave_step = pmc["SQ_INSTS_VALU"] / waves / k_prof       # wave-level VALU instructions per env-step batch of 64
-                valu_rate = per_wave_step * (n_local / 64.0) * kern_steps / (ms_launch * 1e-3)
+                per_wave_step = pmc["SQ_INSTS_VALU"] / waves / k_prof       # wave-level VALU instructions per step of one wave's tables
+                valu_rate = per_wave_step * waves * (n_local / float(args.tables)) * kern_steps / (ms_launch * 1e-3)
                 lanes = pmc.get("SQ_THREAD_CYCLES_VALU", 0) / (64.0 * pmc["SQ_ACTIVE_INST_VALU"]) if pmc.get("SQ_ACTIVE_INST_VALU") else None
                 roof["valu"] = {"bound": "valu-issue", "achieved": valu_rate, "peak": VALU_PEAK_WAVE_INSTS_PER_S,
                                 "unit": "wave-instr/s", "frac": valu_rate / VALU_PEAK_WAVE_INSTS_PER_S,
