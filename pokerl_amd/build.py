@@ -42,6 +42,17 @@ def build_prof_lib(verbose=False):
     return out
 
 
+def build_counts_lib(verbose=False):
+    """Diagnostic build that COUNTS wave-level events with global atomics (lanes served per end_block, side-pot passes and
+    their active lanes); its timings are meaningless.  tools/block_profile.py with PK_COUNTS=1; not shipped."""
+    out = os.path.join(HERE, "libpokerl_hip_counts.so")
+    cmd = [hipcc()] + FLAGS + ["-DPK_PROFILE", "-DPK_PROFILE_COUNTS"] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", out]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return out
+
+
 def build_lib(force=False, verbose=False):
     if not force and not stale():
         return LIB
@@ -57,3 +68,5 @@ if __name__ == "__main__":
     build_lib(force="--force" in sys.argv, verbose=True)
     if "--prof" in sys.argv:
         build_prof_lib(verbose=True)
+    if "--counts" in sys.argv:
+        build_counts_lib(verbose=True)

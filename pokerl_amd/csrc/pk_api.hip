@@ -94,7 +94,7 @@ __global__ void __launch_bounds__(PK_TABLE_BLOCK) k_step(const State *__restrict
     for (;;) {  // same flat shape as k_rollout / k_env_step: one instantiation of cursor and end_block
         if (todo) { tb.begin_step(H, action, high_bet); todo = false; }
         tb.cursor();
-        if (!__any(tb.lstate == LS_END)) break;
+        if (!__any(tb.parked())) break;
         tb.end_block(H, t, table_id, lds, false);
     }
     tb.finish_step();
@@ -180,14 +180,23 @@ __global__ void __launch_bounds__(PK_TABLE_BLOCK) PK_ROLLOUT_ATTR k_rollout(cons
         PK_PROF(tb.prof.count(PF_N_CURSOR);)
         retire();
         PK_PROF(tb.prof.lap(PF_CURSOR);)
-        const int parked = __popcll(__ballot(tb.lstate == LS_END));
+#ifndef PK_POT_WEIGHT
+#define PK_POT_WEIGHT 2   // halves: how much a showdown waiting in its side-pot loop counts towards `park`
+#endif
+        const int parked = __popcll(__ballot(tb.parked()));
+        const int pots = __popcll(__ballot(tb.lstate == LS_POT));
+        const int waiting = parked - pots + (pots * PK_POT_WEIGHT) / 2;
         const int runnable = __popcll(__ballot(alive && tb.lstate == LS_DONE && owed > 0));
         if (parked + runnable < quit) break;
-        if (parked >= park || runnable == 0) {
+        if (waiting >= park || runnable == 0) {
             tb.end_block(H, t, table_id, lds, auto_reset != 0);
             retire();
         }
     }
+    // LS_POT never survives a kernel.  A launch that ends early (deferred work) simply takes such a showdown back to
+    // LS_END: end_hand up to there is idempotent (the pending bets are committed and zero, payoffs are re-zeroed, the
+    // side pots restart from the unchanged committed bets), so the next launch redoes it together with its own arrivals.
+    if (tb.lstate == LS_POT) { tb.lstate = LS_END; tb.evals -= (uint32_t)__popc((tb.st_called | tb.st_allin) & Table<N>::FULL); }
     if (live) {
         tb.store(S, t);
         tb.store_show(S.show, S.T, t, lds);
@@ -238,7 +247,7 @@ __global__ void __launch_bounds__(PK_TABLE_BLOCK) k_env_reset(const State *__res
         }
         tb.cursor();
         retire();
-        const int parked = __popcll(__ballot(tb.lstate == LS_END));
+        const int parked = __popcll(__ballot(tb.parked()));
         const int runnable = __popcll(__ballot(more && tb.lstate == LS_DONE));
         if (parked == 0 && runnable == 0) break;
         if (parked >= park || runnable == 0) {
@@ -333,7 +342,7 @@ __global__ void __launch_bounds__(PK_TABLE_BLOCK) k_env_step(const State *__rest
         }
         tb.cursor();
         retire();
-        const int parked = __popcll(__ballot(tb.lstate == LS_END));
+        const int parked = __popcll(__ballot(tb.parked()));
         const int runnable = __popcll(__ballot(phase != PH_END && tb.lstate == LS_DONE));
         if (parked == 0 && runnable == 0) break;
         if (parked >= park || runnable == 0) {
@@ -793,7 +802,7 @@ int pk_create(pk_handle **out, int device, int num_tables, int num_players, cons
         std::vector<uint8_t> valid(T, (uint8_t)((1u << MV_FOLD) | (1u << MV_CHECK) | (1u << MV_ALL_IN)));
         h->hot.fresh = d_fresh;
         h->hot.big_blind = big_blind; h->hot.small_blind = small_blind; h->hot.start_credits = d_start; h->hot.show = S.show;
-        h->hot.key0 = S.key0; h->hot.key1 = S.key1; h->hot.table_id_base = table_id_base; h->hot.T = num_tables; h->hot.tpb = h->tpb;
+        h->hot.key0 = S.key0; h->hot.key1 = S.key1; h->hot.table_id_base = table_id_base; h->hot.T = num_tables; h->hot.tpb = h->tpb; h->hot.prof = S.prof;
         h->hot.start_uniform = S.start_credits[0]; h->hot.start_is_uniform = 1;
         for (int i = 1; i < num_players; ++i) if (S.start_credits[i] != S.start_credits[0]) h->hot.start_is_uniform = 0;
         if (hipMemcpyAsync(d_start, S.start_credits, PK_MAX_PLAYERS * 8, hipMemcpyHostToDevice, h->stream) != hipSuccess ||

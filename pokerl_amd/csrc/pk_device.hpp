@@ -70,6 +70,7 @@ struct Hot {
     uint32_t *show;               // State::show
     uint32_t key0, key1, table_id_base;
     int T;
+    unsigned long long *prof;  // State::prof (diagnostic builds only)
     int tpb;  // tables per wavefront (= per workgroup): 64 when the batch fills the chip, fewer for small batches so that
               // every SIMD gets a wave (a wave-step costs the same however many lanes are live, idle SIMDs cost nothing)
 };
@@ -344,7 +345,14 @@ __device__ __forceinline__ uint32_t eval7_distinct(const uint32_t (&c)[7]) {
 //   LS_END   end_hand + setup_hand (game.py:453-539, 414-451): lanes park here until no lane is in SCAN/TURN, then
 //            the whole wave runs the block together; showdown hands of all parked lanes are compacted through LDS and
 //            evaluated one hand per lane (eval7_distinct).
-enum : int { LS_DONE = 0, LS_SCAN = 1, LS_END = 3 };
+//   LS_POT   a showdown whose side-pot loop (game.py:498-525) needs ANOTHER full iteration (18 % of showdowns under
+//            random agents: three or more players all-in for different amounts).  end_block runs one full iteration
+//            of that loop per call (plus the closing `num_potential_winners == 1` pass, :500-505, which 67 % of
+//            showdowns end with) for the showdowns that arrive and the ones still in the loop together, instead of
+//            iterating until the slowest arrival is done: that took 3.8 wave-iterations of the ~300-instruction body
+//            with 14 of 64 lanes active, a third of all instructions of the kernel.  Never survives a kernel: the
+//            complete kernels run until nothing is parked, k_rollout takes it back to LS_END when it ends early.
+enum : int { LS_DONE = 0, LS_SCAN = 1, LS_POT = 2, LS_END = 3 };
 #ifndef PK_WAVE
 #define PK_WAVE 64  // lanes per wavefront on gfx950 (tools/host_sim builds this header with 1)
 #endif
@@ -352,13 +360,22 @@ enum : int { LS_DONE = 0, LS_SCAN = 1, LS_END = 3 };
 // Diagnostic build only (-DPK_PROFILE, libpokerl_hip_prof.so; never the shipped library): per-wave cycle stamps
 // (s_memtime) around the blocks of the step machine, summed into State::prof.  Shares, not run times, are read from it.
 enum : int { PF_ACTION = 0, PF_CURSOR = 1, PF_END_PRE = 2, PF_EVAL = 3, PF_SIDEPOT = 4, PF_SETUP = 5, PF_DEAL = 6, PF_OTHER = 7,
-             PF_N_CURSOR = 8, PF_N_END = 9, PF_N_EVALPASS = 10, PF_N_SIDEPOT = 11, PF_SLOTS = 12 };
+             PF_N_CURSOR = 8, PF_N_END = 9, PF_N_EVALPASS = 10, PF_N_SIDEPOT = 11,
+             PF_N_SIDEPOT_LANES = 12, PF_N_END_LANES = 13, PF_SLOTS = 16 };
 #ifdef PK_PROFILE
 struct Prof {
     unsigned long long acc[PF_SLOTS] = {0}, t0 = 0;
     __device__ __forceinline__ void start() { t0 = __builtin_readcyclecounter(); }
     __device__ __forceinline__ void lap(int slot) { unsigned long long t = __builtin_readcyclecounter(); acc[slot] += t - t0; t0 = t; }
     __device__ __forceinline__ void count(int slot, unsigned n = 1) { acc[slot] += n; }
+    // wave-level event inside divergent control flow: counted once (by the first active lane), plus the active lanes
+    // (global atomics: the build that uses this is for COUNTS only, its timings are meaningless)
+    __device__ __forceinline__ void count_wave(unsigned long long *dst, int slot_events, int slot_lanes) {
+        const unsigned long long act = __ballot(1);
+        if ((int)(threadIdx.x & 63) == __ffsll((long long)act) - 1) {
+            atomicAdd(&dst[slot_events], 1ull); atomicAdd(&dst[slot_lanes], (unsigned long long)__popcll(act));
+        }
+    }
     __device__ __forceinline__ void flush(unsigned long long *dst) {
         if ((threadIdx.x & 63) == 0) for (int i = 0; i < PF_SLOTS; ++i) atomicAdd(&dst[i], acc[i]);
     }
@@ -472,6 +489,11 @@ struct Table {
     int active, dealer, sb, bb, turn, hand;
     uint64_t hand_serial, step_serial;
     uint32_t cards[W];
+    // showdown in progress (valid from end_hand's showdown branch until its side-pot loop is over: lstate LS_POT between calls)
+    double pot_wb[N];            // `bets` working copy of game.py:485
+    uint32_t pot_hv[N];          // hand_rankings with processed seats set to NONE (:522)
+    uint32_t pot_todo;           // showdown seats not yet processed (:495-496)
+    int pot_npw;                 // num_potential_winners (:472, :525)
     // per-step machine state
     int lstate, current, hands_this_step;
     uint32_t flags, terr, stepped;  // stepped: 1 while a Game.step is in flight on this lane
@@ -499,6 +521,8 @@ struct Table {
         // anything else: the host flushes deferred work before every other kernel).
         current = (cur >> 20) & 0xf; lstate = (cur >> 24) & 3; foldout = (cur >> 26) & 1; stepped = (cur >> 27) & 1;
         flags = (cur >> 28) & 7; hands_this_step = 0; terr = 0;
+        PK_FOR(p, N) pot_wb[p] = 0.0; pot_hv[p] = NONE_V; PK_END
+        pot_todo = 0; pot_npw = 0;
         evals = 0; games = 0; hands = 0; seen = 0; showed = false;
     }
     // A lane with no table (t >= T) still walks the wave-uniform control flow: give it inert, well-defined state.
@@ -507,6 +531,8 @@ struct Table {
         min_raise = 0.0; st_active = st_called = st_allin = 0; st_broken = FULL;
         active = dealer = sb = bb = turn = hand = 0; hand_serial = step_serial = 0;
         PK_FOR(w, W) cards[w] = 0; PK_END
+        PK_FOR(p, N) pot_wb[p] = 0.0; pot_hv[p] = NONE_V; PK_END
+        pot_todo = 0; pot_npw = 0;
         idle();
         evals = 0; games = 0; hands = 0; seen = 0; showed = false;
     }
@@ -728,15 +754,20 @@ struct Table {
         foldout = false;
     }
 
+    __device__ __forceinline__ bool parked() const { return lstate == LS_END || lstate == LS_POT; }
+
     // end_hand + setup_hand for every lane parked at LS_END (game.py:453-539), executed by the WHOLE wave.
     // auto_reset: a finished game (or a table that hit PK_HAND_CAP, which the reference would never leave) is
     // Game.reset() on the spot, as the rollout/bench loop does on the host side of the reference.
     __device__ __forceinline__ void end_block(const Hot &S, int t, uint32_t table_id, Lds<N> &lds, bool auto_reset) {
         const bool e = lstate == LS_END;
+        const bool resumed = lstate == LS_POT;
         PK_PROF(prof.lap(PF_OTHER); prof.count(PF_N_END);)
+#ifdef PK_PROFILE_COUNTS
+        if (e) { const unsigned long long act = __ballot(1); if ((int)(threadIdx.x & 63) == __ffsll((long long)act) - 1) atomicAdd(&S.prof[PF_N_END_LANES], (unsigned long long)__popcll(act)); }
+#endif
         bool sd = false, nowin = false;
         uint32_t showdown = 0;
-        int npw = 0;
         if (e) {
             PK_FOR(p, N)                                          // :457-461, :468
                 bets[p] = bets[p] + pending[p]; credits[p] = credits[p] - pending[p];
@@ -744,7 +775,7 @@ struct Table {
              PK_END
             min_raise = 0.0;
             uint32_t pw = (st_active | st_called | st_allin) & FULL;               // :471 (not BROKEN, not FOLDED)
-            npw = __popc(pw);                                                      // :472
+            const int npw = __popc(pw);                                            // :472
             nowin = npw <= 0;                                                      // :473
             if (npw == 1) {                                                        // :475-480
                 int winner = __ffs(pw) - 1;
@@ -756,10 +787,11 @@ struct Table {
             } else if (npw > 1) {
                 sd = true;
                 showdown = (st_called | st_allin) & FULL;                          // :488, :496
+                pot_npw = npw;
             }
         }
         PK_PROF(prof.lap(PF_END_PRE);)
-        // ---- showdown hands of all parked lanes -> LDS queue -> one hand per lane (game.py:488-489)
+        // ---- showdown hands of all arriving lanes -> LDS queue -> one hand per lane (game.py:488-489)
         const int lane = threadIdx.x & 63;
         uint32_t total = 0, my_base[N];
         PK_FOR(p, N)
@@ -767,8 +799,6 @@ struct Table {
             my_base[p] = total + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
             total += (uint32_t)__popcll(bal);
          PK_END
-        uint32_t hv[N];
-        PK_FOR(p, N) hv[p] = NONE_V; PK_END
         if (total) {  // wave-uniform
             PK_FOR(p, N)
                 if ((showdown >> p) & 1) {                                         // hand = deck[:5] + hole cards (:394-395)
@@ -787,58 +817,71 @@ struct Table {
                 }
             }
             __syncthreads();
-            PK_FOR(p, N) hv[p] = ((showdown >> p) & 1) ? lds.res[lane * N + p] : NONE_V; PK_END
+            if (sd) { PK_FOR(p, N) pot_hv[p] = ((showdown >> p) & 1) ? lds.res[lane * N + p] : NONE_V; PK_END }
             __syncthreads();  // the queue is reused by the next end_block of this wave
             evals += __popc(showdown);
+        } else if (sd) {
+            PK_FOR(p, N) pot_hv[p] = NONE_V; PK_END                                // potential winners, none of them CALLED / ALL_IN
         }
         PK_PROF(prof.lap(PF_EVAL);)
         if (sd) {
-            double wb[N];                                                          // :485
             PK_FOR(p, N)
-                wb[p] = bets[p];
-                hv[p] = ((showdown >> p) & 1) ? hv[p] : NONE_V;
-                lds.show[p][lane] = hv[p];
+                pot_wb[p] = bets[p];                                               // :485
+                lds.show[p][lane] = pot_hv[p];
              PK_END
             showed = true;
-            uint32_t todo = showdown;                                              // :495-496 argsort(bets) filtered, stable
-            while (todo) {                                                         // :498
-                PK_PROF(prof.count(PF_N_SIDEPOT);)
-                bool any_pos = false;
-                PK_FOR(p, N) any_pos = any_pos || !(wb[p] <= 0.0); PK_END
-                if (!any_pos) break;                                               // :499 (independent of which seat is next)
+            pot_todo = showdown;                                                   // :495-496 argsort(bets) filtered, stable
+        }
+        // ---- the side-pot loop (:498-525) for the arriving showdowns and the ones still in it: per call ONE pass of
+        //      the general body plus, if that leaves a single potential winner, the closing pass of :500-505.
+        bool pot_over = false;
+        if (sd || resumed) {
+#ifdef PK_PROFILE_COUNTS
+            prof.count_wave(S.prof, PF_N_SIDEPOT, PF_N_SIDEPOT_LANES);
+#endif
+            bool left = false;                                                     // any bet still > 0 (:499)
+            PK_FOR(p, N) left = left || !(pot_wb[p] <= 0.0); PK_END
+            if (pot_todo != 0 && left && pot_npw != 1) {                           // a general pass (:507-525)
                 int player = 0; double best = 0.0, max_bet = 0.0; bool have = false;
                 PK_FOR(p, N)                                                       // next seat in ascending ORIGINAL-bet order
-                    bool cand = (todo >> p) & 1;
+                    bool cand = (pot_todo >> p) & 1;
                     bool better = cand && (!have || bets[p] < best);
-                    player = better ? p : player; best = better ? bets[p] : best; max_bet = better ? wb[p] : max_bet;  // :508
+                    player = better ? p : player; best = better ? bets[p] : best; max_bet = better ? pot_wb[p] : max_bet;  // :508
                     have = have || cand;
                 PK_END
-                todo &= ~(1u << player);
-                if (npw == 1) {                                                    // :500-505
-                    double s = np_sum<N>(wb);
-                    PK_FOR(p, N) payoffs[p] = (p == player) ? payoffs[p] + s : payoffs[p]; PK_END
-                    break;
-                }
+                pot_todo &= ~(1u << player);
                 double mb[N];                                                      // :509 np.clip(bets, 0, max_bet)
-                PK_FOR(p, N) double x = wb[p]; x = (x < 0.0) ? 0.0 : x; x = (x > max_bet) ? max_bet : x; mb[p] = x; PK_END
+                PK_FOR(p, N) double x = pot_wb[p]; x = (x < 0.0) ? 0.0 : x; x = (x > max_bet) ? max_bet : x; mb[p] = x; PK_END
                 int nw;
-                uint32_t win = compare_rankings<N>(hv, nw);                        // :512
+                uint32_t win = compare_rankings<N>(pot_hv, nw);                    // :512
                 double s = np_sum<N>(mb);
                 // :515 single winner: += s.  :516 split: += s*onehot/k, i.e. s/k for winners ((s*1.0)/k == s/k) and
                 // (s*0.0)/k == +0.0 for the rest (s >= 0), which leaves a non-negative payoff unchanged bit for bit.
                 double share = (nw == 2) ? s * 0.5 : s;                           // s / 2 == s * 0.5 exactly
                 if (nw > 2) share = s / (double)nw;                                // real division only for 3+-way ties
+                left = false;
                 PK_FOR(p, N)
                     payoffs[p] = ((win >> p) & 1) ? payoffs[p] + share : payoffs[p];
-                    hv[p] = (p == player) ? NONE_V : hv[p];                        // :522
-                    wb[p] = wb[p] - mb[p];                                         // :523
+                    pot_hv[p] = (p == player) ? NONE_V : pot_hv[p];                // :522
+                    pot_wb[p] = pot_wb[p] - mb[p];                                 // :523
+                    left = left || !(pot_wb[p] <= 0.0);
                 PK_END
-                npw -= 1;                                                          // :525
+                pot_npw -= 1;                                                      // :525
             }
-            PK_FOR(p, N) credits[p] = credits[p] + payoffs[p]; PK_END  // :528
+            // what the next pass of the loop would do: stop (:498, :499), hand everything left to the last potential
+            // winner (:500-505; with one potential winner left at most one seat is left in `todo`), or go on
+            if (pot_todo == 0 || !left) pot_over = true;
+            else if (pot_npw == 1) {
+                const int player = __ffs(pot_todo) - 1;
+                double s = np_sum<N>(pot_wb);
+                PK_FOR(p, N) payoffs[p] = (p == player) ? payoffs[p] + s : payoffs[p]; PK_END
+                pot_over = true;
+            }
+            if (pot_over) { PK_FOR(p, N) credits[p] = credits[p] + payoffs[p]; PK_END }  // :528
+            else lstate = LS_POT;                                                  // another general pass, in the next call
         }
         PK_PROF(prof.lap(PF_SIDEPOT);)
-        if (e) {
+        if ((e && !sd) || pot_over) {
             if (nowin) {                                                           // :473 assert (state left as the reference leaves it)
                 terr |= PK_TERR_NO_WINNER; lstate = LS_DONE;
             } else {
@@ -885,7 +928,7 @@ struct Table {
         for (;;) {
             cursor();
             PK_PROF(prof.lap(PF_CURSOR); prof.count(PF_N_CURSOR);)
-            if (!__any(lstate == LS_END)) break;
+            if (!__any(parked())) break;
             end_block(S, t, table_id, lds, auto_reset);
         }
         PK_PROF(prof.lap(PF_OTHER);)

@@ -7,7 +7,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("POKERL_HIP_LIB", os.path.join(ROOT, "pokerl_amd", "libpokerl_hip_prof.so"))
+os.environ.setdefault("POKERL_HIP_LIB", os.path.join(ROOT, "pokerl_amd", "libpokerl_hip_counts.so" if os.environ.get("PK_COUNTS") else "libpokerl_hip_prof.so"))
 import numpy as np  # noqa: E402
 import pokerl_amd  # noqa: E402
 from pokerl_amd import _lib as L  # noqa: E402
@@ -20,7 +20,7 @@ g.reset()
 g.rollout(K, policy)
 lib = L.lib()
 lib.pk_prof_read.argtypes = [C.c_void_p, C.c_void_p]
-buf = np.zeros(12, np.uint64)
+buf = np.zeros(16, np.uint64)
 lib.pk_prof_read(g._h, L.ptr(buf))
 launches = 4
 ms, c = g.time_rollout(K, policy, True, True, launches)
@@ -34,3 +34,7 @@ for i, n in enumerate(names):
 print("  cursor passes/step %.2f  end_blocks/step %.2f  eval passes/step %.2f  sidepot iters/step %.2f" % tuple(
     buf[8 + i] / waves / launches / K for i in range(4)))
 print("  total cycles/wave-step %.0f" % (tot / waves / launches / K))
+if buf[11]:
+    ends = float(buf[9])
+    print("  per end_block: %.1f lanes served; side-pot loop %.2f wave-iterations with %.1f lanes active each" % (
+        buf[13] / ends, buf[11] / ends, buf[12] / max(1.0, float(buf[11]))))
