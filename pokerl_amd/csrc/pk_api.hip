@@ -136,8 +136,8 @@ __global__ void __launch_bounds__(PK_TABLE_BLOCK) k_pick(State S, Hot H, int pol
 #ifndef PK_ROLLOUT_ATTR
 #define PK_ROLLOUT_ATTR
 #endif
-template <int N>
-__global__ void __launch_bounds__(PK_TABLE_BLOCK) PK_ROLLOUT_ATTR k_rollout(const State *__restrict__ Sp, Hot H, int K, int policy, int auto_reset, int park, int slack, int clear_terr) {
+template <int N, bool ONE_PASS>
+__device__ __forceinline__ void rollout_body(const State *__restrict__ Sp, const Hot &H, int K, int policy, int auto_reset, int park, int slack, int clear_terr) {
     // Array bases by pointer (loaded only where the table is loaded / stored), loop scalars by value: see pk::Hot.
     const State &S = *Sp;
     __shared__ Lds<N> lds;
@@ -189,7 +189,7 @@ __global__ void __launch_bounds__(PK_TABLE_BLOCK) PK_ROLLOUT_ATTR k_rollout(cons
         const int runnable = __popcll(__ballot(alive && tb.lstate == LS_DONE && owed > 0));
         if (parked + runnable < quit) break;
         if (waiting >= park || runnable == 0) {
-            tb.end_block(H, t, table_id, lds, auto_reset != 0);
+            tb.template end_block<ONE_PASS>(H, t, table_id, lds, auto_reset != 0);
             retire();
         }
     }
@@ -206,6 +206,19 @@ __global__ void __launch_bounds__(PK_TABLE_BLOCK) PK_ROLLOUT_ATTR k_rollout(cons
     }
     wave_add_counters(S, steps, tb.hands, tb.evals, tb.games);  // every lane takes part in the shuffles
     PK_PROF(tb.prof.flush(S.prof);)
+}
+
+// N >= 8 seats in a batch of one wave per SIMD: the whole register file is there to be used (a cap would spill) ...
+template <int N>
+__global__ void __launch_bounds__(PK_TABLE_BLOCK) PK_ROLLOUT_ATTR k_rollout(const State *__restrict__ Sp, Hot H, int K, int policy, int auto_reset, int park, int slack, int clear_terr) {
+    rollout_body<N, true>(Sp, H, K, policy, auto_reset, park, slack, clear_terr);
+}
+// ... everything else: register allocation capped at 168 for three waves per SIMD.  No spill up to N = 7 and marginally
+// faster even at one wave per SIMD; with several waves per SIMD (batches beyond 65 536 tables) the third wave is worth
+// +19 % at 1 M x 6 (44.0 G env-steps/s) and +14 % at 524 288 x 9 in spite of 92 B of scratch per lane.
+template <int N>
+__global__ void __launch_bounds__(PK_TABLE_BLOCK, 3) k_rollout_occ3(const State *__restrict__ Sp, Hot H, int K, int policy, int auto_reset, int park, int slack, int clear_terr) {
+    rollout_body<N, true>(Sp, H, K, policy, auto_reset, park, slack, clear_terr);
 }
 
 // PokerGameEnv.reset / .step (envs/game_env.py:20-29, :31-53) share k_rollout's shape: ONE flat loop in which every
@@ -595,6 +608,7 @@ static thread_local std::string g_err;
 struct pk_handle {
     int device = 0, T = 0, N = 0, block = 64, dealer = 0;
     int tpb = 64;   // tables per wavefront (Hot::tpb)
+    bool occ3 = true;  // k_rollout_occ3 (registers capped for 3 waves per SIMD) vs k_rollout; knob PK_OCC3
     int park = 40;  // lanes parked at end_hand before a wave runs end_block (k_rollout); tuning knob PK_PARK
     int endk = 48;  // a deferred rollout launch ends once fewer than this many of a wave's lanes have work; knob PK_ENDK
                     // (measured optimum 44..52 at 20 and at 512 steps per launch: tools/tune_sweep.py)
@@ -671,8 +685,12 @@ static inline int flat_grid(size_t n) { return (int)((n + 255) / 256); }
 // wave have work left (endk == 1: runs to completion).
 static int launch_rollout(pk_handle *h, int k_steps, int policy, int auto_reset, int endk) {
     const int slack = endk <= 1 ? PK_WAVE : ((PK_WAVE - endk) * h->tpb) / PK_WAVE;   // lanes allowed to idle before a launch ends
-    DISPATCH_N(h, k_rollout, table_grid(h), (const State *)h->d_S, h->hot, k_steps, policy, auto_reset, scaled_park(h), slack,
-               h->pending ? 0 : 1);
+    if (!h->occ3)
+        DISPATCH_N(h, k_rollout, table_grid(h), (const State *)h->d_S, h->hot, k_steps, policy, auto_reset, scaled_park(h), slack,
+                   h->pending ? 0 : 1);
+    else
+        DISPATCH_N(h, k_rollout_occ3, table_grid(h), (const State *)h->d_S, h->hot, k_steps, policy, auto_reset, scaled_park(h), slack,
+                   h->pending ? 0 : 1);
     HIPCHK(h, hipGetLastError());
     h->pending = slack < PK_WAVE;
     h->pend_policy = policy; h->pend_auto = auto_reset;
@@ -738,6 +756,8 @@ int pk_create(pk_handle **out, int device, int num_tables, int num_players, cons
         while (tpb > 1 && (long)num_tables <= 1024L * (tpb / 2)) tpb /= 2;
         if (const char *pk = getenv("PK_TPB")) { int v = atoi(pk); if (v >= 1 && v <= 64) tpb = v; }
         h->tpb = tpb;
+        h->occ3 = num_players <= 7 || num_tables > 2 * 65536;   // see k_rollout_occ3
+        if (const char *pk = getenv("PK_OCC3")) h->occ3 = atoi(pk) != 0;
     }
     if (const char *pk = getenv("PK_PARK")) { int v = atoi(pk); if (v >= 1 && v <= 64) h->park = v; }
     if (const char *pk = getenv("PK_ENDK")) { int v = atoi(pk); if (v >= 1 && v <= 64) h->endk = v; }

@@ -362,6 +362,23 @@ def test_all_player_counts_fused_vs_oracle(HB, O):
             assert_same(o.snapshot(), h.snapshot(), "N=%d policy=%d" % (N, policy))
 
 
+@pytest.mark.parametrize("occ3", ["0", "1"])
+def test_both_rollout_kernels_vs_oracle(HB, O, monkeypatch, occ3):
+    """k_rollout (uncapped registers) and k_rollout_occ3 (capped for three waves per SIMD; spills to scratch at N >= 8)
+    are picked by batch shape; PK_OCC3 forces either, and both must be bit-exact for every seat count."""
+    monkeypatch.setenv("PK_OCC3", occ3)
+    for N, T, policy, K in [(6, 5000, 0, 150), (9, 3000, 1, 60), (10, 2000, 0, 120), (8, 140000, 0, 10), (2, 70000, 0, 40)]:
+        o = O.OracleGame(T, N, seed=1000 + N)
+        h = HB(T, N, seed=1000 + N)
+        o.reset(); h.reset()
+        for k in (K // 3, K - K // 3):
+            h.g.rollout(k, policy, True, True, counters=False)        # deferred launches too
+        co, _ = o.rollout(K, policy, True)
+        assert co.tolist() == h.rollout(0, policy, True).tolist(), (N, T, occ3)
+        assert_same(o.snapshot(), h.snapshot(), "N=%d T=%d occ3=%s" % (N, T, occ3))
+        h.g.close()
+
+
 def test_hand_cap_rule(HB, O):
     """start_credits = 0: every seat is re-dealt all-in with no chips for ever -- the reference's Game.step would never
     return.  step() reports PK_TERR_HAND_CAP; a rollout with auto_reset treats it as a finished game."""
