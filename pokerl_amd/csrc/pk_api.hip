@@ -208,16 +208,20 @@ __device__ __forceinline__ void rollout_body(const State *__restrict__ Sp, const
     PK_PROF(tb.prof.flush(S.prof);)
 }
 
-// N >= 8 seats in a batch of one wave per SIMD: the whole register file is there to be used (a cap would spill) ...
+// Batches of up to two waves per SIMD: registers capped at 256 (no instantiation needs more; N = 10 uses 245), which
+// also steers the max-ILP scheduler to a slightly better schedule than an unlimited budget (24.1 vs 23.4 G at 65 536 x 6) ...
 template <int N>
-__global__ void __launch_bounds__(PK_TABLE_BLOCK) PK_ROLLOUT_ATTR k_rollout(const State *__restrict__ Sp, Hot H, int K, int policy, int auto_reset, int park, int slack, int clear_terr) {
+__global__ void __launch_bounds__(PK_TABLE_BLOCK, 2) PK_ROLLOUT_ATTR k_rollout(const State *__restrict__ Sp, Hot H, int K, int policy, int auto_reset, int park, int slack, int clear_terr) {
     rollout_body<N, true>(Sp, H, K, policy, auto_reset, park, slack, clear_terr);
 }
-// ... everything else: register allocation capped at 168 for three waves per SIMD.  No spill up to N = 7 and marginally
-// faster even at one wave per SIMD; with several waves per SIMD (batches beyond 65 536 tables) the third wave is worth
-// +19 % at 1 M x 6 (44.0 G env-steps/s) and +14 % at 524 288 x 9 in spite of 92 B of scratch per lane.
+// ... larger batches: capped at 168 for three waves per SIMD (no spill up to N = 7).  The third wave is worth +19 % at
+// 1 M x 6 (44.0 G env-steps/s) and +14 % at 524 288 x 9 in spite of 92 B of scratch per lane; a cap of 128 (four waves)
+// spills too much (18.4 G at 65 536 x 6).
+#ifndef PK_OCC_CAP
+#define PK_OCC_CAP 3
+#endif
 template <int N>
-__global__ void __launch_bounds__(PK_TABLE_BLOCK, 3) k_rollout_occ3(const State *__restrict__ Sp, Hot H, int K, int policy, int auto_reset, int park, int slack, int clear_terr) {
+__global__ void __launch_bounds__(PK_TABLE_BLOCK, PK_OCC_CAP) k_rollout_occ3(const State *__restrict__ Sp, Hot H, int K, int policy, int auto_reset, int park, int slack, int clear_terr) {
     rollout_body<N, true>(Sp, H, K, policy, auto_reset, park, slack, clear_terr);
 }
 
@@ -756,7 +760,7 @@ int pk_create(pk_handle **out, int device, int num_tables, int num_players, cons
         while (tpb > 1 && (long)num_tables <= 1024L * (tpb / 2)) tpb /= 2;
         if (const char *pk = getenv("PK_TPB")) { int v = atoi(pk); if (v >= 1 && v <= 64) tpb = v; }
         h->tpb = tpb;
-        h->occ3 = num_players <= 7 || num_tables > 2 * 65536;   // see k_rollout_occ3
+        h->occ3 = num_tables > 2 * 65536;   // see k_rollout_occ3
         if (const char *pk = getenv("PK_OCC3")) h->occ3 = atoi(pk) != 0;
     }
     if (const char *pk = getenv("PK_PARK")) { int v = atoi(pk); if (v >= 1 && v <= 64) h->park = v; }
