@@ -166,29 +166,31 @@ __device__ __forceinline__ void rollout_body(const State *__restrict__ Sp, const
             else { ++steps; tb.games += tb.flags & PK_FLAG_GAME_OVER; }
         }
     };
+#ifndef PK_BET_PASSES
+#define PK_BET_PASSES 4   // betting passes between two looks at the parked lanes: end_block then serves what four passes
+#endif                    // have parked (1: 23.8 G, 2: 25.1 G, 3: 24.4 G, 4: 25.6 G, 6: 24.7 G, 8: 23.2 G at 65 536 x 6)
     for (;;) {
-        const bool go = alive && tb.lstate == LS_DONE && owed > 0;
-        uint32_t word = 0;
-        if (policy == PK_POLICY_RANDOM) word = ring.draw16(lds, H, table_id, tb.step_serial, go);   // wave-uniform
-        if (go) {
-            uint32_t mask = tb.valid_mask(high_bet);
-            tb.begin_step(H, policy == PK_POLICY_ALLIN ? (int)MV_ALL_IN
-                                                       : action_from_draw_lds(lds, ActionRing::half_of(word, tb.step_serial), mask), high_bet);
+#pragma unroll
+        for (int pass = 0; pass < PK_BET_PASSES; ++pass) {
+            const bool go = alive && tb.lstate == LS_DONE && owed > 0;
+            uint32_t word = 0;
+            if (policy == PK_POLICY_RANDOM) word = ring.draw16(lds, H, table_id, tb.step_serial, go);   // wave-uniform
+            if (go) {
+                uint32_t mask = tb.valid_mask(high_bet);
+                tb.begin_step(H, policy == PK_POLICY_ALLIN ? (int)MV_ALL_IN
+                                                           : action_from_draw_lds(lds, ActionRing::half_of(word, tb.step_serial), mask), high_bet);
+            }
+            PK_PROF(tb.prof.lap(PF_ACTION);)
+            tb.cursor();
+            PK_PROF(tb.prof.count(PF_N_CURSOR);)
+            retire();
+            PK_PROF(tb.prof.lap(PF_CURSOR);)
         }
-        PK_PROF(tb.prof.lap(PF_ACTION);)
-        tb.cursor();
-        PK_PROF(tb.prof.count(PF_N_CURSOR);)
-        retire();
-        PK_PROF(tb.prof.lap(PF_CURSOR);)
-#ifndef PK_POT_WEIGHT
-#define PK_POT_WEIGHT 2   // halves: how much a showdown waiting in its side-pot loop counts towards `park`
-#endif
+        // showdowns waiting in their side-pot loop (LS_POT) count towards `park` like arrivals (weights 0 and 1/2 measured no better)
         const int parked = __popcll(__ballot(tb.parked()));
-        const int pots = __popcll(__ballot(tb.lstate == LS_POT));
-        const int waiting = parked - pots + (pots * PK_POT_WEIGHT) / 2;
         const int runnable = __popcll(__ballot(alive && tb.lstate == LS_DONE && owed > 0));
         if (parked + runnable < quit) break;
-        if (waiting >= park || runnable == 0) {
+        if (parked >= park || runnable == 0) {
             tb.template end_block<ONE_PASS>(H, t, table_id, lds, auto_reset != 0);
             retire();
         }
@@ -613,7 +615,7 @@ struct pk_handle {
     int device = 0, T = 0, N = 0, block = 64, dealer = 0;
     int tpb = 64;   // tables per wavefront (Hot::tpb)
     bool occ3 = true;  // k_rollout_occ3 (registers capped for 3 waves per SIMD) vs k_rollout; knob PK_OCC3
-    int park = 40;  // lanes parked at end_hand before a wave runs end_block (k_rollout); tuning knob PK_PARK
+    int park = 32;  // lanes parked at end_hand before a wave runs end_block (k_rollout looks every 4 betting passes); knob PK_PARK
     int endk = 48;  // a deferred rollout launch ends once fewer than this many of a wave's lanes have work; knob PK_ENDK
                     // (measured optimum 44..52 at 20 and at 512 steps per launch: tools/tune_sweep.py)
     // Deferred rollout work: steps requested by pk_rollout that no launch has executed yet may exist on the device
