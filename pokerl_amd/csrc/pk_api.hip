@@ -170,11 +170,12 @@ __device__ __forceinline__ void rollout_body(const State *__restrict__ Sp, const
 #define PK_BET_PASSES 4   // betting passes between two looks at the parked lanes: end_block then serves what four passes
 #endif                    // have parked (1: 23.8 G, 2: 25.1 G, 3: 24.4 G, 4: 25.6 G, 6: 24.7 G, 8: 23.2 G at 65 536 x 6)
     for (;;) {
+        if (policy == PK_POLICY_RANDOM) ring.ensure(lds, H, table_id, tb.step_serial, alive && owed > 0, PK_BET_PASSES);   // wave-uniform
 #pragma unroll
         for (int pass = 0; pass < PK_BET_PASSES; ++pass) {
             const bool go = alive && tb.lstate == LS_DONE && owed > 0;
             uint32_t word = 0;
-            if (policy == PK_POLICY_RANDOM) word = ring.draw16(lds, H, table_id, tb.step_serial, go);   // wave-uniform
+            if (policy == PK_POLICY_RANDOM) word = ActionRing::peek(lds, tb.step_serial);
             if (go) {
                 uint32_t mask = tb.valid_mask(high_bet);
                 tb.begin_step(H, policy == PK_POLICY_ALLIN ? (int)MV_ALL_IN

@@ -446,6 +446,38 @@ struct ActionRing {
         const uint32_t j = (uint32_t)step_serial & 7;
         return lds.act[(q & 1) * 4 + (j >> 1)][lane];   // the word holding draw j; half_of() picks the 16 bits at the use site,
     }                                                    // so that the LDS latency hides behind the valid-mask arithmetic
+    // The same split in two for a caller that draws up to `ahead` (<= 8) times per lane between two wave-uniform points:
+    // ensure() once, peek() per draw.  `may`: this lane may pick actions before the next ensure().
+    template <typename LDS>
+    __device__ __forceinline__ void ensure(LDS &lds, const Hot &S, uint32_t table_id, uint64_t step_serial, bool may, int ahead) {
+        const int lane = threadIdx.x & (PK_WAVE - 1);
+        const uint64_t qfull = step_serial >> 3;
+        const uint32_t q = (uint32_t)qfull;
+        if (!primed || (int32_t)(filled - q) < 0) filled = q;
+        primed = true;
+        const int have = (int)(filled - q) * 8 - (int)((uint32_t)step_serial & 7);   // draws of this lane held in LDS
+        if (__any(may && have < ahead)) {
+#pragma unroll 1
+            for (int r = 0; r < 2; ++r) {
+                const bool fill = (int32_t)(filled - q) < 2;
+                if (!__any(fill)) break;
+                if (fill) {
+                    const uint64_t b = qfull + (uint64_t)(filled - q);
+                    uint32_t w[4];
+                    philox4x32_10(table_id, (uint32_t)b, STREAM_ACTION, (uint32_t)(b >> 32), S.key0, S.key1, w);
+                    const int slot = (filled & 1) * 4;
+                    lds.act[slot + 0][lane] = w[0]; lds.act[slot + 1][lane] = w[1];
+                    lds.act[slot + 2][lane] = w[2]; lds.act[slot + 3][lane] = w[3];
+                    filled += 1;
+                }
+            }
+        }
+    }
+    template <typename LDS>
+    __device__ __forceinline__ static uint32_t peek(const LDS &lds, uint64_t step_serial) {
+        const uint32_t s = (uint32_t)step_serial;
+        return lds.act[((s >> 3) & 1) * 4 + ((s & 7) >> 1)][threadIdx.x & (PK_WAVE - 1)];
+    }
     __device__ __forceinline__ static uint32_t half_of(uint32_t word, uint64_t step_serial) {
         return ((uint32_t)step_serial & 1) ? (word >> 16) : (word & 0xffffu);
     }
