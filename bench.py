@@ -199,51 +199,92 @@ def env_mode(args, ctx, device):
     """--mode env: the RL-facing path as a device-resident loop -- seat 0 picks with the in-kernel random
     agent (pk_pick_actions_d), PokerGameEnv.step auto-plays the opponents (pk_env_step_d), finished episodes are reset
     (pk_env_reset_d with the done mask), observations are exported (pk_get_obs_d).  Not the headline metric."""
+    import ctypes as C
     import numpy as np
     import pokerl_amd
     from pokerl_amd import _lib as L
     from pokerl_amd.hipmem import DeviceBuffer
-    T, N = args.tables, args.players
-    env = pokerl_amd.VecPokerGameEnv(0, num_tables=T, num_players=N, device=device)
-    g, lib = env.game, L.lib()
+    T, N, B = args.tables, args.players, max(1, args.env_batches)
     D = 17 + 3 * N
-    act, rew, done, hand, terr, obs = (DeviceBuffer(T * 4, device), DeviceBuffer(T * 8, device), DeviceBuffer(T, device),
-                                       DeviceBuffer(T, device), DeviceBuffer(T, device), DeviceBuffer(T * D * 8, device))
-    L.check(lib.pk_env_reset_d(g._h, None, 0), g._h)
+    lib = L.lib()
 
-    def loop(k):
-        for _ in range(k):
-            if args.env_unfused:   # five launches per env step
-                L.check(lib.pk_pick_actions_d(g._h, 0, act.ptr), g._h)
-                L.check(lib.pk_env_step_d(g._h, act.ptr, 0, rew.ptr, done.ptr, hand.ptr, terr.ptr), g._h)
-                L.check(lib.pk_env_reset_d(g._h, done.ptr, 0), g._h)   # finished episodes ...
-                L.check(lib.pk_env_reset_d(g._h, terr.ptr, 0), g._h)   # ... and tables the reference would never return from
-                L.check(lib.pk_get_obs_d(g._h, -1, obs.ptr), g._h)     #     (PK_TERR_HAND_CAP: ~1 per 25 M game steps)
+    class Batch:   # one independent environment batch: its own handle, stream and output buffers
+        def __init__(self, b):
+            self.env = pokerl_amd.VecPokerGameEnv(0, num_tables=T, num_players=N, device=device,
+                                                  table_id_base=(ctx.rank * B + b) * T)
+            self.g = self.env.game
+            self.act, self.rew, self.done, self.hand, self.terr, self.obs = (
+                DeviceBuffer(T * 4, device), DeviceBuffer(T * 8, device), DeviceBuffer(T, device),
+                DeviceBuffer(T, device), DeviceBuffer(T, device), DeviceBuffer(T * D * 8, device))
+            L.check(lib.pk_env_reset_d(self.g._h, None, 0), self.g._h)
+            # --env-async: one ready[T] slice per timed launch, summed after the timed region
+            self.ready = DeviceBuffer(T * (args.steps + 1), device) if args.env_async > 0 else None
+            self.launch = 0
+
+        def step(self, timed=False):
+            g, h = self.g, self.g._h
+            if args.env_async > 0:   # bounded launches: tables whose env.step has not returned stay in flight
+                slot = 1 + self.launch if timed else 0
+                self.launch += 1 if timed else 0
+                L.check(lib.pk_env_step_async_d(h, None, 0, 0, 1, args.env_async, self.rew.ptr, self.done.ptr, self.hand.ptr,
+                                                self.terr.ptr, self.obs.ptr, C.c_void_p(self.ready.ptr.value + slot * T)), h)
+            elif args.env_unfused:   # five launches per env step
+                L.check(lib.pk_pick_actions_d(h, 0, self.act.ptr), h)
+                L.check(lib.pk_env_step_d(h, self.act.ptr, 0, self.rew.ptr, self.done.ptr, self.hand.ptr, self.terr.ptr), h)
+                L.check(lib.pk_env_reset_d(h, self.done.ptr, 0), h)   # finished episodes ...
+                L.check(lib.pk_env_reset_d(h, self.terr.ptr, 0), h)   # ... and tables the reference would never return from
+                L.check(lib.pk_get_obs_d(h, -1, self.obs.ptr), h)     #     (PK_TERR_HAND_CAP: ~1 per 25 M game steps)
             else:                  # the same work in ONE launch: seat 0 in-kernel, auto-reset, observation from registers
-                L.check(lib.pk_env_step_fused_d(g._h, None, 0, 0, 1, rew.ptr, done.ptr, hand.ptr, terr.ptr, obs.ptr), g._h)
+                L.check(lib.pk_env_step_fused_d(h, None, 0, 0, 1, self.rew.ptr, self.done.ptr, self.hand.ptr, self.terr.ptr,
+                                                self.obs.ptr), h)
+
+    batches = [Batch(b) for b in range(B)]
+
+    def loop(k, timed=False):   # round-robin over the batches: each handle launches on its own stream, nothing waits in between
+        for _ in range(k):
+            for b in batches:
+                b.step(timed)
+
+    def sync():
+        for b in batches:
+            b.g.sync()
 
     loop(args.warmup)
-    g.sync()
-    s0 = int(g.step_serial.sum())
+    sync()
+    s0 = sum(int(b.g.step_serial.sum()) for b in batches)
     ctx.barrier()
     t0 = time.perf_counter()
-    loop(args.steps)
-    g.sync(); ctx.barrier()
+    loop(args.steps, True)
+    sync(); ctx.barrier()
     dt = time.perf_counter() - t0
-    game_steps = int(g.step_serial.sum()) - s0
-    capped = int((terr.download(np.uint8, T) != 0).sum())
+    env_steps = B * T * args.steps
+    if args.env_async > 0:   # delivered env.steps = ready flags of the timed launches; then drain so that the tables can be read
+        env_steps = sum(int(b.ready.download(np.uint8, T * (args.steps + 1))[T:].sum(dtype=np.int64)) for b in batches)
+        for b in batches:
+            L.check(lib.pk_env_step_async_d(b.g._h, None, 0, 0, 1, 0, b.rew.ptr, b.done.ptr, b.hand.ptr, b.terr.ptr, b.obs.ptr,
+                                            b.ready.ptr), b.g._h)
+        sync()
+    game_steps = sum(int(b.g.step_serial.sum()) for b in batches) - s0
+    capped = sum(int((b.terr.download(np.uint8, T) != 0).sum()) for b in batches)
     if ctx.rank == 0:
         print(json.dumps({
             "metric": "PokerGameEnv.step seat-0 steps/s (device-resident loop: pick + env_step + env_reset(done) + obs; %s)"
-                      % ("five launches per step" if args.env_unfused else "fused into one launch per step"),
-            "value": T * args.steps / dt, "unit": "env.step/s", "n_gpus": ctx.world, "steps": args.steps,
+                      % ("bounded launches of %d betting passes, steps that have not returned stay in flight "
+                         "(pk_env_step_async_d); value counts DELIVERED env.steps" % args.env_async if args.env_async > 0 else
+                         "five launches per step" if args.env_unfused else "fused into one launch per step"),
+            "value": env_steps / dt, "unit": "env.step/s", "n_gpus": ctx.world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%d tables x %d seats, seat 0 + opponents random in-kernel, episodes auto-reset; "
-                                   "reference pokerl/envs/game_env.py:20-53" % (T, N)},
-            "game_steps_per_s": game_steps / dt, "game_steps_per_env_step": game_steps / (T * args.steps),
+            "config": {"workload": "%d batch(es) x %d tables x %d seats per GPU, seat 0 + opponents random in-kernel, "
+                                   "episodes auto-reset; reference pokerl/envs/game_env.py:20-53" % (B, T, N),
+                       "env_batches": B,
+                       "note": "one env.step of a batch lasts as long as its slowest table (a busted seat 0 waits for the "
+                               "rest of the game, game_env.py:44-47); independent batches on their own streams fill that tail"},
+            "game_steps_per_s": game_steps / dt, "game_steps_per_env_step": game_steps / max(1, env_steps),
+            "ready_fraction_per_launch": env_steps / (B * T * args.steps),
             "tables_with_error_bits_in_last_step": capped}))
-    env.game.close()
+    for b in batches:
+        b.g.close()
 
 
 def main():
@@ -263,6 +304,9 @@ def main():
     ap.add_argument("--samples", type=int, default=7, help="timed samples; the MEDIAN is reported")
     ap.add_argument("--unfused", action="store_true", help="one launch per step (state round-trips HBM every step)")
     ap.add_argument("--mode", choices=["game", "env"], default="game")
+    ap.add_argument("--env-batches", type=int, default=1, help="--mode env: independent batches in flight, one stream each")
+    ap.add_argument("--env-async", type=int, default=0, metavar="PASSES",
+                    help="--mode env through pk_env_step_async_d with this pass budget per launch (0: synchronous)")
     ap.add_argument("--env-unfused", action="store_true", help="--mode env with separate pick / step / reset / obs launches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-evaluator", action="store_true", help="skip the stand-alone evaluator kernel leg")

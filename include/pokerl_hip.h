@@ -44,6 +44,7 @@ extern "C" {
 #define PK_E_HIP (-3)
 #define PK_E_OOM (-4)
 #define PK_E_TABLE (-5) /* at least one table reported a PK_TERR_* bit; call completed for all other tables */
+#define PK_E_BUSY (-6)  /* PokerGameEnv steps are in flight (pk_env_step_async_d); nothing was done: drain them first */
 
 /* per-table error bits */
 #define PK_TERR_INVALID_ACTION 1 /* Game.step ValueError, pokerl/game.py:649-651: that table is left untouched */
@@ -220,6 +221,21 @@ int pk_env_reset_d(pk_handle *h, const uint8_t *mask_d /* NULL = all */, int opp
  * obs_d != NULL receives the dense StateView row of the player to act (PK_OBS_DIM(N) doubles per table). */
 int pk_env_step_fused_d(pk_handle *h, const int32_t *actions_d, int seat0_policy, int opp_policy, int auto_reset,
                         double *reward_d, uint8_t *done_d, uint8_t *hand_d, uint8_t *terr_d, double *obs_d);
+
+/* The same as a BOUNDED launch for learners that act on whichever tables are ready (asynchronous vector environment).
+ * One PokerGameEnv.step of a whole batch lasts as long as its slowest table: a seat 0 that goes broke during an
+ * opponent's step waits for the end of the game (game_env.py:49-52), ~150 Game.steps against a mean of 6.  Here a launch
+ * runs at most max_passes betting passes (each busy table executes about one Game.step per pass); a table whose
+ * env.step (and, with auto_reset, the reset after it) has returned by then gets ready_d[t] = 1 and its reward / done /
+ * hand / terr / obs row written; the others get ready_d[t] = 0, their outputs are left untouched and their step stays IN
+ * FLIGHT on the device: the next call carries on with it and IGNORES actions_d[t].  A table with an invalid action
+ * returns at once (ready, PK_TERR_INVALID_ACTION, untouched).  Per table the sequence of steps, outputs and RNG draws is
+ * exactly that of pk_env_step_fused_d; only the call that delivers them differs.  max_passes <= 0: run every step to its
+ * end (every table ready).  While steps may be in flight (after any call with max_passes > 0) all other entry points
+ * that read or change tables return PK_E_BUSY (pk_sync only waits); a call with max_passes <= 0 ends that state. */
+int pk_env_step_async_d(pk_handle *h, const int32_t *actions_d, int seat0_policy, int opp_policy, int auto_reset,
+                        int max_passes, double *reward_d, uint8_t *done_d, uint8_t *hand_d, uint8_t *terr_d,
+                        double *obs_d, uint8_t *ready_d);
 
 /* Stream control (no torch types: `stream` is a hipStream_t, `event` a hipEvent_t, passed as void*).  A handle creates
  * its own non-blocking stream.  pk_set_stream makes it run on the caller's stream instead (NULL: back to its own), which

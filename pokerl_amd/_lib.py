@@ -8,7 +8,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("POKERL_HIP_LIB") or os.path.join(HERE, "libpokerl_hip.so")  # override: diagnostic builds
 
-PK_OK, PK_E_INVALID_ARG, PK_E_NO_DEVICE, PK_E_HIP, PK_E_OOM, PK_E_TABLE = 0, -1, -2, -3, -4, -5
+PK_OK, PK_E_INVALID_ARG, PK_E_NO_DEVICE, PK_E_HIP, PK_E_OOM, PK_E_TABLE, PK_E_BUSY = 0, -1, -2, -3, -4, -5, -6
 TERR_INVALID_ACTION, TERR_NO_WINNER, TERR_HAND_CAP, TERR_ENV_CAP = 1, 2, 4, 8
 FLAG_GAME_OVER, FLAG_HAND_OVER, FLAG_TURN_OVER = 1, 2, 4
 F_CREDITS, F_BETS, F_PENDING_BETS, F_PAYOFFS = 0, 1, 2, 3
@@ -26,7 +26,7 @@ SYMBOLS = ["pk_abi_version", "pk_device_count", "pk_last_error", "pk_create", "p
            "pk_env_reset", "pk_env_step", "pk_get_obs", "pk_sync", "pk_time_rollout", "pk_get_obs_d",
            "pk_get_valid_actions_d", "pk_env_step_d", "pk_env_reset_d", "pk_eval7_d", "pk_make_hands_d", "pk_time_eval7_d",
            "pk_get_serials", "pk_set_serials", "pk_get_table_f64", "pk_get_game_over", "pk_eval_hands_d",
-           "pk_pick_actions_d", "pk_flush", "pk_get_owed", "pk_env_step_fused_d", "pk_set_tuning", "pk_get_stream", "pk_set_stream", "pk_wait_event",
+           "pk_pick_actions_d", "pk_flush", "pk_get_owed", "pk_env_step_fused_d", "pk_env_step_async_d", "pk_set_tuning", "pk_get_stream", "pk_set_stream", "pk_wait_event",
            "pk_record_event"]
 
 
@@ -90,6 +90,7 @@ def lib():
     L.pk_pick_actions_d.argtypes = [_vp, C.c_int, _vp]
     L.pk_flush.argtypes = [_vp]
     L.pk_env_step_fused_d.argtypes = [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]
+    L.pk_env_step_async_d.argtypes = [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]
     L.pk_get_owed.argtypes = [_vp, _vp]
     L.pk_set_tuning.argtypes = [_vp, C.c_int, C.c_int]
     L.pk_get_stream.argtypes = [_vp, C.POINTER(_vp)]

@@ -290,8 +290,15 @@ __global__ void __launch_bounds__(PK_TABLE_BLOCK) k_env_reset(const State *__res
 // (auto_reset: PokerGameEnv.reset(), game_env.py:20-29 -- what the caller would do next for `done` tables; reward /
 // done / hand still describe the step that ended it), and the dense StateView row of the player to act can be
 // written straight from registers (obs != NULL, layout PK_OBS_DIM).
-template <int N>
-__global__ void __launch_bounds__(PK_TABLE_BLOCK) k_env_step(const State *__restrict__ Sp, Hot H, const int32_t *actions, int seat0_policy, int opp_policy, int auto_reset, double *reward, uint8_t *done_out, uint8_t *hand_out, uint8_t *terr, double *obs, int park) {
+//
+// ASYNC (pk_env_step_async_d): a launch lasts at most `max_passes` betting passes.  A PokerGameEnv.step that has not
+// returned by then stays IN FLIGHT: its machine state goes to State::env_ctx / env_rew (plus the step-in-flight bits of
+// the table itself), the next launch carries on with it, and only tables whose step returned in this launch write
+// their outputs and ready[t] = 1.  One env.step of a whole batch lasts as long as its slowest table (a seat 0 that
+// busts during an opponent's step waits for the end of the game, game_env.py:49-52); a learner that acts on the ready
+// tables only never waits for those.  Per table the sequence of steps, outputs and RNG draws is the synchronous one.
+template <int N, bool ASYNC>
+__device__ __forceinline__ void env_step_body(const State *__restrict__ Sp, const Hot &H, const int32_t *actions, int seat0_policy, int opp_policy, int auto_reset, double *reward, uint8_t *done_out, uint8_t *hand_out, uint8_t *terr, double *obs, int park, uint8_t *ready, int max_passes) {
     const State &S = *Sp;
     __shared__ Lds<N> lds;
     const int t = blockIdx.x * H.tpb + threadIdx.x;
@@ -299,17 +306,27 @@ __global__ void __launch_bounds__(PK_TABLE_BLOCK) k_env_step(const State *__rest
     const uint32_t table_id = H.table_id_base + (uint32_t)t;
     Table<N> tb;
     if (live) tb.load(S, t); else tb.blank();
+    uint64_t ctx = 0;                                          // != 0: a PokerGameEnv.step of this table is in flight
+    if (ASYNC && live) ctx = S.env_ctx[t];
+    const bool carried = ctx != 0;
     ActionRng rng;
     double high_bet;
     const uint32_t vm0 = tb.valid_mask(high_bet);
-    const int action = !live ? -1 : (actions ? actions[t] : pick_action(H, rng, table_id, tb.step_serial, vm0, seat0_policy));
-    const bool ok = live && action >= 0 && action < PK_NUM_MOVES && ((vm0 >> action) & 1);   // game.py:648-651
+    const int action = (!live || carried) ? -1 : (actions ? actions[t] : pick_action(H, rng, table_id, tb.step_serial, vm0, seat0_policy));
+    const bool ok = carried || (live && action >= 0 && action < PK_NUM_MOVES && ((vm0 >> action) & 1));   // game.py:648-651
     enum { PH_SEAT0 = 0, PH_HAND = 1, PH_TURN = 2, PH_RESET = 3, PH_RESET_PLAY = 4, PH_END = 5 };
     int phase = ok ? PH_SEAT0 : PH_END;
     double rew = 0.0;                                                              // :34
     bool done = false, hand = false;
     uint32_t terr_step = 0;
     int budget = PK_ENV_STEP_CAP, budget_reset = PK_ENV_STEP_CAP;
+    if (ASYNC && carried) {
+        phase = (int)(ctx >> 1) & 7; done = (ctx >> 4) & 1; hand = (ctx >> 5) & 1; terr_step = (uint32_t)(ctx >> 8) & 0xff;
+        budget = (int)((ctx >> 16) & 0xffff) - 1; budget_reset = (int)((ctx >> 32) & 0xffff) - 1;
+        rew = S.env_rew[t];
+        tb.hands_this_step = (int)S.mid[t];
+    }
+    int passes = 0;
     const uint32_t caps = PK_TERR_HAND_CAP | PK_TERR_ENV_CAP;
     auto step_finished = [&]() {   // PokerGameEnv.step has returned: its outputs are final; maybe reset the episode
         terr_step = tb.terr;
@@ -349,7 +366,10 @@ __global__ void __launch_bounds__(PK_TABLE_BLOCK) k_env_step(const State *__rest
         }
     };
     for (;;) {
-        if (phase != PH_END && tb.lstate == LS_DONE) {                             // begin this lane's next Game.step()
+        // ASYNC, pass budget used up: no lane begins another Game.step; the hands that are ending are still brought to
+        // their end (a lane parked at end_hand would otherwise wait for 'park' neighbours launch after launch)
+        const bool draining = ASYNC && max_passes > 0 && passes >= max_passes;
+        if (!draining && phase != PH_END && tb.lstate == LS_DONE) {                // begin this lane's next Game.step()
             if (phase == PH_RESET) {                                               // game_env.py:23 / :27
                 tb.reset_state(H, 0); tb.deal(H, table_id);
                 phase = tb.active != 0 ? PH_RESET_PLAY : PH_END;                   // :24
@@ -363,8 +383,9 @@ __global__ void __launch_bounds__(PK_TABLE_BLOCK) k_env_step(const State *__rest
         tb.cursor();
         retire();
         const int parked = __popcll(__ballot(tb.parked()));
-        const int runnable = __popcll(__ballot(phase != PH_END && tb.lstate == LS_DONE));
-        if (parked == 0 && runnable == 0) break;
+        const int runnable = draining ? 0 : __popcll(__ballot(phase != PH_END && tb.lstate == LS_DONE));
+        if (parked == 0 && runnable == 0) break;                                   // draining: the rest stays in flight
+        ++passes;
         if (parked >= park || runnable == 0) {
             tb.end_block(H, t, table_id, lds, false);
             retire();
@@ -376,6 +397,16 @@ __global__ void __launch_bounds__(PK_TABLE_BLOCK) k_env_step(const State *__rest
         tb.store_show(S.show, S.T, t, lds);
     }
     const uint32_t vmask = tb.valid_mask(high_bet);
+    if (ASYNC) {
+        const bool returned = phase == PH_END;
+        S.env_ctx[t] = returned ? 0ull
+                                : (1ull | ((uint64_t)phase << 1) | ((uint64_t)done << 4) | ((uint64_t)hand << 5) | ((uint64_t)(terr_step & 0xff) << 8) |
+                                   ((uint64_t)(budget + 1) << 16) | ((uint64_t)(budget_reset + 1) << 32));
+        S.mid[t] = returned ? 0u : (uint32_t)tb.hands_this_step;
+        S.valid[t] = (uint8_t)vmask;
+        ready[t] = returned;
+        if (!returned) { S.env_rew[t] = rew; return; }
+    }
     const uint32_t te = ok ? (terr_step | tb.terr) : (uint32_t)PK_TERR_INVALID_ACTION;
     reward[t] = ok ? rew : 0.0; done_out[t] = ok && done; hand_out[t] = ok && hand;  // :53
     if (ok) S.valid[t] = (uint8_t)vmask;
@@ -391,6 +422,14 @@ __global__ void __launch_bounds__(PK_TABLE_BLOCK) k_env_step(const State *__rest
         PK_FOR(c, 5) o[12 + c] = (tb.turn != 0 && c < tb.turn + 2) ? (double)tb.card(c) : -1.0; PK_END   // game.py:278
         PK_FOR(p, N) o[17 + p] = tb.credits[p]; o[17 + N + p] = tb.bets[p]; o[17 + 2 * N + p] = tb.pending[p]; PK_END
     }
+}
+template <int N>
+__global__ void __launch_bounds__(PK_TABLE_BLOCK) k_env_step(const State *__restrict__ Sp, Hot H, const int32_t *actions, int seat0_policy, int opp_policy, int auto_reset, double *reward, uint8_t *done_out, uint8_t *hand_out, uint8_t *terr, double *obs, int park) {
+    env_step_body<N, false>(Sp, H, actions, seat0_policy, opp_policy, auto_reset, reward, done_out, hand_out, terr, obs, park, nullptr, 0);
+}
+template <int N>
+__global__ void __launch_bounds__(PK_TABLE_BLOCK) k_env_step_async(const State *__restrict__ Sp, Hot H, const int32_t *actions, int seat0_policy, int opp_policy, int auto_reset, double *reward, uint8_t *done_out, uint8_t *hand_out, uint8_t *terr, double *obs, int park, uint8_t *ready, int max_passes) {
+    env_step_body<N, true>(Sp, H, actions, seat0_policy, opp_policy, auto_reset, reward, done_out, hand_out, terr, obs, park, ready, max_passes);
 }
 
 // ---- exports: device-side conversion from the SoA/bitmask layout to the reference's table-major arrays
@@ -623,6 +662,9 @@ struct pk_handle {
     // (State::owed, steps in flight).  Every entry point that reads or changes table state flushes first.
     bool pending = false;
     int pend_policy = 0, pend_auto = 0;
+    // PokerGameEnv.steps left in flight by pk_env_step_async_d (State::env_ctx): every other entry point that touches
+    // table state refuses to run until a draining call (max_passes <= 0) has completed them.
+    bool env_pending = false;
     hipStream_t stream = nullptr, own_stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     State S{};
@@ -704,9 +746,14 @@ static int launch_rollout(pk_handle *h, int k_steps, int policy, int auto_reset,
     return PK_OK;
 }
 // Completes whatever deferred rollout launches left undone.  Called by every entry point that reads or mutates tables.
-static int flush(pk_handle *h) {
+static int flush_rollout(pk_handle *h) {
     if (!h->pending) return PK_OK;
     return launch_rollout(h, 0, h->pend_policy, h->pend_auto, 1);
+}
+static int flush(pk_handle *h) {
+    if (h->env_pending)
+        return h->fail(PK_E_BUSY, "PokerGameEnv steps are in flight (pk_env_step_async_d): drain them with max_passes = 0 first");
+    return flush_rollout(h);
 }
 #define FLUSH(h)                   \
     do {                           \
@@ -784,7 +831,7 @@ int pk_create(pk_handle **out, int device, int num_tables, int num_players, cons
     const size_t nwaves = (T + (size_t)h->tpb - 1) / (size_t)h->tpb;
     size_t total = 4 * al(T * N * 8) + 4 * al(T * 8) + 4 * al(T * 4) + al(W * T * 4) + al(N * T * 4) + 2 * al(T) +
                    al(nwaves * PK_NUM_COUNTERS * 8) + al(PK_NUM_COUNTERS * 8) + al(PF_SLOTS * 8) + al(sizeof(State)) +
-                   al(PK_MAX_PLAYERS * 8) + al(sizeof(Fresh)) + al(T * 4) + 5 * al(T) + al(T * 8) + h->export_bytes;
+                   al(PK_MAX_PLAYERS * 8) + al(sizeof(Fresh)) + al(T * 4) + 5 * al(T) + al(T * 8) + 2 * al(T * 8) + h->export_bytes;
     e = hipMalloc(&h->arena, total);
     if (e != hipSuccess) return bail(h->fail(PK_E_OOM, "hipMalloc(table state)", e));
     if (hipMemsetAsync(h->arena, 0, total, h->stream) != hipSuccess) return bail(h->fail(PK_E_HIP, "hipMemset"));
@@ -798,6 +845,7 @@ int pk_create(pk_handle **out, int device, int num_tables, int num_players, cons
     S.hand_serial = (uint64_t *)take(T * 8); S.step_serial = (uint64_t *)take(T * 8);
     S.cursors = (uint32_t *)take(T * 4); S.hand = (int32_t *)take(T * 4);
     S.owed = (uint32_t *)take(T * 4); S.mid = (uint32_t *)take(T * 4);
+    S.env_ctx = (uint64_t *)take(T * 8); S.env_rew = (double *)take(T * 8);
     S.cards = (uint32_t *)take(W * T * 4);
     S.show = (uint32_t *)take(N * T * 4);
     S.valid = (uint8_t *)take(T); S.terr = (uint8_t *)take(T);
@@ -1003,7 +1051,7 @@ int pk_get_i32(pk_handle *h, int field, int32_t *out) {
 int pk_get_serials(pk_handle *h, uint64_t *hand_serial, uint64_t *step_serial) {
     if (!h) return PK_E_INVALID_ARG;
     ON_DEVICE(h);
-    FLUSH(h);
+    if (!h->env_pending) FLUSH(h);   // with env steps in flight: the counts of the hands dealt / Game.steps completed so far
     if (hand_serial) HIPCHK(h, hipMemcpyAsync(hand_serial, h->S.hand_serial, (size_t)h->T * 8, hipMemcpyDeviceToHost, h->stream));
     if (step_serial) HIPCHK(h, hipMemcpyAsync(step_serial, h->S.step_serial, (size_t)h->T * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1102,6 +1150,21 @@ int pk_env_step_fused_d(pk_handle *h, const int32_t *actions_d, int seat0_policy
     DISPATCH_N(h, k_env_step, table_grid(h), (const State *)h->d_S, h->hot, actions_d, actions_d ? -1 : seat0_policy, opp_policy,
                auto_reset ? 1 : 0, reward_d, done_d, hand_d, terr_d, obs_d, scaled_park(h));
     HIPCHK(h, hipGetLastError());
+    return PK_OK;
+}
+
+int pk_env_step_async_d(pk_handle *h, const int32_t *actions_d, int seat0_policy, int opp_policy, int auto_reset, int max_passes,
+                        double *reward_d, uint8_t *done_d, uint8_t *hand_d, uint8_t *terr_d, double *obs_d, uint8_t *ready_d) {
+    if (!h || !reward_d || !done_d || !hand_d || !terr_d || !ready_d || opp_policy < 0 || opp_policy > 1 ||
+        (!actions_d && (seat0_policy < 0 || seat0_policy > 1)))
+        return h ? h->fail(PK_E_INVALID_ARG, "pk_env_step_async_d: bad argument") : PK_E_INVALID_ARG;
+    ON_DEVICE(h);
+    int rc = flush_rollout(h);
+    if (rc) return rc;
+    DISPATCH_N(h, k_env_step_async, table_grid(h), (const State *)h->d_S, h->hot, actions_d, actions_d ? -1 : seat0_policy, opp_policy,
+               auto_reset ? 1 : 0, reward_d, done_d, hand_d, terr_d, obs_d, scaled_park(h), ready_d, max_passes > 0 ? max_passes : 0);
+    HIPCHK(h, hipGetLastError());
+    h->env_pending = max_passes > 0;
     return PK_OK;
 }
 
@@ -1246,7 +1309,7 @@ int pk_prof_read(pk_handle *h, unsigned long long *out) {
 int pk_sync(pk_handle *h) {
     if (!h) return PK_E_INVALID_ARG;
     ON_DEVICE(h);
-    FLUSH(h);
+    if (!h->env_pending) FLUSH(h);   // env steps in flight stay in flight: only wait for the launches made so far
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return PK_OK;
 }

@@ -36,6 +36,9 @@ struct State {
     uint32_t *show;                              // [N][T]   last showdown: HandRanking<<20 | kickers value
     uint32_t *owed;                              // [T]      Game.step()s requested by pk_rollout and not executed yet (deferred launches)
     uint32_t *mid;                               // [T]      hands rolled so far by a step that is in flight across launches
+    uint64_t *env_ctx;                           // [T]      PokerGameEnv.step in flight across pk_env_step_async_d launches (0: none):
+                                                 //          1 | phase<<1 | done<<4 | hand<<5 | terr<<8 | (budget+1)<<16 | (reset budget+1)<<32
+    double *env_rew;                             // [T]      ... and its reward so far (game_env.py:34, :47)
     uint8_t *valid;                              // [T]      valid-action bitmask of the active player (game.py:339-383)
     uint8_t *terr;                               // [T]      PK_TERR_* of the last call
     unsigned long long *counters;                // [waves][PK_NUM_COUNTERS]: one slot per wavefront, no atomics (4 096

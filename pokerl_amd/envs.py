@@ -56,3 +56,14 @@ class VecPokerGameEnv:
         if terr.any():
             raise L.PokerlHipError('table error bits %s' % np.unique(terr))
         return g.observations, reward, done != 0, hand != 0
+
+    def step_async_d(self, actions_d, reward_d, done_d, hand_d, terr_d, obs_d, ready_d, max_passes=8, seat0_policy=Policy.RANDOM,
+                     auto_reset=True):
+        """pk_env_step_async_d on DEVICE pointers (ints / c_void_p; actions_d None = seat 0 played by `seat0_policy`
+        in-kernel): a bounded launch that delivers the tables whose PokerGameEnv.step returned (ready_d[t] = 1) and keeps
+        the others in flight.  max_passes <= 0 drains.  See include/pokerl_hip.h."""
+        g = self.game
+        vp = lambda x: x if x is None or isinstance(x, L.C.c_void_p) else L.C.c_void_p(int(x))
+        L.check(g._lib.pk_env_step_async_d(g._h, vp(actions_d), int(seat0_policy), self.opp_policy, 1 if auto_reset else 0,
+                                           int(max_passes), vp(reward_d), vp(done_d), vp(hand_d), vp(terr_d), vp(obs_d),
+                                           vp(ready_d)), g._h)

@@ -291,3 +291,93 @@ def test_fused_env_step_matches_the_separate_calls(HB, O):
         g.sync()
         assert (terr.download(np.uint8, T) == 1).all() and GU.bits_equal(before, g.credits)
         g.close()
+
+
+@pytest.mark.gpu
+def test_async_env_step_delivers_the_synchronous_sequences(HB, O):
+    """pk_env_step_async_d: bounded launches, tables whose PokerGameEnv.step has not returned stay in flight.  Per table
+    the delivered (reward, done, hand, obs row) sequence must be bit-identical to the synchronous fused call's (whose
+    reward / done / hand are checked against the oracle here as well), whatever the pass budget -- with seat 0 played
+    in-kernel and with supplied actions (a function of the table's last delivered row; garbage is supplied for tables in
+    flight and must be ignored).  Other entry points refuse to run until a draining call."""
+    import pokerl_amd
+    from pokerl_amd import _lib as L
+    from pokerl_amd.hipmem import DeviceBuffer
+    lib = L.lib()
+
+    def choose(row, k):   # seat 0's host-side policy: the (k mod #valid)-th valid action of the delivered row
+        mask = row[:, 3:10] > 0
+        nth = k % mask.sum(axis=1)
+        return ((np.cumsum(mask, axis=1) - 1 == nth[:, None]) & mask).argmax(axis=1).astype(np.int32)
+
+    for T, N, opp, K, passes in [(4096, 6, 0, 40, 6), (1000, 3, 0, 40, 1), (640, 9, 1, 25, 3), (2048, 2, 0, 40, 2), (512, 4, 0, 30, 13)]:
+        D = 17 + 3 * N
+        rew, done, hand, terr, obs, ready, act = (DeviceBuffer(T * 8), DeviceBuffer(T), DeviceBuffer(T), DeviceBuffer(T),
+                                                  DeviceBuffer(T * D * 8), DeviceBuffer(T), DeviceBuffer(T * 4))
+        outputs = lambda: (rew.download(np.float64, T), done.download(np.uint8, T), hand.download(np.uint8, T),
+                           obs.download(np.float64, T * D).reshape(T, D))
+        for supplied in (False, True):
+            # ---- the synchronous sequences (and the oracle beside them)
+            env = pokerl_amd.VecPokerGameEnv(opp, num_tables=T, num_players=N, seed=1234)
+            g = env.game
+            o = O.OracleGame(T, N, seed=1234)
+            row = env.reset(); o.env_reset(None, opp)
+            want = dict(rew=np.zeros((T, K)), done=np.zeros((T, K), np.uint8), hand=np.zeros((T, K), np.uint8), obs=np.zeros((T, K, D)))
+            for k in range(K):
+                a = choose(row, np.full(T, k)) if supplied else o.pick_actions(0)
+                ro, do, ho, eo = o.env_step(a, opp)
+                assert not eo.any()
+                if do.any():
+                    o.env_reset(do, opp)
+                if supplied:
+                    act.upload(a)
+                L.check(lib.pk_env_step_fused_d(g._h, act.ptr if supplied else None, 0, opp, 1, rew.ptr, done.ptr, hand.ptr,
+                                                terr.ptr, obs.ptr), g._h)
+                g.sync()
+                want["rew"][:, k], want["done"][:, k], want["hand"][:, k], want["obs"][:, k] = outputs()
+                row = want["obs"][:, k]
+                assert GU.bits_equal(ro, want["rew"][:, k]) and np.array_equal(do, want["done"][:, k]) and np.array_equal(ho, want["hand"][:, k])
+            g.close()
+            # ---- the same tables through bounded launches
+            env = pokerl_amd.VecPokerGameEnv(opp, num_tables=T, num_players=N, seed=1234)
+            g = env.game
+            row = env.reset().copy()
+            got = {k: np.zeros_like(v) for k, v in want.items()}
+            count = np.zeros(T, np.int64)
+            r = np.ones(T, bool)                        # every table is ready for its first action
+            launches = in_flight_seen = 0
+            while count.min() < K:
+                launches += 1
+                assert launches < 60 * K, ("async env steps do not make progress", T, N, passes)
+                if supplied:
+                    a = np.full(T, -1, np.int32)        # garbage for tables in flight: must be ignored
+                    a[r] = choose(row[r], count[r])
+                    act.upload(a)
+                env.step_async_d(act.ptr if supplied else None, rew.ptr, done.ptr, hand.ptr, terr.ptr, obs.ptr, ready.ptr,
+                                 max_passes=passes)
+                g.sync()
+                r = ready.download(np.uint8, T) != 0
+                in_flight_seen += int((~r).sum())
+                assert not terr.download(np.uint8, T)[r].any()
+                out = outputs()
+                row[r] = out[3][r]
+                idx = np.nonzero(r & (count < K))[0]
+                c = count[idx]
+                got["rew"][idx, c], got["done"][idx, c], got["hand"][idx, c], got["obs"][idx, c] = (x[idx] for x in out)
+                count[r] += 1
+            assert in_flight_seen > 0, ("the pass budget never left a step in flight: nothing was tested", T, N, passes)
+            for k in want:
+                same = GU.bits_equal(want[k], got[k]) if want[k].dtype == np.float64 else np.array_equal(want[k], got[k])
+                assert same, (T, N, supplied, k)
+            # steps may be in flight: observers refuse, pk_sync waits, a draining call delivers everything and unlocks
+            with pytest.raises(L.PokerlHipError):
+                g.credits
+            if supplied:
+                a = np.full(T, -1, np.int32)
+                a[r] = choose(row[r], count[r])
+                act.upload(a)
+            env.step_async_d(act.ptr if supplied else None, rew.ptr, done.ptr, hand.ptr, terr.ptr, obs.ptr, ready.ptr, max_passes=0)
+            g.sync()
+            assert (ready.download(np.uint8, T) != 0).all() and not terr.download(np.uint8, T).any()
+            assert GU.bits_equal(obs.download(np.float64, T * D).reshape(T, D), g.observations)
+            g.close()
