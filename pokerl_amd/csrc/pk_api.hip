@@ -309,11 +309,13 @@ __device__ __forceinline__ void env_step_body(const State *__restrict__ Sp, cons
     uint64_t ctx = 0;                                          // != 0: a PokerGameEnv.step of this table is in flight
     if (ASYNC && live) ctx = S.env_ctx[t];
     const bool carried = ctx != 0;
-    ActionRng rng;
+    ActionRing ring;
+    stage_nth(lds);
     double high_bet;
     const uint32_t vm0 = tb.valid_mask(high_bet);
-    const int action = (!live || carried) ? -1 : (actions ? actions[t] : pick_action(H, rng, table_id, tb.step_serial, vm0, seat0_policy));
-    const bool ok = carried || (live && action >= 0 && action < PK_NUM_MOVES && ((vm0 >> action) & 1));   // game.py:648-651
+    // seat 0's action: supplied (checked here, game.py:648-651) or drawn in the loop like the opponents' (always valid)
+    const int action = (!live || carried || !actions) ? -1 : actions[t];
+    const bool ok = carried || (live && (!actions || (action >= 0 && action < PK_NUM_MOVES && ((vm0 >> action) & 1))));
     enum { PH_SEAT0 = 0, PH_HAND = 1, PH_TURN = 2, PH_RESET = 3, PH_RESET_PLAY = 4, PH_END = 5 };
     int phase = ok ? PH_SEAT0 : PH_END;
     double rew = 0.0;                                                              // :34
@@ -365,27 +367,38 @@ __device__ __forceinline__ void env_step_body(const State *__restrict__ Sp, cons
             }
         }
     };
+#ifndef PK_ENV_PASSES
+#define PK_ENV_PASSES 4   // betting passes between two looks at the parked lanes, as in k_rollout
+#endif
+    const bool draws = seat0_policy == PK_POLICY_RANDOM || opp_policy == PK_POLICY_RANDOM;   // wave-uniform
     for (;;) {
         // ASYNC, pass budget used up: no lane begins another Game.step; the hands that are ending are still brought to
         // their end (a lane parked at end_hand would otherwise wait for 'park' neighbours launch after launch)
         const bool draining = ASYNC && max_passes > 0 && passes >= max_passes;
-        if (!draining && phase != PH_END && tb.lstate == LS_DONE) {                // begin this lane's next Game.step()
-            if (phase == PH_RESET) {                                               // game_env.py:23 / :27
-                tb.reset_state(H, 0); tb.deal(H, table_id);
-                phase = tb.active != 0 ? PH_RESET_PLAY : PH_END;                   // :24
-            }
-            if (phase != PH_END) {
+        if (!draining && phase == PH_RESET && tb.lstate == LS_DONE) {              // game_env.py:23 / :27
+            tb.reset_state(H, 0); tb.deal(H, table_id);
+            phase = tb.active != 0 ? PH_RESET_PLAY : PH_END;                       // :24
+        }
+        if (draws) ring.ensure(lds, H, table_id, tb.step_serial, live && phase != PH_END, PK_ENV_PASSES);
+#pragma unroll
+        for (int pass = 0; pass < PK_ENV_PASSES; ++pass) {
+            const bool open = !(ASYNC && max_passes > 0 && passes + pass >= max_passes);
+            const uint32_t word = draws ? ActionRing::peek(lds, tb.step_serial) : 0u;
+            if (open && phase != PH_END && phase != PH_RESET && tb.lstate == LS_DONE) {   // begin this lane's next Game.step()
                 const uint32_t vm = tb.valid_mask(high_bet);
-                const int a = phase == PH_SEAT0 ? action : pick_action(H, rng, table_id, tb.step_serial, vm, opp_policy);
+                const int pol = phase == PH_SEAT0 ? seat0_policy : opp_policy;
+                const int a = (phase == PH_SEAT0 && actions) ? action
+                            : pol == PK_POLICY_ALLIN ? (int)MV_ALL_IN
+                                                     : action_from_draw_lds(lds, ActionRing::half_of(word, tb.step_serial), vm);
                 tb.begin_step(H, a, high_bet);                                     // :35 / :43-44 / :51-52 / :25-26
             }
+            tb.cursor();
+            retire();
         }
-        tb.cursor();
-        retire();
         const int parked = __popcll(__ballot(tb.parked()));
         const int runnable = draining ? 0 : __popcll(__ballot(phase != PH_END && tb.lstate == LS_DONE));
         if (parked == 0 && runnable == 0) break;                                   // draining: the rest stays in flight
-        ++passes;
+        passes += PK_ENV_PASSES;
         if (parked >= park || runnable == 0) {
             tb.end_block(H, t, table_id, lds, false);
             retire();
@@ -428,7 +441,7 @@ __global__ void __launch_bounds__(PK_TABLE_BLOCK) k_env_step(const State *__rest
     env_step_body<N, false>(Sp, H, actions, seat0_policy, opp_policy, auto_reset, reward, done_out, hand_out, terr, obs, park, nullptr, 0);
 }
 template <int N>
-__global__ void __launch_bounds__(PK_TABLE_BLOCK) k_env_step_async(const State *__restrict__ Sp, Hot H, const int32_t *actions, int seat0_policy, int opp_policy, int auto_reset, double *reward, uint8_t *done_out, uint8_t *hand_out, uint8_t *terr, double *obs, int park, uint8_t *ready, int max_passes) {
+__global__ void __launch_bounds__(PK_TABLE_BLOCK, (N <= 6 ? 3 : 2)) k_env_step_async(const State *__restrict__ Sp, Hot H, const int32_t *actions, int seat0_policy, int opp_policy, int auto_reset, double *reward, uint8_t *done_out, uint8_t *hand_out, uint8_t *terr, double *obs, int park, uint8_t *ready, int max_passes) {
     env_step_body<N, true>(Sp, H, actions, seat0_policy, opp_policy, auto_reset, reward, done_out, hand_out, terr, obs, park, ready, max_passes);
 }
 
