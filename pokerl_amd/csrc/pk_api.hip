@@ -136,9 +136,13 @@ __global__ void __launch_bounds__(PK_TABLE_BLOCK) k_pick(State S, Hot H, int pol
 #ifndef PK_ROLLOUT_ATTR
 #define PK_ROLLOUT_ATTR
 #endif
-template <int N, bool ONE_PASS>
-__device__ __forceinline__ void rollout_body(const State *__restrict__ Sp, const Hot &H, int K, int policy, int auto_reset, int park, int slack, int clear_terr) {
+// POLICY (the in-kernel agents) is a template parameter: with a run-time policy the random agent's LDS lookup sat in a
+// basic block of its own and its latency could not be overlapped with the action-independent part of the step
+// (+2.4 % at 65 536 x 6).
+template <int N, bool ONE_PASS, int POLICY>
+__device__ __forceinline__ void rollout_body(const State *__restrict__ Sp, const Hot &H, int K, int auto_reset, int park, int slack, int clear_terr) {
     // Array bases by pointer (loaded only where the table is loaded / stored), loop scalars by value: see pk::Hot.
+    constexpr int policy = POLICY;
     const State &S = *Sp;
     __shared__ Lds<N> lds;
     const int t = blockIdx.x * H.tpb + threadIdx.x;
@@ -214,18 +218,26 @@ __device__ __forceinline__ void rollout_body(const State *__restrict__ Sp, const
 // Batches of up to two waves per SIMD: registers capped at 256 (no instantiation needs more; N = 10 uses 245), which
 // also steers the max-ILP scheduler to a slightly better schedule than an unlimited budget (24.1 vs 23.4 G at 65 536 x 6) ...
 template <int N>
-__global__ void __launch_bounds__(PK_TABLE_BLOCK, 2) PK_ROLLOUT_ATTR k_rollout(const State *__restrict__ Sp, Hot H, int K, int policy, int auto_reset, int park, int slack, int clear_terr) {
-    rollout_body<N, true>(Sp, H, K, policy, auto_reset, park, slack, clear_terr);
+__global__ void __launch_bounds__(PK_TABLE_BLOCK, 2) PK_ROLLOUT_ATTR k_rollout(const State *__restrict__ Sp, Hot H, int K, int auto_reset, int park, int slack, int clear_terr) {
+    rollout_body<N, true, PK_POLICY_RANDOM>(Sp, H, K, auto_reset, park, slack, clear_terr);
+}
+template <int N>
+__global__ void __launch_bounds__(PK_TABLE_BLOCK, 2) PK_ROLLOUT_ATTR k_rollout_allin(const State *__restrict__ Sp, Hot H, int K, int auto_reset, int park, int slack, int clear_terr) {
+    rollout_body<N, true, PK_POLICY_ALLIN>(Sp, H, K, auto_reset, park, slack, clear_terr);
 }
 // ... larger batches: capped at 168 for three waves per SIMD (no spill up to N = 7).  The third wave is worth +19 % at
-// 1 M x 6 (44.0 G env-steps/s) and +14 % at 524 288 x 9 in spite of 92 B of scratch per lane; a cap of 128 (four waves)
-// spills too much (18.4 G at 65 536 x 6).
+// 1 M x 6 (44.0 G env-steps/s) and +14 % at 524 288 x 9 in spite of the scratch traffic at N >= 8; a cap of 128 (four
+// waves) spills too much (18.4 G at 65 536 x 6).
 #ifndef PK_OCC_CAP
 #define PK_OCC_CAP 3
 #endif
 template <int N>
-__global__ void __launch_bounds__(PK_TABLE_BLOCK, PK_OCC_CAP) k_rollout_occ3(const State *__restrict__ Sp, Hot H, int K, int policy, int auto_reset, int park, int slack, int clear_terr) {
-    rollout_body<N, true>(Sp, H, K, policy, auto_reset, park, slack, clear_terr);
+__global__ void __launch_bounds__(PK_TABLE_BLOCK, PK_OCC_CAP) k_rollout_occ3(const State *__restrict__ Sp, Hot H, int K, int auto_reset, int park, int slack, int clear_terr) {
+    rollout_body<N, true, PK_POLICY_RANDOM>(Sp, H, K, auto_reset, park, slack, clear_terr);
+}
+template <int N>
+__global__ void __launch_bounds__(PK_TABLE_BLOCK, PK_OCC_CAP) k_rollout_occ3_allin(const State *__restrict__ Sp, Hot H, int K, int auto_reset, int park, int slack, int clear_terr) {
+    rollout_body<N, true, PK_POLICY_ALLIN>(Sp, H, K, auto_reset, park, slack, clear_terr);
 }
 
 // PokerGameEnv.reset / .step (envs/game_env.py:20-29, :31-53) share k_rollout's shape: ONE flat loop in which every
@@ -747,12 +759,15 @@ static inline int flat_grid(size_t n) { return (int)((n + 255) / 256); }
 // wave have work left (endk == 1: runs to completion).
 static int launch_rollout(pk_handle *h, int k_steps, int policy, int auto_reset, int endk) {
     const int slack = endk <= 1 ? PK_WAVE : ((PK_WAVE - endk) * h->tpb) / PK_WAVE;   // lanes allowed to idle before a launch ends
-    if (!h->occ3)
-        DISPATCH_N(h, k_rollout, table_grid(h), (const State *)h->d_S, h->hot, k_steps, policy, auto_reset, scaled_park(h), slack,
-                   h->pending ? 0 : 1);
-    else
-        DISPATCH_N(h, k_rollout_occ3, table_grid(h), (const State *)h->d_S, h->hot, k_steps, policy, auto_reset, scaled_park(h), slack,
-                   h->pending ? 0 : 1);
+#define ROLLOUT_ARGS (const State *)h->d_S, h->hot, k_steps, auto_reset, scaled_park(h), slack, h->pending ? 0 : 1
+    if (!h->occ3) {
+        if (policy == PK_POLICY_RANDOM) DISPATCH_N(h, k_rollout, table_grid(h), ROLLOUT_ARGS);
+        else DISPATCH_N(h, k_rollout_allin, table_grid(h), ROLLOUT_ARGS);
+    } else {
+        if (policy == PK_POLICY_RANDOM) DISPATCH_N(h, k_rollout_occ3, table_grid(h), ROLLOUT_ARGS);
+        else DISPATCH_N(h, k_rollout_occ3_allin, table_grid(h), ROLLOUT_ARGS);
+    }
+#undef ROLLOUT_ARGS
     HIPCHK(h, hipGetLastError());
     h->pending = slack < PK_WAVE;
     h->pend_policy = policy; h->pend_auto = auto_reset;
@@ -947,7 +962,7 @@ int pk_wait_event(pk_handle *h, void *event) {
 int pk_record_event(pk_handle *h, void *event) {
     if (!h || !event) return PK_E_INVALID_ARG;
     ON_DEVICE(h);
-    FLUSH(h);  // "everything requested so far" includes deferred rollout steps
+    if (!h->env_pending) FLUSH(h);  // "everything requested so far" includes deferred rollout steps (env steps in flight stay so)
     HIPCHK(h, hipEventRecord((hipEvent_t)event, h->stream));
     return PK_OK;
 }
@@ -1213,6 +1228,7 @@ static int fetch_counters(pk_handle *h, uint64_t *counters) {
 // fused: one launch that may leave work for later (counters == NULL) or must complete it (counters != NULL);
 // unfused: k_steps complete single-step launches (state round-trips HBM every step).
 static int enqueue_rollout(pk_handle *h, int k_steps, int policy, int auto_reset, int fused, bool complete) {
+    if (h->env_pending) return flush(h);   // PK_E_BUSY
     if (h->pending && (policy != h->pend_policy || auto_reset != h->pend_auto)) FLUSH(h);  // owed steps keep THEIR agents
     if (!fused) {
         FLUSH(h);

@@ -372,6 +372,8 @@ def test_async_env_step_delivers_the_synchronous_sequences(HB, O):
             # steps may be in flight: observers refuse, pk_sync waits, a draining call delivers everything and unlocks
             with pytest.raises(L.PokerlHipError):
                 g.credits
+            with pytest.raises(L.PokerlHipError):
+                g.rollout(4, 0)
             if supplied:
                 a = np.full(T, -1, np.int32)
                 a[r] = choose(row[r], count[r])
