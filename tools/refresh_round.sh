@@ -23,5 +23,8 @@ python bench.py --tables 1048576 --no-cpu-baseline --no-evaluator --samples 3 --
 python bench.py --unfused --steps 512 --warmup 64 --no-cpu-baseline --no-evaluator --samples 3 > gpurun_out/${R}_bench_65536x6_unfused.json 2>/dev/null
 python bench.py --mode env --steps 200 --warmup 20 2>/dev/null | tail -1 > gpurun_out/${R}_bench_env.json
 python bench.py --mode env --env-unfused --steps 200 --warmup 20 2>/dev/null | tail -1 > gpurun_out/${R}_bench_env_unfused.json
+python bench.py --mode env --steps 200 --warmup 20 --env-batches 4 2>/dev/null | tail -1 > gpurun_out/${R}_bench_env_sync_batches4.json
+python bench.py --mode env --steps 2000 --warmup 200 --env-async 8 2>/dev/null | tail -1 > gpurun_out/${R}_bench_env_async8_batches1.json
+python bench.py --mode env --steps 2000 --warmup 200 --env-async 8 --env-batches 4 2>/dev/null | tail -1 > gpurun_out/${R}_bench_env_async8_batches4.json
 python tools/launch_overhead.py > gpurun_out/${R}_launch_overhead.txt 2>&1
 echo refreshed $R

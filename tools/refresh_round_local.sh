@@ -14,7 +14,7 @@ PY
 done
 cp gpurun_out/blockprof_${R}_n6.txt gpurun_out/blockprof_${R}_n9_allin.txt profiles/
 cp gpurun_out/${R}_launch_overhead.txt profiles/${R}_launch_overhead.txt
-for f in driver 65536x6 65536x9_allin 4096x2 1048576x6 65536x6_unfused env env_unfused; do
+for f in driver 65536x6 65536x9_allin 4096x2 1048576x6 65536x6_unfused env env_unfused env_sync_batches4 env_async8_batches1 env_async8_batches4; do
   tail -1 gpurun_out/${R}_bench_$f.json > profiles/${R}_bench_$f.json
   python - <<PY
 import json
