@@ -162,13 +162,16 @@ __device__ __forceinline__ void rollout_body(const State *__restrict__ Sp, const
     const int cap = __popcll(__ballot(live && (owed > 0 || tb.lstate == LS_END)));
     const int quit = max(1, cap - slack);
     PK_PROF(tb.prof.start();)
-    auto retire = [&]() {  // a lane whose Game.step() has returned
-        if (tb.stepped && tb.lstate == LS_DONE) {
-            tb.finish_step();
-            --owed;
-            if (tb.terr) { alive = false; owed = 0; }  // table keeps its (reference-identical) state; reported through terr
-            else { ++steps; tb.games += tb.flags & PK_FLAG_GAME_OVER; }
-        }
+    auto retire = [&]() {  // a lane whose Game.step() has returned (selects, not branches: nearly every lane, every pass)
+        const bool r = tb.stepped && tb.lstate == LS_DONE;
+        const bool bad = r && tb.terr != 0;            // table keeps its (reference-identical) state; reported through terr
+        const bool good = r && tb.terr == 0;
+        tb.step_serial += (r && !(tb.terr & PK_TERR_NO_WINNER)) ? 1u : 0u;   // finish_step()
+        tb.stepped = r ? 0u : tb.stepped;
+        owed = bad ? 0u : owed - (r ? 1u : 0u);
+        alive = alive && !bad;
+        steps += good ? 1u : 0u;
+        tb.games += good ? (tb.flags & PK_FLAG_GAME_OVER) : 0u;
     };
 #ifndef PK_BET_PASSES
 #define PK_BET_PASSES 4   // betting passes between two looks at the parked lanes: end_block then serves what four passes
@@ -186,7 +189,8 @@ __device__ __forceinline__ void rollout_body(const State *__restrict__ Sp, const
                                                            : action_from_draw_lds(lds, ActionRing::half_of(word, tb.step_serial), mask), high_bet);
             }
             PK_PROF(tb.prof.lap(PF_ACTION);)
-            tb.cursor();
+            tb.scan_first();      // every lane in LS_SCAN: the steps just begun and the ones end_block carried into a new hand
+            tb.cursor_tail();
             PK_PROF(tb.prof.count(PF_N_CURSOR);)
             retire();
             PK_PROF(tb.prof.lap(PF_CURSOR);)

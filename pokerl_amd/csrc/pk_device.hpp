@@ -774,16 +774,37 @@ struct Table {
     __device__ __forceinline__ void cursor() {
         if (lstate != LS_SCAN) return;
         if (scan()) { lstate = LS_DONE; return; }
+        next_turns();
+    }
+    // The same in two halves for k_rollout's betting pass: scan_first() is branch-free (nearly every step ends there);
+    // cursor_tail() is the divergent rest for the lanes whose walk failed.  cursor_tail() ONLY after scan_first().
+    __device__ __forceinline__ void scan_first() {
+        int d = current - active; d = d < 0 ? d + N : d;
+        uint32_t window = rotr(st_active, active) & ((2u << d) - 1);
+        int a = active + (__ffs(window) - 1); a = a >= N ? a - N : a;
+        const bool hit = lstate == LS_SCAN && window != 0;
+        active = hit ? a : active;
+        lstate = hit ? (int)LS_DONE : lstate;
+    }
+    __device__ __forceinline__ void cursor_tail() {
+        if (lstate != LS_SCAN) return;
+        active = current;                                                          // the failed walk ends at current_player
+        next_turns();
+    }
+    __device__ __forceinline__ void next_turns() {
         PK_FOR(p, N) bets[p] = bets[p] + pending[p]; credits[p] = credits[p] - pending[p]; pending[p] = 0.0; PK_END  // :554-557
         min_raise = 0.0;                                                           // :558
         turn += 1;                                                                 // :561
-        bool found = false;
-        if (turn < 4) {                                                            // :566-576
-            if (__popc(st_called) > 1) { st_active |= st_called; st_called = 0; }
-            active = first_playing(dealer + 1);
-            flags = PK_FLAG_TURN_OVER;
-            found = scan();
-        }
+        const bool more = turn < 4;                                                // :566-576, as selects (one basic block)
+        const bool merge = more && __popc(st_called) > 1;
+        st_active |= merge ? st_called : 0u; st_called = merge ? 0u : st_called;
+        const int first = first_playing(dealer + 1);
+        int d = current - first; d = d < 0 ? d + N : d;                            // scan() from `first`
+        const uint32_t window = rotr(st_active, first) & ((2u << d) - 1);
+        int a = first + (__ffs(window) - 1); a = a >= N ? a - N : a;
+        const bool found = more && window != 0;
+        active = more ? (window ? a : current) : active;
+        flags = more ? (uint32_t)PK_FLAG_TURN_OVER : flags;
         lstate = found ? LS_DONE : LS_END;                                         // :563-565 (turn 4, now or after no-op turns)
         turn = found ? turn : 4;
         foldout = false;
@@ -815,18 +836,17 @@ struct Table {
             uint32_t pw = (st_active | st_called | st_allin) & FULL;               // :471 (not BROKEN, not FOLDED)
             const int npw = __popc(pw);                                            // :472
             nowin = npw <= 0;                                                      // :473
-            if (npw == 1) {                                                        // :475-480
-                int winner = __ffs(pw) - 1;
-                double pot = np_sum<N>(bets);
+            {                                                                      // :475-480 (selects: one basic block)
+                const int winner = (npw == 1) ? __ffs(pw) - 1 : -1;
+                const double pot = np_sum<N>(bets);
                 PK_FOR(p, N)
                     payoffs[p] = (p == winner) ? pot : payoffs[p];
                     credits[p] = (p == winner) ? credits[p] + pot : credits[p];
                  PK_END
-            } else if (npw > 1) {
-                sd = true;
-                showdown = (st_called | st_allin) & FULL;                          // :488, :496
-                pot_npw = npw;
             }
+            sd = npw > 1;
+            showdown = sd ? (st_called | st_allin) & FULL : 0u;                    // :488, :496
+            pot_npw = sd ? npw : pot_npw;
         }
         PK_PROF(prof.lap(PF_END_PRE);)
         // ---- showdown hands of all arriving lanes -> LDS queue -> one hand per lane (game.py:488-489)
@@ -909,12 +929,12 @@ struct Table {
             }
             // what the next pass of the loop would do: stop (:498, :499), hand everything left to the last potential
             // winner (:500-505; with one potential winner left at most one seat is left in `todo`), or go on
-            if (pot_todo == 0 || !left) pot_over = true;
-            else if (pot_npw == 1) {
-                const int player = __ffs(pot_todo) - 1;
-                double s = np_sum<N>(pot_wb);
+            {                                                                      // (selects: one basic block)
+                const bool stop = pot_todo == 0 || !left;
+                const int player = (!stop && pot_npw == 1) ? __ffs(pot_todo) - 1 : -1;
+                const double s = np_sum<N>(pot_wb);
                 PK_FOR(p, N) payoffs[p] = (p == player) ? payoffs[p] + s : payoffs[p]; PK_END
-                pot_over = true;
+                pot_over = stop || pot_npw == 1;
             }
             if (ONE_PASS || pot_over) break;
           }
@@ -935,21 +955,17 @@ struct Table {
                 st_active &= ~broke; st_called &= ~broke; st_allin &= ~broke; st_broken |= broke;
                 setup_state(S);                                                    // :539 (shuffle: deal() below)
                 const bool go = game_over();
-                if (foldout) { flags = (go ? PK_FLAG_GAME_OVER : 0) | PK_FLAG_HAND_OVER; lstate = LS_DONE; }   // :619
-                else {
-                    flags = (go ? PK_FLAG_GAME_OVER : 0) | PK_FLAG_HAND_OVER | PK_FLAG_TURN_OVER;              // :565
-                    if (go) lstate = LS_DONE;                                      // :610
-                    else {
-                        // The step can never return: (a) dead table -- every seat's credits are exactly 0 and no seat
-                        // is ACTIVE, so each further hand is a zero-chip showdown that re-creates this very state;
-                        // (b) backstop: PK_HAND_CAP hands inside one step.
-                        bool chips = false;
-                        PK_FOR(p, N) chips = chips || credits[p] != 0.0; PK_END
-                        const bool dead = !chips && st_active == 0;
-                        if (dead || hands_this_step > PK_HAND_CAP) { terr |= PK_TERR_HAND_CAP; lstate = LS_DONE; }
-                        else lstate = LS_SCAN;
-                    }
-                }
+                // fold-out: the step returns (:619).  Else TURN_OVER too (:565) and the step returns only if the game
+                // is over (:610) -- or if it never could: (a) dead table -- every seat's credits are exactly 0 and no
+                // seat is ACTIVE, so each further hand is a zero-chip showdown that re-creates this very state;
+                // (b) backstop: PK_HAND_CAP hands inside one step.  (Selects: one basic block up to the deal.)
+                bool chips = false;
+                PK_FOR(p, N) chips = chips || credits[p] != 0.0; PK_END
+                const bool dead = !chips && st_active == 0;
+                const bool capped = !foldout && !go && (dead || hands_this_step > PK_HAND_CAP);
+                flags = (go ? PK_FLAG_GAME_OVER : 0) | PK_FLAG_HAND_OVER | (foldout ? 0 : PK_FLAG_TURN_OVER);
+                terr |= capped ? PK_TERR_HAND_CAP : 0;
+                lstate = (foldout || go || capped) ? (int)LS_DONE : (int)LS_SCAN;
                 if (auto_reset && lstate == LS_DONE && (go || (terr & PK_TERR_HAND_CAP))) {
                     seen |= terr; terr = 0;
                     flags |= PK_FLAG_GAME_OVER;   // counted as a finished game by the caller (k_rollout's retire)
