@@ -177,6 +177,11 @@ __device__ __forceinline__ void rollout_body(const State *__restrict__ Sp, const
 #define PK_BET_PASSES 4   // betting passes between two looks at the parked lanes: end_block then serves what four passes
 #endif                    // have parked (1: 23.8 G, 2: 25.1 G, 3: 24.4 G, 4: 25.6 G, 6: 24.7 G, 8: 23.2 G at 65 536 x 6)
     for (;;) {
+        // Nothing is in flight at the top of an iteration.  Without this the compiler cannot rule out that a table
+        // register still waits for the global loads before the loop or for end_block's LDS reads (both sit in
+        // conditionally executed blocks), and parks a full s_waitcnt right behind the first LDS read of every betting
+        // pass: the action ring's latency was exposed three passes out of four.
+        if (policy == PK_POLICY_RANDOM) __builtin_amdgcn_s_waitcnt(0);   // (the all-in kernel has no LDS read in its passes)
         if (policy == PK_POLICY_RANDOM) ring.ensure(lds, H, table_id, tb.step_serial, alive && owed > 0, PK_BET_PASSES);   // wave-uniform
 #pragma unroll
         for (int pass = 0; pass < PK_BET_PASSES; ++pass) {

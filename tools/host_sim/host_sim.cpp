@@ -65,7 +65,15 @@ static int run(int T, int K, int policy, uint64_t seed, Cfg cfg = default_cfg(),
             ActionRing ring;   // the LDS ring of k_rollout (one lane)
             uint32_t draw = policy == 0 ? ActionRing::half_of(ring.draw16(lds, H, cfg.base + (uint32_t)t, x.step_serial, true), x.step_serial) : 0;
             x.begin_step(H, policy == 1 ? (int)MV_ALL_IN : action_from_draw(draw, mask), hb);
-            x.run(H, t, cfg.base + (uint32_t)t, lds, true);
+            if (k & 1) x.run(H, t, cfg.base + (uint32_t)t, lds, true);             // k_step's driver ...
+            else {                                                                 // ... and k_rollout's betting pass
+                for (;;) {
+                    x.scan_first(); x.cursor_tail();
+                    if (!x.parked()) break;
+                    x.end_block(H, t, cfg.base + (uint32_t)t, lds, true);
+                }
+                x.finish_step();
+            }
             x.store(S, t);
         }
         orc_get_f64(o, 0, oc.data()); orc_get_f64(o, 1, ob.data()); orc_get_f64(o, 2, op.data()); orc_get_f64(o, 3, oy.data());
