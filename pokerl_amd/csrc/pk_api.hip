@@ -400,6 +400,7 @@ __device__ __forceinline__ void env_step_body(const State *__restrict__ Sp, cons
             tb.reset_state(H, 0); tb.deal(H, table_id);
             phase = tb.active != 0 ? PH_RESET_PLAY : PH_END;                       // :24
         }
+        if (draws) __builtin_amdgcn_s_waitcnt(0);   // as in k_rollout: no stray full wait behind the passes' LDS reads
         if (draws) ring.ensure(lds, H, table_id, tb.step_serial, live && phase != PH_END, PK_ENV_PASSES);
 #pragma unroll
         for (int pass = 0; pass < PK_ENV_PASSES; ++pass) {
