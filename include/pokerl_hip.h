@@ -191,7 +191,8 @@ int pk_get_owed(pk_handle *h, uint32_t *out);
 /* Completes deferred rollout steps now (asynchronous on the handle's stream); a no-op when there are none. */
 int pk_flush(pk_handle *h);
 /* Tuning knobs of the fused rollout (values outside 1..64 leave the knob unchanged): `park` = lanes of a wave waiting at
- * end_hand before the wave runs it; `endk` = a deferred launch ends once fewer than this many lanes have work (1 = never defer). */
+ * end_hand before the wave runs it (default: per kernel, 28 for random agents, 32 otherwise); `endk` = a deferred launch
+ * ends once fewer than this many lanes have work (1 = never defer). */
 int pk_set_tuning(pk_handle *h, int park, int endk);
 
 /* PokerGameEnv.reset() / .step(action) (pokerl/envs/game_env.py:20-29, :31-53): seat 0 is the controlled seat,

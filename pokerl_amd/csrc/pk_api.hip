@@ -690,7 +690,10 @@ struct pk_handle {
     int device = 0, T = 0, N = 0, block = 64, dealer = 0;
     int tpb = 64;   // tables per wavefront (Hot::tpb)
     bool occ3 = true;  // k_rollout_occ3 (registers capped for 3 waves per SIMD) vs k_rollout; knob PK_OCC3
-    int park = 32;  // lanes parked at end_hand before a wave runs end_block (k_rollout looks every 4 betting passes); knob PK_PARK
+    // lanes parked at end_hand before a wave runs end_block (the kernels look every 4 betting passes); knob PK_PARK /
+    // pk_set_tuning.  0 = the measured optimum of each kernel: 28 for k_rollout with random agents (20.9 vs 20.6 G at
+    // 20-step launches, the same at long ones), 32 for the all-in agents (44.3 vs 43.3 G) and for the env kernels.
+    int park = 0;
     int endk = 48;  // a deferred rollout launch ends once fewer than this many of a wave's lanes have work; knob PK_ENDK
                     // (measured optimum 44..52 at 20 and at 512 steps per launch: tools/tune_sweep.py)
     // Deferred rollout work: steps requested by pk_rollout that no launch has executed yet may exist on the device
@@ -762,14 +765,17 @@ struct DeviceGuard {
 
 static inline int table_grid(const pk_handle *h) { return (h->T + h->tpb - 1) / h->tpb; }
 // parking threshold for waves that hold h->tpb tables instead of 64
-static inline int scaled_park(const pk_handle *h) { int p = (h->park * h->tpb + 63) / 64; return p < 1 ? 1 : p; }
+static inline int scaled_park(const pk_handle *h, int dflt = 32) {
+    int p = ((h->park > 0 ? h->park : dflt) * h->tpb + 63) / 64;
+    return p < 1 ? 1 : p;
+}
 static inline int flat_grid(size_t n) { return (int)((n + 255) / 256); }
 
 // One fused rollout launch: every table owes k_steps more steps; the launch ends once fewer than `endk` lanes of a
 // wave have work left (endk == 1: runs to completion).
 static int launch_rollout(pk_handle *h, int k_steps, int policy, int auto_reset, int endk) {
     const int slack = endk <= 1 ? PK_WAVE : ((PK_WAVE - endk) * h->tpb) / PK_WAVE;   // lanes allowed to idle before a launch ends
-#define ROLLOUT_ARGS (const State *)h->d_S, h->hot, k_steps, auto_reset, scaled_park(h), slack, h->pending ? 0 : 1
+#define ROLLOUT_ARGS (const State *)h->d_S, h->hot, k_steps, auto_reset, scaled_park(h, policy == PK_POLICY_RANDOM ? 28 : 32), slack, h->pending ? 0 : 1
     if (!h->occ3) {
         if (policy == PK_POLICY_RANDOM) DISPATCH_N(h, k_rollout, table_grid(h), ROLLOUT_ARGS);
         else DISPATCH_N(h, k_rollout_allin, table_grid(h), ROLLOUT_ARGS);
