@@ -390,7 +390,8 @@ struct Prof {
 
 template <int N>
 struct Lds {  // per workgroup (= one wavefront); ~10 KB at N = 10
-    uint32_t item[64 * N][2];  // [0] = community cards 0..3 (bytes); [1] = card4 | hole0<<6 | hole1<<12 | dest<<18
+    uint32_t item[64 * N + 64][2];  // [0] = community cards 0..3 (bytes); [1] = card4 | hole0<<6 | hole1<<12 | dest<<18
+                               // (the last 64 entries: one scratch slot per lane for the writes of seats not in the showdown)
     uint32_t res[64 * N];      // dest = lane*N + seat -> HandRanking<<20 | kickers
     uint32_t act[8][64];       // k_rollout's action draws: two Philox blocks per lane, [slot * 4 + word][lane]
     uint32_t show[N][64];      // rankings of each lane's last showdown; written back by Table::store_show at kernel end
@@ -858,11 +859,10 @@ struct Table {
             total += (uint32_t)__popcll(bal);
          PK_END
         if (total) {  // wave-uniform
-            PK_FOR(p, N)
-                if ((showdown >> p) & 1) {                                         // hand = deck[:5] + hole cards (:394-395)
-                    lds.item[my_base[p]][0] = cards[0];
-                    lds.item[my_base[p]][1] = card(4) | (card(5 + 2 * p) << 6) | (card(6 + 2 * p) << 12) | ((uint32_t)(lane * N + p) << 18);
-                }
+            PK_FOR(p, N)                                                           // hand = deck[:5] + hole cards (:394-395)
+                const uint32_t slot = ((showdown >> p) & 1) ? my_base[p] : (uint32_t)(64 * N + lane);   // no branch per seat
+                lds.item[slot][0] = cards[0];
+                lds.item[slot][1] = card(4) | (card(5 + 2 * p) << 6) | (card(6 + 2 * p) << 12) | ((uint32_t)(lane * N + p) << 18);
              PK_END
             __syncthreads();
             for (uint32_t base = 0; base < total; base += PK_WAVE) {
