@@ -173,9 +173,17 @@ __device__ __forceinline__ void rollout_body(const State *__restrict__ Sp, const
         steps += good ? 1u : 0u;
         tb.games += good ? (tb.flags & PK_FLAG_GAME_OVER) : 0u;
     };
+// Which of the betting passes also run cursor_tail() (next_turn for the lanes whose seat walk failed: ~75 instructions for
+// ~1 lane in 5).  Every other pass: the block runs half as often over twice the lanes, a lane waits at most one pass
+// (29.7 vs 28.6 G at 65 536 x 6; last pass only 28.7, passes 0+3 29.1, six passes with three tails 29.2).  The LAST
+// pass must be in the mask: no lane may be left in LS_SCAN when the wave looks at its parked lanes or leaves the loop.
+#ifndef PK_TAIL_MASK
+#define PK_TAIL_MASK 0xA
+#endif
 #ifndef PK_BET_PASSES
 #define PK_BET_PASSES 4   // betting passes between two looks at the parked lanes: end_block then serves what four passes
 #endif                    // have parked (1: 23.8 G, 2: 25.1 G, 3: 24.4 G, 4: 25.6 G, 6: 24.7 G, 8: 23.2 G at 65 536 x 6)
+    static_assert(((PK_TAIL_MASK) >> (PK_BET_PASSES - 1)) & 1, "the last betting pass must run cursor_tail()");
     for (;;) {
         // Nothing is in flight at the top of an iteration.  Without this the compiler cannot rule out that a table
         // register still waits for the global loads before the loop or for end_block's LDS reads (both sit in
@@ -195,7 +203,7 @@ __device__ __forceinline__ void rollout_body(const State *__restrict__ Sp, const
             }
             PK_PROF(tb.prof.lap(PF_ACTION);)
             tb.scan_first();      // every lane in LS_SCAN: the steps just begun and the ones end_block carried into a new hand
-            tb.cursor_tail();
+            if ((PK_TAIL_MASK >> pass) & 1) tb.cursor_tail();
             PK_PROF(tb.prof.count(PF_N_CURSOR);)
             retire();
             PK_PROF(tb.prof.lap(PF_CURSOR);)
