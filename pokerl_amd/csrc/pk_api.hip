@@ -233,7 +233,7 @@ __device__ __forceinline__ void rollout_body(const State *__restrict__ Sp, const
 }
 
 // Batches of up to two waves per SIMD: registers capped at 256 (no instantiation needs more; N = 10 uses 245), which
-// also steers the max-ILP scheduler to a slightly better schedule than an unlimited budget (24.1 vs 23.4 G at 65 536 x 6) ...
+// also steers the max-ILP scheduler to a slightly better schedule than an unlimited budget (24.1 vs 23.4 G at 65 536 x 6 when it was introduced) ...
 template <int N>
 __global__ void __launch_bounds__(PK_TABLE_BLOCK, 2) PK_ROLLOUT_ATTR k_rollout(const State *__restrict__ Sp, Hot H, int K, int auto_reset, int park, int slack, int clear_terr) {
     rollout_body<N, true, PK_POLICY_RANDOM>(Sp, H, K, auto_reset, park, slack, clear_terr);
@@ -243,7 +243,7 @@ __global__ void __launch_bounds__(PK_TABLE_BLOCK, 2) PK_ROLLOUT_ATTR k_rollout_a
     rollout_body<N, true, PK_POLICY_ALLIN>(Sp, H, K, auto_reset, park, slack, clear_terr);
 }
 // ... larger batches: capped at 168 for three waves per SIMD (no spill up to N = 7).  The third wave is worth +19 % at
-// 1 M x 6 (44.0 G env-steps/s) and +14 % at 524 288 x 9 in spite of the scratch traffic at N >= 8; a cap of 128 (four
+// 1 M x 6 (49 G env-steps/s) and +14 % at 524 288 x 9 in spite of the scratch traffic at N >= 8; a cap of 128 (four
 // waves) spills too much (18.4 G at 65 536 x 6).
 #ifndef PK_OCC_CAP
 #define PK_OCC_CAP 3

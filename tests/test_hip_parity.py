@@ -364,7 +364,7 @@ def test_all_player_counts_fused_vs_oracle(HB, O):
 
 @pytest.mark.parametrize("occ3", ["0", "1"])
 def test_both_rollout_kernels_vs_oracle(HB, O, monkeypatch, occ3):
-    """k_rollout (uncapped registers) and k_rollout_occ3 (capped for three waves per SIMD; spills to scratch at N >= 8)
+    """k_rollout (registers capped at 256) and k_rollout_occ3 (capped for three waves per SIMD; spills to scratch at N >= 8)
     are picked by batch shape; PK_OCC3 forces either, and both must be bit-exact for every seat count."""
     monkeypatch.setenv("PK_OCC3", occ3)
     for N, T, policy, K in [(6, 5000, 0, 150), (9, 3000, 1, 60), (10, 2000, 0, 120), (8, 140000, 0, 10), (2, 70000, 0, 40)]:
