@@ -67,3 +67,25 @@ class VecPokerGameEnv:
         L.check(g._lib.pk_env_step_async_d(g._h, vp(actions_d), int(seat0_policy), self.opp_policy, 1 if auto_reset else 0,
                                            int(max_passes), vp(reward_d), vp(done_d), vp(hand_d), vp(terr_d), vp(obs_d),
                                            vp(ready_d)), g._h)
+
+    def step_async(self, actions=None, max_passes=8, seat0_policy=Policy.RANDOM, auto_reset=True):
+        """Host-array convenience over step_async_d: returns (ready bool[T], obs f64[T, D], reward f64[T], done bool[T],
+        hand bool[T], terr u8[T]); rows are meaningful where `ready`.  `actions` (int32[T], None = seat 0 played by
+        `seat0_policy` in-kernel) is read for the tables that were ready after the previous call only."""
+        from .hipmem import DeviceBuffer
+        g = self.game
+        T, D = g.num_tables, 17 + 3 * g.num_players
+        if not hasattr(self, '_async_buf'):
+            dev = g.device
+            self._async_buf = dict(act=DeviceBuffer(T * 4, dev), rew=DeviceBuffer(T * 8, dev), done=DeviceBuffer(T, dev),
+                                   hand=DeviceBuffer(T, dev), terr=DeviceBuffer(T, dev), obs=DeviceBuffer(T * D * 8, dev),
+                                   ready=DeviceBuffer(T, dev))
+        b = self._async_buf
+        if actions is not None:
+            b['act'].upload(g._actions(actions))
+        self.step_async_d(b['act'].ptr if actions is not None else None, b['rew'].ptr, b['done'].ptr, b['hand'].ptr,
+                          b['terr'].ptr, b['obs'].ptr, b['ready'].ptr, max_passes, seat0_policy, auto_reset)
+        g.sync()
+        return (b['ready'].download(np.uint8, T) != 0, b['obs'].download(np.float64, T * D).reshape(T, D),
+                b['rew'].download(np.float64, T), b['done'].download(np.uint8, T) != 0,
+                b['hand'].download(np.uint8, T) != 0, b['terr'].download(np.uint8, T))

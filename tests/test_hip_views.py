@@ -383,3 +383,37 @@ def test_async_env_step_delivers_the_synchronous_sequences(HB, O):
             assert (ready.download(np.uint8, T) != 0).all() and not terr.download(np.uint8, T).any()
             assert GU.bits_equal(obs.download(np.float64, T * D).reshape(T, D), g.observations)
             g.close()
+
+
+@pytest.mark.gpu
+def test_async_env_step_host_arrays(HB, O):
+    """VecPokerGameEnv.step_async (host arrays over pk_env_step_async_d): the delivered rows equal the synchronous
+    env.step's for each table's k-th step; a drain delivers every table."""
+    import pokerl_amd
+    T, N, K = 512, 5, 12
+    sync_env = pokerl_amd.VecPokerGameEnv(0, num_tables=T, num_players=N, seed=5)
+    o = O.OracleGame(T, N, seed=5)
+    sync_env.reset(); o.env_reset(None, 0)
+    want = []
+    for k in range(K):
+        a = o.pick_actions(0)
+        ro, do, ho, eo = o.env_step(a, 0)
+        if do.any():
+            o.env_reset(do, 0)
+        want.append((ro, do != 0, ho != 0))
+    env = pokerl_amd.VecPokerGameEnv(0, num_tables=T, num_players=N, seed=5)
+    env.reset()
+    count = np.zeros(T, np.int64)
+    for launch in range(400):
+        ready, obs, rew, done, hand, terr = env.step_async(None, max_passes=4)
+        assert not terr[ready].any()
+        for t in np.nonzero(ready & (count < K))[0]:
+            k = count[t]
+            assert GU.bits_equal(rew[t:t + 1], want[k][0][t:t + 1]) and done[t] == want[k][1][t] and hand[t] == want[k][2][t], (t, k)
+        count[ready] += 1
+        if count.min() >= K:
+            break
+    assert count.min() >= K
+    ready, obs, *_ = env.step_async(None, max_passes=0)
+    assert ready.all() and GU.bits_equal(obs, env.game.observations)
+    env.game.close(); sync_env.game.close()
