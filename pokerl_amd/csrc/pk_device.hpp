@@ -882,14 +882,10 @@ struct Table {
             PK_FOR(p, N) pot_hv[p] = NONE_V; PK_END                                // potential winners, none of them CALLED / ALL_IN
         }
         PK_PROF(prof.lap(PF_EVAL);)
-        if (sd) {
-            PK_FOR(p, N)
-                pot_wb[p] = bets[p];                                               // :485
-                lds.show[p][lane] = pot_hv[p];
-             PK_END
-            showed = true;
-            pot_todo = showdown;                                                   // :495-496 argsort(bets) filtered, stable
-        }
+        PK_FOR(p, N) pot_wb[p] = sd ? bets[p] : pot_wb[p]; PK_END                  // :485 (selects: one basic block)
+        pot_todo = sd ? showdown : pot_todo;                                       // :495-496 argsort(bets) filtered, stable
+        showed = showed || sd;
+        if (sd) { PK_FOR(p, N) lds.show[p][lane] = pot_hv[p]; PK_END }             // (an unconditional write to a scratch row: slower)
         // ---- the side-pot loop (:498-525) for the arriving showdowns and the ones still in it: per call ONE pass of
         //      the general body plus, if that leaves a single potential winner, the closing pass of :500-505.
         bool pot_over = false;
