@@ -330,13 +330,15 @@ __device__ __forceinline__ uint32_t eval7_distinct(const uint32_t (&c)[7]) {
         taken |= take ? bit : 0; L = take ? (L & ~bit) : L;
     }
     uint32_t m = base & ~taken;
+    // the top five ranks of m unconditionally (an exhausted mask yields rank nibble 0), then the top nm of them by a shift
+    uint32_t k5 = 0;
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
-        uint32_t bit = 0x80000000u >> (__clz((int)m) & 31);
-        bool take = i < nm;
-        kick = take ? ((kick << 4) | (uint32_t)(32 - __clz((int)m))) : kick;
-        m = take ? (m & ~bit) : m;
+        const uint32_t lz = (uint32_t)__clz((int)m);
+        k5 = (k5 << 4) | (32u - lz);
+        m &= ~(0x80000000u >> (lz & 31));
     }
+    kick = (kick << (4 * nm)) | (nm ? (k5 >> (4 * (5 - nm))) : 0u);
     return (cat << 20) | kick;
 }
 
