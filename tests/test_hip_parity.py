@@ -679,3 +679,38 @@ def test_bench_json_contract():
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and cb["unit"] == "env-steps/s" and cb["sample"]
     ev = r["evaluator"]
     assert ev["roofline"]["bytes_per_eval"] == 12 and ev["hand_evals_per_s"] > 0
+
+
+@pytest.mark.parametrize("N,policy", [(6, 0), (9, 1), (2, 0), (10, 0)])
+def test_full_width_waves_lockstep_and_env(HB, O, monkeypatch, N, policy):
+    """Batches below 32 769 tables spread over 1 024 waves with fewer than 64 tables each (Hot::tpb), so the small
+    lockstep / env cases above never fill a wave.  PK_TPB=64 forces full waves: pk_step (k_step), pk_pick_actions,
+    pk_reset with a mask, pk_env_reset / pk_env_step and the getters against the oracle with 64 tables per wave."""
+    monkeypatch.setenv("PK_TPB", "64")
+    T = 2048 + 37                                      # ragged last wave
+    o = O.OracleGame(T, N, seed=4242)
+    h = HB(T, N, seed=4242)
+    o.reset(); h.reset()
+    for s in range(160):
+        a = o.pick_actions(policy)
+        assert np.array_equal(a, h.pick_actions(policy))
+        fo, eo = o.step(a)
+        fh, eh = h.step(a)
+        assert np.array_equal(fo, fh) and np.array_equal(eo, eh), s
+        over = (fo & 1).astype(np.uint8)
+        if over.any():
+            o.reset(mask=over); h.reset(mask=over)
+        if s % 20 == 0:
+            assert_same(o.snapshot(), h.snapshot(), "step %d" % s)
+    assert_same(o.snapshot(), h.snapshot(), "lockstep")
+    o.env_reset(None, policy); h.env_reset(None, policy)
+    assert_same(o.snapshot(), h.snapshot(), "env reset")
+    for s in range(40):
+        a = o.pick_actions(0)
+        ro, do, ho, eo = o.env_step(a, policy)
+        rh, dh, hh, eh = h.env_step(a, policy)
+        assert GU.bits_equal(ro, rh) and np.array_equal(do, dh) and np.array_equal(ho, hh) and np.array_equal(eo, eh), s
+        m = ((do != 0) | (eo != 0)).astype(np.uint8)
+        if m.any():
+            o.env_reset(m, policy); h.env_reset(m, policy)
+    assert_same(o.snapshot(), h.snapshot(), "env")

@@ -294,7 +294,7 @@ def test_fused_env_step_matches_the_separate_calls(HB, O):
 
 
 @pytest.mark.gpu
-def test_async_env_step_delivers_the_synchronous_sequences(HB, O):
+def test_async_env_step_delivers_the_synchronous_sequences(HB, O, monkeypatch):
     """pk_env_step_async_d: bounded launches, tables whose PokerGameEnv.step has not returned stay in flight.  Per table
     the delivered (reward, done, hand, obs row) sequence must be bit-identical to the synchronous fused call's (whose
     reward / done / hand are checked against the oracle here as well), whatever the pass budget -- with seat 0 played
@@ -310,7 +310,13 @@ def test_async_env_step_delivers_the_synchronous_sequences(HB, O):
         nth = k % mask.sum(axis=1)
         return ((np.cumsum(mask, axis=1) - 1 == nth[:, None]) & mask).argmax(axis=1).astype(np.int32)
 
-    for T, N, opp, K, passes in [(4096, 6, 0, 40, 6), (1000, 3, 0, 40, 1), (640, 9, 1, 25, 3), (2048, 2, 0, 40, 2), (512, 4, 0, 30, 13)]:
+    # small batches put few tables into each wave (Hot::tpb); the last two cases force full 64-table waves (PK_TPB)
+    for T, N, opp, K, passes, tpb in [(4096, 6, 0, 40, 6, None), (1000, 3, 0, 40, 1, None), (640, 9, 1, 25, 3, None),
+                                      (2048, 2, 0, 40, 2, None), (512, 4, 0, 30, 13, None), (4096, 6, 0, 30, 8, 64), (1111, 7, 0, 20, 4, 64)]:
+        if tpb:
+            monkeypatch.setenv("PK_TPB", str(tpb))
+        else:
+            monkeypatch.delenv("PK_TPB", raising=False)
         D = 17 + 3 * N
         rew, done, hand, terr, obs, ready, act = (DeviceBuffer(T * 8), DeviceBuffer(T), DeviceBuffer(T), DeviceBuffer(T),
                                                   DeviceBuffer(T * D * 8), DeviceBuffer(T), DeviceBuffer(T * 4))
