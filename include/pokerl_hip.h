@@ -233,7 +233,9 @@ int pk_env_step_fused_d(pk_handle *h, const int32_t *actions_d, int seat0_policy
  * returns at once (ready, PK_TERR_INVALID_ACTION, untouched).  Per table the sequence of steps, outputs and RNG draws is
  * exactly that of pk_env_step_fused_d; only the call that delivers them differs.  max_passes <= 0: run every step to its
  * end (every table ready).  While steps may be in flight (after any call with max_passes > 0) all other entry points
- * that read or change tables return PK_E_BUSY (pk_sync only waits); a call with max_passes <= 0 ends that state. */
+ * that read or change tables return PK_E_BUSY (pk_sync only waits); a call with max_passes <= 0 ends that state.
+ * Use auto_reset != 0 with bounded launches: pk_env_reset_d is one of the entry points that are busy meanwhile, so a
+ * finished episode could only be reset after a drain. */
 int pk_env_step_async_d(pk_handle *h, const int32_t *actions_d, int seat0_policy, int opp_policy, int auto_reset,
                         int max_passes, double *reward_d, uint8_t *done_d, uint8_t *hand_d, uint8_t *terr_d,
                         double *obs_d, uint8_t *ready_d);
