@@ -422,4 +422,12 @@ def test_async_env_step_host_arrays(HB, O):
     assert count.min() >= K
     ready, obs, *_ = env.step_async(None, max_passes=0)
     assert ready.all() and GU.bits_equal(obs, env.game.observations)
+    # an invalid supplied action: the table returns at once, untouched, with PK_TERR_INVALID_ACTION (game.py:649-651)
+    before = (env.game.credits.copy(), env.game.step_serial.copy())
+    bad = np.full(T, 7, np.int32)
+    bad[::2] = -1
+    ready, obs2, rew, done, hand, terr = env.step_async(bad, max_passes=0)
+    assert ready.all() and (terr == 1).all() and not rew.any() and not done.any()
+    assert GU.bits_equal(before[0], env.game.credits) and np.array_equal(before[1], env.game.step_serial)
+    assert GU.bits_equal(obs2, obs)
     env.game.close(); sync_env.game.close()
