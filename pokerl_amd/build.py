@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpokerl_hip.so")
 SOURCES = ["pk_api.hip"]
-HEADERS = [os.path.join(CSRC, "pk_device.hpp"), os.path.join(os.path.dirname(HERE), "include", "pokerl_hip.h")]
+HEADERS = [os.path.join(CSRC, "pk_device.hpp"), os.path.join(CSRC, "pk_kernels.hpp"), os.path.join(os.path.dirname(HERE), "include", "pokerl_hip.h")]
 # -ffp-contract=off: numpy never fuses multiply-add, so neither may we (bit-exact f64 money).
 # -amdgpu-sched-strategy=max-ilp: the table kernels run ONE wave per SIMD (65 536 tables = 1 024 waves), where issue is bound
 #   by dependent-instruction latency (tools/microbench/valu_rates.hip: 8.5 cycles dependent vs 5 independent), so the

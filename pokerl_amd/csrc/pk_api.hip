@@ -1,4 +1,4 @@
-// pk_api.hip -- kernels + C ABI (include/pokerl_hip.h) of libpokerl_hip.so.  gfx950 only; plain HIP runtime,
+// pk_api.hip -- host side of the C ABI (include/pokerl_hip.h) of libpokerl_hip.so; kernels: pk_kernels.hpp.  gfx950 only; plain HIP runtime,
 // no torch types.  Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -shared -fPIC (see pokerl_amd/build.py).
 #include <hip/hip_runtime.h>
 
@@ -10,686 +10,9 @@
 #include <vector>
 
 #include "pk_device.hpp"
+#include "pk_kernels.hpp"
 
 using namespace pk;
-
-// ================================================================================================ kernels
-// One table per lane, one wavefront per workgroup.  At the headline size (65 536 tables) that is exactly one wave per
-// SIMD (256 CUs x 4), so occupancy cannot hide anything and the register budget is the whole 512-entry file:
-// __launch_bounds__(64) lets the compiler keep a table's full state in VGPRs instead of spilling to scratch.
-#define PK_TABLE_BLOCK 64
-
-__device__ __forceinline__ void wave_add_counters(const State &S, uint32_t steps, uint32_t hands, uint32_t evals, uint32_t games) {
-    // 64-wide butterfly reduction in registers, then lane 0 adds to the slot this wavefront owns (plain RMW, no atomics).
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        steps += __shfl_down(steps, off, 64); hands += __shfl_down(hands, off, 64);
-        evals += __shfl_down(evals, off, 64); games += __shfl_down(games, off, 64);
-    }
-    if ((threadIdx.x & 63) == 0) {
-        unsigned long long *slot = S.counters + (size_t)blockIdx.x * PK_NUM_COUNTERS;
-        slot[PK_C_STEPS] += steps; slot[PK_C_HANDS] += hands; slot[PK_C_EVALS] += evals; slot[PK_C_GAMES] += games;
-    }
-}
-
-// Sums and clears the per-wave counter slots: one workgroup, grid-stride over the slots.
-__global__ void __launch_bounds__(256) k_sum_counters(unsigned long long *slots, int nslots, unsigned long long *out) {
-    __shared__ unsigned long long part[256][PK_NUM_COUNTERS];
-    unsigned long long acc[PK_NUM_COUNTERS] = {0, 0, 0, 0};
-    for (int i = threadIdx.x; i < nslots; i += 256)
-        for (int c = 0; c < PK_NUM_COUNTERS; ++c) { acc[c] += slots[(size_t)i * PK_NUM_COUNTERS + c]; slots[(size_t)i * PK_NUM_COUNTERS + c] = 0; }
-    for (int c = 0; c < PK_NUM_COUNTERS; ++c) part[threadIdx.x][c] = acc[c];
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) for (int c = 0; c < PK_NUM_COUNTERS; ++c) part[threadIdx.x][c] += part[threadIdx.x + s][c];
-        __syncthreads();
-    }
-    if (threadIdx.x < PK_NUM_COUNTERS) out[threadIdx.x] = part[0][threadIdx.x];
-}
-
-template <int N>
-__global__ void __launch_bounds__(PK_TABLE_BLOCK) k_reset(State S, Hot H, const uint8_t *mask, int dealer) {  // Game.reset, game.py:397-412
-    int t = blockIdx.x * H.tpb + threadIdx.x;
-    if ((int)threadIdx.x >= H.tpb || t >= S.T) return;
-    if (mask && !mask[t]) return;
-    Table<N> tb;
-    tb.load(S, t);
-    tb.reset_state(H, dealer);
-    tb.deal(H, H.table_id_base + (uint32_t)t);
-    tb.store(S, t);
-    double hb;
-    S.valid[t] = (uint8_t)tb.valid_mask(hb);
-    S.terr[t] = 0;
-}
-
-// The table Game.reset(dealer = 0) produces before its deal, for this handle's configuration (see pk::Fresh).
-template <int N>
-__global__ void k_make_fresh(Hot H, Fresh *out) {
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    Table<N> tb;
-    tb.blank();
-    tb.reset_state(H, 0);
-    Fresh f{};
-    PK_FOR(p, N) f.credits[p] = tb.credits[p]; f.pending[p] = tb.pending[p]; PK_END
-    f.min_raise = tb.min_raise;
-    f.st_active = tb.st_active; f.st_called = tb.st_called; f.st_allin = tb.st_allin; f.st_broken = tb.st_broken;
-    f.active = tb.active; f.dealer = tb.dealer; f.sb = tb.sb; f.bb = tb.bb;
-    *out = f;
-}
-
-template <int N>
-__global__ void __launch_bounds__(PK_TABLE_BLOCK) k_step(const State *__restrict__ Sp, Hot H, const int32_t *actions, uint8_t *flags, uint8_t *terr) {  // Game.step, game.py:621-700
-    const State &S = *Sp;
-    __shared__ Lds<N> lds;
-    const int t = blockIdx.x * H.tpb + threadIdx.x;
-    const bool live = (int)threadIdx.x < H.tpb && t < S.T;
-    const uint32_t table_id = H.table_id_base + (uint32_t)t;
-    Table<N> tb;
-    if (live) tb.load(S, t); else tb.blank();
-    double high_bet;
-    uint32_t mask = tb.valid_mask(high_bet);                                       // :648
-    const int action = live ? actions[t] : -1;
-    const bool ok = live && action >= 0 && action < PK_NUM_MOVES && ((mask >> action) & 1);
-    bool todo = ok;
-    for (;;) {  // same flat shape as k_rollout / k_env_step: one instantiation of cursor and end_block
-        if (todo) { tb.begin_step(H, action, high_bet); todo = false; }
-        tb.cursor();
-        if (!__any(tb.parked())) break;
-        tb.end_block(H, t, table_id, lds, false);
-    }
-    tb.finish_step();
-    if (!live) return;
-    tb.store_show(S.show, S.T, t, lds);
-    if (!ok) {                                                                     // :649-651: no mutation
-        flags[t] = 0;
-        S.terr[t] = PK_TERR_INVALID_ACTION;
-        if (terr) terr[t] = PK_TERR_INVALID_ACTION;
-        return;
-    }
-    tb.store(S, t);
-    flags[t] = (uint8_t)tb.flags;
-    S.valid[t] = (uint8_t)tb.valid_mask(high_bet);
-    S.terr[t] = (uint8_t)tb.terr;
-    if (terr) terr[t] = (uint8_t)tb.terr;
-}
-
-template <int N>
-__global__ void __launch_bounds__(PK_TABLE_BLOCK) k_pick(State S, Hot H, int policy, int32_t *actions) {
-    int t = blockIdx.x * H.tpb + threadIdx.x;
-    if ((int)threadIdx.x >= H.tpb || t >= S.T) return;
-    ActionRng rng;
-    actions[t] = pick_action(H, rng, H.table_id_base + (uint32_t)t, S.step_serial[t], S.valid[t], policy);
-}
-
-// K more steps per table, in-kernel agents, table state in registers for the whole launch (K == 1, endk == 1: the
-// unfused form).  Tables are independent, so lanes need not stay in lockstep INSIDE the launch: a lane whose step
-// reaches end_hand parks at LS_END while the other lanes of the wave run ahead on their own step counters; the expensive
-// end_block (showdown + side pots + setup_hand + deal) runs only once `park` lanes are waiting (or nobody else can
-// run), which raises its lane utilisation from ~25 % to ~60 %.
-// Nor need they stay in lockstep ACROSS launches: every table carries the number of steps it still owes (State::owed;
-// a launch adds K), and a launch may end while lanes still owe steps or are parked in the middle of one -- as soon as
-// fewer than `endk` of the wave's lanes have work left, i.e. before the stragglers would run alone (the tail that
-// costs a 20-step launch 45 % of its throughput).  What is left is picked up by the next launch or by the flush
-// (endk == 1: run to completion) the host issues before anything can observe the tables.  Every table still makes
-// exactly the requested steps with the actions the RNG spec assigns to (table, step_serial), so the observable state
-// is bit-identical to the lockstep order.
-#ifndef PK_ROLLOUT_ATTR
-#define PK_ROLLOUT_ATTR
-#endif
-// POLICY (the in-kernel agents) is a template parameter: with a run-time policy the random agent's LDS lookup sat in a
-// basic block of its own and its latency could not be overlapped with the action-independent part of the step
-// (+2.4 % at 65 536 x 6).
-template <int N, bool ONE_PASS, int POLICY>
-__device__ __forceinline__ void rollout_body(const State *__restrict__ Sp, const Hot &H, int K, int auto_reset, int park, int slack, int clear_terr) {
-    // Array bases by pointer (loaded only where the table is loaded / stored), loop scalars by value: see pk::Hot.
-    constexpr int policy = POLICY;
-    const State &S = *Sp;
-    __shared__ Lds<N> lds;
-    const int t = blockIdx.x * H.tpb + threadIdx.x;
-    const bool live = (int)threadIdx.x < H.tpb && t < S.T;
-    const uint32_t table_id = H.table_id_base + (uint32_t)t;
-    Table<N> tb;
-    uint32_t owed = 0;
-    Table<N>::stage_fresh(lds, H.fresh);
-    stage_nth(lds);
-    if (live) { tb.load(S, t); tb.hands_this_step = (int)S.mid[t]; owed = S.owed[t] + (uint32_t)K; } else tb.blank();
-    uint32_t steps = 0;
-    bool alive = live;
-    ActionRing ring;
-    double high_bet;
-    // lanes that can work at all in this launch; the launch ends once more than `slack` of them have run out of work
-    // (slack >= 64: never, i.e. run to completion)
-    const int cap = __popcll(__ballot(live && (owed > 0 || tb.lstate == LS_END)));
-    const int quit = max(1, cap - slack);
-    PK_PROF(tb.prof.start();)
-    auto retire = [&]() {  // a lane whose Game.step() has returned (selects, not branches: nearly every lane, every pass)
-        const bool r = tb.stepped && tb.lstate == LS_DONE;
-        const bool bad = r && tb.terr != 0;            // table keeps its (reference-identical) state; reported through terr
-        const bool good = r && tb.terr == 0;
-        tb.step_serial += (r && !(tb.terr & PK_TERR_NO_WINNER)) ? 1u : 0u;   // finish_step()
-        tb.stepped = r ? 0u : tb.stepped;
-        owed = bad ? 0u : owed - (r ? 1u : 0u);
-        alive = alive && !bad;
-        steps += good ? 1u : 0u;
-        tb.games += good ? (tb.flags & PK_FLAG_GAME_OVER) : 0u;
-    };
-// Which of the betting passes also run cursor_tail() (next_turn for the lanes whose seat walk failed: ~75 instructions for
-// ~1 lane in 5).  Every other pass: the block runs half as often over twice the lanes, a lane waits at most one pass
-// (29.7 vs 28.6 G at 65 536 x 6; last pass only 28.7, passes 0+3 29.1, six passes with three tails 29.2).  The LAST
-// pass must be in the mask: no lane may be left in LS_SCAN when the wave looks at its parked lanes or leaves the loop.
-#ifndef PK_TAIL_MASK
-#define PK_TAIL_MASK 0xA
-#endif
-#ifndef PK_BET_PASSES
-#define PK_BET_PASSES 4   // betting passes between two looks at the parked lanes: end_block then serves what four passes
-#endif                    // have parked (1: 23.8 G, 2: 25.1 G, 3: 24.4 G, 4: 25.6 G, 6: 24.7 G, 8: 23.2 G at 65 536 x 6)
-    static_assert(((PK_TAIL_MASK) >> (PK_BET_PASSES - 1)) & 1, "the last betting pass must run cursor_tail()");
-    for (;;) {
-        // Nothing is in flight at the top of an iteration.  Without this the compiler cannot rule out that a table
-        // register still waits for the global loads before the loop or for end_block's LDS reads (both sit in
-        // conditionally executed blocks), and parks a full s_waitcnt right behind the first LDS read of every betting
-        // pass: the action ring's latency was exposed three passes out of four.
-        if (policy == PK_POLICY_RANDOM) __builtin_amdgcn_s_waitcnt(0);   // (the all-in kernel has no LDS read in its passes)
-        if (policy == PK_POLICY_RANDOM) ring.ensure(lds, H, table_id, tb.step_serial, alive && owed > 0, PK_BET_PASSES);   // wave-uniform
-#pragma unroll
-        for (int pass = 0; pass < PK_BET_PASSES; ++pass) {
-            const bool go = alive && tb.lstate == LS_DONE && owed > 0;
-            uint32_t word = 0;
-            if (policy == PK_POLICY_RANDOM) word = ActionRing::peek(lds, tb.step_serial);
-            if (go) {
-                uint32_t mask = tb.valid_mask(high_bet);
-                tb.begin_step(H, policy == PK_POLICY_ALLIN ? (int)MV_ALL_IN
-                                                           : action_from_draw_lds(lds, ActionRing::half_of(word, tb.step_serial), mask), high_bet);
-            }
-            PK_PROF(tb.prof.lap(PF_ACTION);)
-            tb.scan_first();      // every lane in LS_SCAN: the steps just begun and the ones end_block carried into a new hand
-            if ((PK_TAIL_MASK >> pass) & 1) tb.cursor_tail();
-            PK_PROF(tb.prof.count(PF_N_CURSOR);)
-            retire();
-            PK_PROF(tb.prof.lap(PF_CURSOR);)
-        }
-        // showdowns waiting in their side-pot loop (LS_POT) count towards `park` like arrivals (weights 0 and 1/2 measured no better)
-        const int parked = __popcll(__ballot(tb.parked()));
-        const int runnable = __popcll(__ballot(alive && tb.lstate == LS_DONE && owed > 0));
-        if (parked + runnable < quit) break;
-        if (parked >= park || runnable == 0) {
-            tb.template end_block<ONE_PASS>(H, t, table_id, lds, auto_reset != 0);
-            retire();
-        }
-    }
-    // LS_POT never survives a kernel.  A launch that ends early (deferred work) simply takes such a showdown back to
-    // LS_END: end_hand up to there is idempotent (the pending bets are committed and zero, payoffs are re-zeroed, the
-    // side pots restart from the unchanged committed bets), so the next launch redoes it together with its own arrivals.
-    if (tb.lstate == LS_POT) { tb.lstate = LS_END; tb.evals -= (uint32_t)__popc((tb.st_called | tb.st_allin) & Table<N>::FULL); }
-    if (live) {
-        tb.store(S, t);
-        tb.store_show(S.show, S.T, t, lds);
-        S.owed[t] = owed; S.mid[t] = (uint32_t)tb.hands_this_step;
-        S.valid[t] = (uint8_t)tb.valid_mask(high_bet);
-        S.terr[t] = (uint8_t)((clear_terr ? 0 : S.terr[t]) | tb.terr | tb.seen);
-    }
-    wave_add_counters(S, steps, tb.hands, tb.evals, tb.games);  // every lane takes part in the shuffles
-    PK_PROF(tb.prof.flush(S.prof);)
-}
-
-// Batches of up to two waves per SIMD: registers capped at 256 (no instantiation needs more; N = 10 uses 245), which
-// also steers the max-ILP scheduler to a slightly better schedule than an unlimited budget (24.1 vs 23.4 G at 65 536 x 6 when it was introduced) ...
-template <int N>
-__global__ void __launch_bounds__(PK_TABLE_BLOCK, 2) PK_ROLLOUT_ATTR k_rollout(const State *__restrict__ Sp, Hot H, int K, int auto_reset, int park, int slack, int clear_terr) {
-    rollout_body<N, true, PK_POLICY_RANDOM>(Sp, H, K, auto_reset, park, slack, clear_terr);
-}
-template <int N>
-__global__ void __launch_bounds__(PK_TABLE_BLOCK, 2) PK_ROLLOUT_ATTR k_rollout_allin(const State *__restrict__ Sp, Hot H, int K, int auto_reset, int park, int slack, int clear_terr) {
-    rollout_body<N, true, PK_POLICY_ALLIN>(Sp, H, K, auto_reset, park, slack, clear_terr);
-}
-// ... larger batches: capped at 168 for three waves per SIMD (no spill up to N = 7).  The third wave is worth +19 % at
-// 1 M x 6 (49 G env-steps/s) and +14 % at 524 288 x 9 in spite of the scratch traffic at N >= 8; a cap of 128 (four
-// waves) spills too much (18.4 G at 65 536 x 6).
-#ifndef PK_OCC_CAP
-#define PK_OCC_CAP 3
-#endif
-template <int N>
-__global__ void __launch_bounds__(PK_TABLE_BLOCK, PK_OCC_CAP) k_rollout_occ3(const State *__restrict__ Sp, Hot H, int K, int auto_reset, int park, int slack, int clear_terr) {
-    rollout_body<N, true, PK_POLICY_RANDOM>(Sp, H, K, auto_reset, park, slack, clear_terr);
-}
-template <int N>
-__global__ void __launch_bounds__(PK_TABLE_BLOCK, PK_OCC_CAP) k_rollout_occ3_allin(const State *__restrict__ Sp, Hot H, int K, int auto_reset, int park, int slack, int clear_terr) {
-    rollout_body<N, true, PK_POLICY_ALLIN>(Sp, H, K, auto_reset, park, slack, clear_terr);
-}
-
-// PokerGameEnv.reset / .step (envs/game_env.py:20-29, :31-53) share k_rollout's shape: ONE flat loop in which every
-// lane owns a small phase machine, begins its next Game.step() as soon as the previous one has returned, and the wave
-// runs end_block (end_hand + setup_hand + deal) once for all lanes parked at it.  The step machine is instantiated once
-// per kernel (three inlined copies of run() cost k_env_step 256 VGPRs + AGPR spills), table bases come by pointer.
-
-// PokerGameEnv.reset: Game.reset() (:23), then opponents play until seat 0 is to act (:24-26); a game that ends before
-// seat 0 ever acts is reset again (:27).
-template <int N>
-__global__ void __launch_bounds__(PK_TABLE_BLOCK) k_env_reset(const State *__restrict__ Sp, Hot H, const uint8_t *mask, int opp_policy, int park) {
-    const State &S = *Sp;
-    __shared__ Lds<N> lds;
-    const int t = blockIdx.x * H.tpb + threadIdx.x;
-    const bool live = (int)threadIdx.x < H.tpb && t < S.T && (!mask || mask[t < S.T ? t : 0]);
-    const uint32_t table_id = H.table_id_base + (uint32_t)t;
-    Table<N> tb;
-    if (live) tb.load(S, t); else tb.blank();
-    ActionRng rng;
-    double high_bet = 0.0;
-    bool more = live, due_reset = live;
-    int budget = PK_ENV_STEP_CAP;  // every wave-uniform loop in this file has an exit all lanes reach
-    auto retire = [&]() {          // an opponent's Game.step() has returned
-        if (tb.stepped && tb.lstate == LS_DONE) {
-            tb.finish_step();
-            if (--budget < 0) tb.terr |= PK_TERR_ENV_CAP;
-            if (tb.terr) more = false;
-            else due_reset = (tb.flags & PK_FLAG_GAME_OVER) != 0;                  // :27
-        }
-    };
-    for (;;) {
-        if (more && tb.lstate == LS_DONE) {                                        // no step in flight on this lane
-            if (due_reset) { tb.reset_state(H, 0); tb.deal(H, table_id); due_reset = false; }   // :23 / :27
-            more = tb.active != 0;                                                 // :24
-            if (more) {
-                uint32_t vm = tb.valid_mask(high_bet);
-                tb.begin_step(H, pick_action(H, rng, table_id, tb.step_serial, vm, opp_policy), high_bet);  // :25-26
-            }
-        }
-        tb.cursor();
-        retire();
-        const int parked = __popcll(__ballot(tb.parked()));
-        const int runnable = __popcll(__ballot(more && tb.lstate == LS_DONE));
-        if (parked == 0 && runnable == 0) break;
-        if (parked >= park || runnable == 0) {
-            tb.end_block(H, t, table_id, lds, false);
-            retire();
-        }
-    }
-    if (live) {
-        tb.store(S, t);
-        tb.store_show(S.show, S.T, t, lds);
-        S.valid[t] = (uint8_t)tb.valid_mask(high_bet);
-        S.terr[t] = (uint8_t)tb.terr;
-    }
-}
-
-// PokerGameEnv.step: seat 0's own step (:35), the opponents until the hand ends or seat 0 is to act (:41-44), the
-// opponents until seat 0 is to act or the game is over (:49-52) -- three phases of one lane-level machine.
-// Fused extras for a learner's loop (all optional, each removes a launch per env step): seat 0 can be played by an
-// in-kernel agent (seat0_policy >= 0; actions == NULL), a finished episode can be reset on the spot
-// (auto_reset: PokerGameEnv.reset(), game_env.py:20-29 -- what the caller would do next for `done` tables; reward /
-// done / hand still describe the step that ended it), and the dense StateView row of the player to act can be
-// written straight from registers (obs != NULL, layout PK_OBS_DIM).
-//
-// ASYNC (pk_env_step_async_d): a launch lasts at most `max_passes` betting passes.  A PokerGameEnv.step that has not
-// returned by then stays IN FLIGHT: its machine state goes to State::env_ctx / env_rew (plus the step-in-flight bits of
-// the table itself), the next launch carries on with it, and only tables whose step returned in this launch write
-// their outputs and ready[t] = 1.  One env.step of a whole batch lasts as long as its slowest table (a seat 0 that
-// busts during an opponent's step waits for the end of the game, game_env.py:49-52); a learner that acts on the ready
-// tables only never waits for those.  Per table the sequence of steps, outputs and RNG draws is the synchronous one.
-template <int N, bool ASYNC>
-__device__ __forceinline__ void env_step_body(const State *__restrict__ Sp, const Hot &H, const int32_t *actions, int seat0_policy, int opp_policy, int auto_reset, double *reward, uint8_t *done_out, uint8_t *hand_out, uint8_t *terr, double *obs, int park, uint8_t *ready, int max_passes) {
-    const State &S = *Sp;
-    __shared__ Lds<N> lds;
-    const int t = blockIdx.x * H.tpb + threadIdx.x;
-    const bool live = (int)threadIdx.x < H.tpb && t < S.T;
-    const uint32_t table_id = H.table_id_base + (uint32_t)t;
-    Table<N> tb;
-    if (live) tb.load(S, t); else tb.blank();
-    uint64_t ctx = 0;                                          // != 0: a PokerGameEnv.step of this table is in flight
-    if (ASYNC && live) ctx = S.env_ctx[t];
-    const bool carried = ctx != 0;
-    ActionRing ring;
-    stage_nth(lds);
-    double high_bet;
-    const uint32_t vm0 = tb.valid_mask(high_bet);
-    // seat 0's action: supplied (checked here, game.py:648-651) or drawn in the loop like the opponents' (always valid)
-    const int action = (!live || carried || !actions) ? -1 : actions[t];
-    const bool ok = carried || (live && (!actions || (action >= 0 && action < PK_NUM_MOVES && ((vm0 >> action) & 1))));
-    enum { PH_SEAT0 = 0, PH_HAND = 1, PH_TURN = 2, PH_RESET = 3, PH_RESET_PLAY = 4, PH_END = 5 };
-    int phase = ok ? PH_SEAT0 : PH_END;
-    double rew = 0.0;                                                              // :34
-    bool done = false, hand = false;
-    uint32_t terr_step = 0;
-    int budget = PK_ENV_STEP_CAP, budget_reset = PK_ENV_STEP_CAP;
-    if (ASYNC && carried) {
-        phase = (int)(ctx >> 1) & 7; done = (ctx >> 4) & 1; hand = (ctx >> 5) & 1; terr_step = (uint32_t)(ctx >> 8) & 0xff;
-        budget = (int)((ctx >> 16) & 0xffff) - 1; budget_reset = (int)((ctx >> 32) & 0xffff) - 1;
-        rew = S.env_rew[t];
-        tb.hands_this_step = (int)S.mid[t];
-    }
-    int passes = 0;
-    const uint32_t caps = PK_TERR_HAND_CAP | PK_TERR_ENV_CAP;
-    auto step_finished = [&]() {   // PokerGameEnv.step has returned: its outputs are final; maybe reset the episode
-        terr_step = tb.terr;
-        phase = (auto_reset && (done || (tb.terr & caps))) ? PH_RESET : PH_END;
-    };
-    auto retire = [&]() {  // a Game.step() of this lane has returned: the reference's control flow between two steps
-        if (tb.stepped && tb.lstate == LS_DONE) {
-            tb.finish_step();
-            if (phase == PH_RESET_PLAY) {                                          // game_env.py:24-27
-                if (--budget_reset < 0) tb.terr |= PK_TERR_ENV_CAP;
-                if (tb.terr) phase = PH_END;
-                else if (tb.flags & PK_FLAG_GAME_OVER) phase = PH_RESET;           // :27
-                else if (tb.active == 0) phase = PH_END;                           // :24
-                return;
-            }
-            if (phase != PH_SEAT0 && --budget < 0) tb.terr |= PK_TERR_ENV_CAP;
-            if (tb.terr) { step_finished(); return; }
-            const bool over = (tb.flags & PK_FLAG_GAME_OVER) != 0, hand_now = (tb.flags & PK_FLAG_HAND_OVER) != 0;
-            const bool seat0 = tb.active == 0;
-            bool leave_hand_stretch = false;                                       // :41's loop is over (or never entered)
-            if (phase == PH_SEAT0) {
-                done = over; hand = hand_now;
-                if (done || (tb.st_broken & 1)) { rew = tb.payoffs[0]; done = true; hand = true; step_finished(); }  // :37-39
-                else if (!hand && !seat0) phase = PH_HAND;                         // :41
-                else leave_hand_stretch = true;
-            } else if (phase == PH_HAND) {
-                done = over; hand = hand_now;                                      // :44
-                leave_hand_stretch = hand || seat0;
-            } else {                                                               // PH_TURN: only `done` is re-read (:52)
-                done = over;
-                if (done || seat0) step_finished();
-            }
-            if (leave_hand_stretch) {
-                if (hand) rew = tb.payoffs[0];                                     // :47
-                if (!done && !seat0) phase = PH_TURN; else step_finished();        // :49
-            }
-        }
-    };
-#ifndef PK_ENV_PASSES
-#define PK_ENV_PASSES 4   // betting passes between two looks at the parked lanes, as in k_rollout
-#endif
-    const bool draws = seat0_policy == PK_POLICY_RANDOM || opp_policy == PK_POLICY_RANDOM;   // wave-uniform
-    for (;;) {
-        // ASYNC, pass budget used up: no lane begins another Game.step; the hands that are ending are still brought to
-        // their end (a lane parked at end_hand would otherwise wait for 'park' neighbours launch after launch)
-        const bool draining = ASYNC && max_passes > 0 && passes >= max_passes;
-        if (!draining && phase == PH_RESET && tb.lstate == LS_DONE) {              // game_env.py:23 / :27
-            tb.reset_state(H, 0); tb.deal(H, table_id);
-            phase = tb.active != 0 ? PH_RESET_PLAY : PH_END;                       // :24
-        }
-        if (draws) __builtin_amdgcn_s_waitcnt(0);   // as in k_rollout: no stray full wait behind the passes' LDS reads
-        if (draws) ring.ensure(lds, H, table_id, tb.step_serial, live && phase != PH_END, PK_ENV_PASSES);
-#pragma unroll
-        for (int pass = 0; pass < PK_ENV_PASSES; ++pass) {
-            const bool open = !(ASYNC && max_passes > 0 && passes + pass >= max_passes);
-            const uint32_t word = draws ? ActionRing::peek(lds, tb.step_serial) : 0u;
-            if (open && phase != PH_END && phase != PH_RESET && tb.lstate == LS_DONE) {   // begin this lane's next Game.step()
-                const uint32_t vm = tb.valid_mask(high_bet);
-                const int pol = phase == PH_SEAT0 ? seat0_policy : opp_policy;
-                const int a = (phase == PH_SEAT0 && actions) ? action
-                            : pol == PK_POLICY_ALLIN ? (int)MV_ALL_IN
-                                                     : action_from_draw_lds(lds, ActionRing::half_of(word, tb.step_serial), vm);
-                tb.begin_step(H, a, high_bet);                                     // :35 / :43-44 / :51-52 / :25-26
-            }
-            tb.cursor();
-            retire();
-        }
-        const int parked = __popcll(__ballot(tb.parked()));
-        const int runnable = draining ? 0 : __popcll(__ballot(phase != PH_END && tb.lstate == LS_DONE));
-        if (parked == 0 && runnable == 0) break;                                   // draining: the rest stays in flight
-        passes += PK_ENV_PASSES;
-        if (parked >= park || runnable == 0) {
-            tb.end_block(H, t, table_id, lds, false);
-            retire();
-        }
-    }
-    if (!live) return;
-    if (ok) {
-        tb.store(S, t);
-        tb.store_show(S.show, S.T, t, lds);
-    }
-    const uint32_t vmask = tb.valid_mask(high_bet);
-    if (ASYNC) {
-        const bool returned = phase == PH_END;
-        S.env_ctx[t] = returned ? 0ull
-                                : (1ull | ((uint64_t)phase << 1) | ((uint64_t)done << 4) | ((uint64_t)hand << 5) | ((uint64_t)(terr_step & 0xff) << 8) |
-                                   ((uint64_t)(budget + 1) << 16) | ((uint64_t)(budget_reset + 1) << 32));
-        S.mid[t] = returned ? 0u : (uint32_t)tb.hands_this_step;
-        S.valid[t] = (uint8_t)vmask;
-        ready[t] = returned;
-        if (!returned) { S.env_rew[t] = rew; return; }
-    }
-    const uint32_t te = ok ? (terr_step | tb.terr) : (uint32_t)PK_TERR_INVALID_ACTION;
-    reward[t] = ok ? rew : 0.0; done_out[t] = ok && done; hand_out[t] = ok && hand;  // :53
-    if (ok) S.valid[t] = (uint8_t)vmask;
-    S.terr[t] = (uint8_t)te; terr[t] = (uint8_t)te;
-    if (obs) {  // Game.StateView(active player), game.py:117-131, from registers (same row k_obs builds from HBM)
-        double *o = obs + (size_t)t * PK_OBS_DIM(N);
-        const int who = tb.active;
-        o[0] = who; o[1] = tb.turn; o[2] = tb.min_raise;
-        for (int a = 0; a < PK_NUM_MOVES; ++a) o[3 + a] = (vmask >> a) & 1;
-        double h0 = 0.0, h1 = 0.0;
-        PK_FOR(p, N) h0 = (who == p) ? (double)tb.card(5 + 2 * p) : h0; h1 = (who == p) ? (double)tb.card(6 + 2 * p) : h1; PK_END
-        o[10] = h0; o[11] = h1;                                                    // game.py:385-389
-        PK_FOR(c, 5) o[12 + c] = (tb.turn != 0 && c < tb.turn + 2) ? (double)tb.card(c) : -1.0; PK_END   // game.py:278
-        PK_FOR(p, N) o[17 + p] = tb.credits[p]; o[17 + N + p] = tb.bets[p]; o[17 + 2 * N + p] = tb.pending[p]; PK_END
-    }
-}
-template <int N>
-__global__ void __launch_bounds__(PK_TABLE_BLOCK) k_env_step(const State *__restrict__ Sp, Hot H, const int32_t *actions, int seat0_policy, int opp_policy, int auto_reset, double *reward, uint8_t *done_out, uint8_t *hand_out, uint8_t *terr, double *obs, int park) {
-    env_step_body<N, false>(Sp, H, actions, seat0_policy, opp_policy, auto_reset, reward, done_out, hand_out, terr, obs, park, nullptr, 0);
-}
-template <int N>
-__global__ void __launch_bounds__(PK_TABLE_BLOCK, (N <= 6 ? 3 : 2)) k_env_step_async(const State *__restrict__ Sp, Hot H, const int32_t *actions, int seat0_policy, int opp_policy, int auto_reset, double *reward, uint8_t *done_out, uint8_t *hand_out, uint8_t *terr, double *obs, int park, uint8_t *ready, int max_passes) {
-    env_step_body<N, true>(Sp, H, actions, seat0_policy, opp_policy, auto_reset, reward, done_out, hand_out, terr, obs, park, ready, max_passes);
-}
-
-// ---- exports: device-side conversion from the SoA/bitmask layout to the reference's table-major arrays
-__global__ void k_export_f64(const double *src, int T, int N, double *out) {  // [N][T] -> [T][N]
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= T * N) return;
-    int t = i / N, p = i - t * N;
-    out[i] = src[(size_t)p * T + t];
-}
-__global__ void k_export_states(const uint64_t *ss, int T, int N, uint8_t *out) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= T * N) return;
-    int t = i / N, p = i - t * N;
-    uint64_t s = ss[t];
-    uint8_t st = PS_FOLDED;
-    if ((s >> p) & 1) st = PS_ACTIVE;
-    if ((s >> (16 + p)) & 1) st = PS_CALLED;
-    if ((s >> (32 + p)) & 1) st = PS_ALL_IN;
-    if ((s >> (48 + p)) & 1) st = PS_BROKEN;
-    out[i] = st;
-}
-__global__ void k_export_i32(State S, int field, int32_t *out) {
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= S.T) return;
-    uint32_t cur = S.cursors[t];
-    int32_t v = 0;
-    switch (field) {
-        case PK_I_ACTIVE_PLAYER: v = cur & 0xf; break;
-        case PK_I_TURN: v = (cur >> 16) & 0xf; break;
-        case PK_I_DEALER_IDX: v = (cur >> 4) & 0xf; break;
-        case PK_I_SMALL_BLIND_IDX: v = (cur >> 8) & 0xf; break;
-        case PK_I_BIG_BLIND_IDX: v = (cur >> 12) & 0xf; break;
-        case PK_I_HAND: v = S.hand[t]; break;
-    }
-    out[t] = v;
-}
-__global__ void k_export_cards(const uint32_t *cards, int T, int K, uint8_t *out) {  // [W][T] words -> [T][K] bytes
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= T * K) return;
-    int t = i / K, c = i - t * K;
-    out[i] = (uint8_t)(cards[(size_t)(c >> 2) * T + t] >> (8 * (c & 3)));
-}
-__global__ void k_export_show(const uint32_t *show, int T, int N, uint8_t *rank, uint32_t *kick) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= T * N) return;
-    int t = i / N, p = i - t * N;
-    uint32_t v = show[(size_t)p * T + t];
-    rank[i] = (uint8_t)(v >> 20);
-    kick[i] = v & 0xFFFFF;
-}
-// Game.get_valid_actions(player), game.py:339-383, of ANY seat as a bitmask (runtime N: export kernels are not
-// templated).  Same expressions, in the same order, as Table::valid_mask.
-__device__ inline uint32_t valid_bits_of(const State &S, int t, int N, int player) {
-    const size_t T = (size_t)S.T;
-    double high_bet = S.pending[t];                                               // :365 np.max
-    for (int p = 1; p < N; ++p) { double x = S.pending[(size_t)p * T + t]; high_bet = (x > high_bet) ? x : high_bet; }
-    const double credit = S.credits[(size_t)player * T + t], min_raise = S.min_raise[t];   // :366
-    uint32_t mask = (1u << MV_FOLD) | (1u << MV_ALL_IN);                          // :367
-    const double d = credit - high_bet;
-    const double rv0 = 0.1 * d, rv1 = 0.25 * d, rv2 = 0.5 * d;                    // :370
-    mask |= (rv0 > min_raise && (high_bet + rv0) < credit) ? (1u << 3) : 0;       // :371
-    mask |= (rv1 > min_raise && (high_bet + rv1) < credit) ? (1u << 4) : 0;
-    mask |= (rv2 > min_raise && (high_bet + rv2) < credit) ? (1u << 5) : 0;
-    mask |= (high_bet == 0.0) ? (1u << MV_CHECK) : 0;                             // :375
-    mask |= (high_bet < credit) ? (1u << MV_CALL) : 0;                            // :376
-    return mask;
-}
-// player < 0: each table's active player (the cached mask); else that seat on every table.  out: one-hot [T][7]
-__global__ void k_export_valid(State S, int N, int player, uint8_t *out) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= S.T * PK_NUM_MOVES) return;
-    int t = i / PK_NUM_MOVES, a = i - t * PK_NUM_MOVES;
-    uint32_t m = player < 0 ? S.valid[t] : valid_bits_of(S, t, N, player);
-    out[i] = (m >> a) & 1;
-}
-// Game.StateView(game, player), game.py:117-131, as one dense f64 row per table (layout: pokerl_hip.h PK_OBS_DIM).
-// player < 0: the active player of each table (what `game.active_state` is, game.py:323-332).
-__global__ void k_obs(State S, int N, int player, double *out) {
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= S.T) return;
-    const int T = S.T, D = PK_OBS_DIM(N);
-    double *o = out + (size_t)t * D;
-    uint32_t cur = S.cursors[t];
-    int active = cur & 0xf, turn = (cur >> 16) & 0xf;
-    const int who = player < 0 ? active : player;
-    const uint32_t vm = player < 0 ? S.valid[t] : valid_bits_of(S, t, N, who);
-    auto card = [&](int c) { return (double)((S.cards[(size_t)(c >> 2) * T + t] >> (8 * (c & 3))) & 0xff); };
-    o[0] = who; o[1] = turn; o[2] = S.min_raise[t];
-    for (int a = 0; a < PK_NUM_MOVES; ++a) o[3 + a] = (vm >> a) & 1;
-    o[10] = card(5 + 2 * who); o[11] = card(6 + 2 * who);                          // game.py:385-389
-    for (int c = 0; c < 5; ++c) o[12 + c] = (turn != 0 && c < turn + 2) ? card(c) : -1.0;  // game.py:278
-    for (int p = 0; p < N; ++p) {
-        o[17 + p] = S.credits[(size_t)p * T + t];
-        o[17 + N + p] = S.bets[(size_t)p * T + t];
-        o[17 + 2 * N + p] = S.pending[(size_t)p * T + t];
-    }
-}
-// Game.pot (np.sum(bets) in numpy's association order, game.py:281-284 + SURVEY A.5) / Game.high_bet
-// (np.max(pending_bets), game.py:287-290) per table; Game.game_over (game.py:317-320).
-__global__ void k_table_f64(State S, int N, int field, double *out) {
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= S.T) return;
-    const size_t T = (size_t)S.T;
-    double r;
-    if (field == PK_TF_POT) {
-        const double *a = S.bets;
-        if (N < 8) {
-            r = a[t];
-            for (int p = 1; p < N; ++p) r = r + a[(size_t)p * T + t];
-        } else {
-            r = ((a[t] + a[T + t]) + (a[2 * T + t] + a[3 * T + t])) + ((a[4 * T + t] + a[5 * T + t]) + (a[6 * T + t] + a[7 * T + t]));
-            for (int p = 8; p < N; ++p) r = r + a[(size_t)p * T + t];
-        }
-    } else if (field == PK_TF_HIGH_BET) {
-        r = S.pending[t];
-        for (int p = 1; p < N; ++p) { double x = S.pending[(size_t)p * T + t]; r = (x > r) ? x : r; }
-    } else r = S.min_raise[t];
-    out[t] = r;
-}
-__global__ void k_game_over(const uint64_t *ss, int T, int N, uint8_t *out) {
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= T) return;
-    uint32_t broken = (uint32_t)(ss[t] >> 48) & 0xffff;
-    out[t] = __popc(~broken & ((1u << N) - 1)) == 1;
-}
-
-// pokerl.judger.eval_hand batched: one hand per lane, cards[M][7] bytes
-__global__ void k_eval_hands(const uint8_t *cards, const uint8_t *ncards, size_t m, uint8_t *rank, uint32_t *kick, uint8_t *nkick) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= m) return;
-    uint32_t c[7];
-#pragma unroll
-    for (int j = 0; j < 7; ++j) c[j] = cards[i * 7 + j];
-    int n = ncards ? ncards[i] : 7;
-    n = n < 0 ? 0 : (n > 7 ? 7 : n);
-    int nk;
-    uint32_t v = eval_hand(c, n, nk);
-    rank[i] = (uint8_t)(v >> 20);
-    kick[i] = v & 0xFFFFF;
-    if (nkick) nkick[i] = (uint8_t)nk;
-}
-// pokerl.judger.compare_rankings batched: one list of n rankings per lane (judger.py:111-158)
-__global__ void k_compare(const uint8_t *rank, const uint32_t *kick, int n, size_t m, uint8_t *onehot) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= m) return;
-    uint32_t best_rank = HR_NONE, best_kicker = 0, win = 0;
-    for (int p = 0; p < n; ++p) {
-        uint32_t r = rank[i * n + p], k = kick[i * n + p];
-        if (r < best_rank) { best_rank = r; best_kicker = k; win = 1u << p; }
-        else if (r == best_rank) {
-            if (k > best_kicker) win = 1u << p;  // line 148: best_kicker is not raised
-            else if (k == best_kicker) win |= 1u << p;
-        }
-    }
-    for (int p = 0; p < n; ++p) onehot[i * n + p] = (win >> p) & 1;
-}
-// Streaming evaluator: two hands per lane per iteration (one 16-byte load, one 8-byte store), grid-stride.
-// VEC: hands 16-byte and out 8-byte aligned (any hipMalloc'ed base); otherwise one hand per lane per iteration.
-template <bool DISTINCT, bool VEC>
-__global__ void __launch_bounds__(256) k_eval7_stream(const uint64_t *__restrict__ hands, size_t m, uint32_t *__restrict__ out) {
-    const size_t pairs = VEC ? m / 2 : 0, stride = (size_t)gridDim.x * blockDim.x;
-    auto eval1 = [](uint64_t w) {
-        uint32_t lo = (uint32_t)w, hi = (uint32_t)(w >> 32);
-        uint32_t c[7] = {lo & 0xff, (lo >> 8) & 0xff, (lo >> 16) & 0xff, lo >> 24, hi & 0xff, (hi >> 8) & 0xff, (hi >> 16) & 0xff};
-        int nk;
-        return DISTINCT ? eval7_distinct(c) : eval_hand(c, 7, nk);
-    };
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < pairs; i += stride) {
-        const ulonglong2 w = reinterpret_cast<const ulonglong2 *>(hands)[i];
-        uint2 r;
-        r.x = eval1(w.x); r.y = eval1(w.y);
-        reinterpret_cast<uint2 *>(out)[i] = r;
-    }
-    if constexpr (VEC) {
-        if ((m & 1) && blockIdx.x == 0 && threadIdx.x == 0) out[m - 1] = eval1(hands[m - 1]);
-    } else {
-        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride) out[i] = eval1(hands[i]);
-    }
-}
-// hand i = first 7 cards of the RNG-spec deck of (table_id = i, hand_serial = 0): the deal of a 1-seat table
-__global__ void __launch_bounds__(256) k_make_hands(Hot H, size_t m, uint64_t *out) {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride) {
-        Table<1> tb;
-        tb.hand_serial = 0;
-        tb.deal(H, (uint32_t)i);
-        out[i] = (uint64_t)tb.cards[0] | ((uint64_t)(tb.cards[1] & 0x00ffffffu) << 32);
-    }
-}
-
-// Exhaustive 7-card sweep used by tests (digest definition: tests/golden/make_eval_digest.py): all hands with prefix
-// (a, b); hand index within the prefix -> combination of 5 from the cards above b is decoded per lane.
-__global__ void k_eval7_prefix(int a, int b, int fast, uint32_t count, uint32_t *out) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count) return;
-    // unrank i among 5-subsets of {b+1..51} in lexicographic order
-    int n = 51 - b;  // pool size
-    int sel5[5];
-    uint32_t r = i;
-    int start = 0;
-    for (int k = 5; k >= 1; --k) {
-        for (int x = start;; ++x) {
-            // C(n - x - 1, k - 1) hands start with element x
-            uint32_t cnt = 1;
-            int top = n - x - 1;
-            if (top < k - 1) cnt = 0;
-            else for (int j = 0; j < k - 1; ++j) cnt = cnt * (uint32_t)(top - j) / (uint32_t)(j + 1);
-            if (r < cnt) { sel5[5 - k] = x; start = x + 1; break; }
-            r -= cnt;
-        }
-    }
-    auto canon = [](int c) { return (uint32_t)(((c % 4) << 4) | (c / 4)); };
-    uint32_t h[7] = {canon(a), canon(b), canon(b + 1 + sel5[0]), canon(b + 1 + sel5[1]), canon(b + 1 + sel5[2]),
-                     canon(b + 1 + sel5[3]), canon(b + 1 + sel5[4])};
-    int nk;
-    out[i] = fast ? eval7_distinct(h) : eval_hand(h, 7, nk);  // in-game evaluator / general (multiset) evaluator
-}
 
 // ================================================================================================ host side
 static thread_local std::string g_err;
