@@ -20,7 +20,7 @@ static thread_local std::string g_err;
 struct pk_handle {
     int device = 0, T = 0, N = 0, block = 64, dealer = 0;
     int tpb = 64;   // tables per wavefront (Hot::tpb)
-    bool occ3 = true;  // k_rollout_occ3 (registers capped for 3 waves per SIMD) vs k_rollout; knob PK_OCC3
+    bool occ3 = false;  // k_rollout_occ3 (registers capped for 3 waves per SIMD) vs k_rollout: see pk_create; knob PK_OCC3
     // lanes parked at end_hand before a wave runs end_block (the kernels look every 4 betting passes); knob PK_PARK /
     // pk_set_tuning.  0 = the measured optimum of each kernel: 28 for k_rollout with random agents (20.9 vs 20.6 G at
     // 20-step launches, the same at long ones), 32 for the all-in agents (44.3 vs 43.3 G) and for the env kernels.
@@ -185,7 +185,10 @@ int pk_create(pk_handle **out, int device, int num_tables, int num_players, cons
         while (tpb > 1 && (long)num_tables <= 1024L * (tpb / 2)) tpb /= 2;
         if (const char *pk = getenv("PK_TPB")) { int v = atoi(pk); if (v >= 1 && v <= 64) tpb = v; }
         h->tpb = tpb;
-        h->occ3 = num_tables > 2 * 65536;   // see k_rollout_occ3
+        // k_rollout_occ3 (registers capped at 168: three waves per SIMD) only where it was measured to pay: seven seats
+        // from 262 144 tables (+6..10 %), eight from 524 288 (+5..7 %).  Up to six seats k_rollout fits 168 registers by
+        // itself (161 at N = 6); at nine and ten seats the cap spills to scratch and loses 10..35 % at every batch size.
+        h->occ3 = (num_players == 7 && num_tables >= 262144) || (num_players == 8 && num_tables >= 524288);
         if (const char *pk = getenv("PK_OCC3")) h->occ3 = atoi(pk) != 0;
     }
     if (const char *pk = getenv("PK_PARK")) { int v = atoi(pk); if (v >= 1 && v <= 64) h->park = v; }

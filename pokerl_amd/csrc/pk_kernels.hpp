@@ -236,9 +236,10 @@ template <int N>
 __global__ void __launch_bounds__(PK_TABLE_BLOCK, 2) PK_ROLLOUT_ATTR k_rollout_allin(const State *__restrict__ Sp, Hot H, int K, int auto_reset, int park, int slack, int clear_terr) {
     rollout_body<N, true, PK_POLICY_ALLIN>(Sp, H, K, auto_reset, park, slack, clear_terr);
 }
-// ... larger batches: capped at 168 for three waves per SIMD (no spill up to N = 7).  The third wave is worth +19 % at
-// 1 M x 6 (49 G env-steps/s) and +14 % at 524 288 x 9 in spite of the scratch traffic at N >= 8; a cap of 128 (four
-// waves) spills too much (18.4 G at 65 536 x 6).
+// ... the same capped at 168 registers for three waves per SIMD.  Up to six seats k_rollout is below the cap anyway
+// (three resident waves are what give 49 G at 1 M x 6); the cap pays at seven seats (175 -> 168 without a spill: 44.3 vs
+// 40.3 G at 1 M x 7) and at eight (39.5 vs 36.8 G at 1 M x 8), and costs 10..35 % at nine and ten seats, where it spills
+// (pk_create picks; profiles/r02_occ3_sweep.txt).  A cap of 128 (four waves) spills too much at every seat count.
 #ifndef PK_OCC_CAP
 #define PK_OCC_CAP 3
 #endif
