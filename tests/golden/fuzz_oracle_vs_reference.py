@@ -79,6 +79,35 @@ def main():
         ok += 1
     print("fuzz oracle vs reference: %d configurations identical, %d skipped (reference never returns within 20 s), "
           "%d stopped by the hand cap where the reference rolled > 4096 hands in one step" % (ok, skipped, capped))
+    # ---- PokerGameEnv.reset / step (envs/game_env.py:20-53) on odd configurations: reward / done / hand and the whole
+    #      table state after every env.step and after every reset of a finished episode
+    env_ok = env_skipped = 0
+    for i in range(max(10, rounds // 3)):
+        n = rng.randint(2, 10)
+        same = rng.random() < 0.5
+        stacks = [x for x in STACKS if x >= 2]
+        start = int(rng.choice([x for x in stacks if x == int(x)])) if same else [rng.choice(stacks) for _ in range(n)]
+        cfg = dict(start_credits=start, big_blind=rng.choice([b for b in BLINDS if 0 < b <= 40]),
+                   small_blind=rng.choice([b for b in BLINDS if 0 < b <= 40]))
+        opp = 1 if rng.random() < 0.25 else 0
+        seed, base = rng.getrandbits(63), rng.getrandbits(32) & 0xFFFFFF00
+        signal.alarm(30)
+        try:
+            out = MG.env_trajectory(n, 0, opp, seed, 3, 40, base, cfg)
+        except Timeout:
+            env_skipped += 1
+            print("skip (reference env spins): n=%d cfg=%s opp=%d" % (n, cfg, opp), flush=True)
+            continue
+        finally:
+            signal.alarm(0)
+        meta = json.loads(str(out["meta"]))
+        try:
+            GU.replay_env(make_oracle, "envfuzz%d" % i, loaded=(out, meta))
+        except AssertionError as e:
+            print("ENV MISMATCH n=%d cfg=%s opp=%d seed=%d base=%d\n%s" % (n, cfg, opp, seed, base, e))
+            return 1
+        env_ok += 1
+    print("fuzz oracle vs reference, PokerGameEnv: %d configurations identical, %d skipped" % (env_ok, env_skipped))
     return 0
 
 

@@ -122,8 +122,8 @@ def replay_digest(make_backend, name, use_rollout=False):
     return meta
 
 
-def replay_env(make_backend, name):
-    z, meta = load_npz(name)
+def replay_env(make_backend, name, loaded=None):
+    z, meta = loaded if loaded is not None else load_npz(name)
     b = make_backend(meta)
     opp = meta["opp_policy"]
     b.env_reset(None, opp)
