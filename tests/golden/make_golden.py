@@ -464,6 +464,13 @@ ENV_SETS = {
     "env_n6_random": (6, R.POLICY_RANDOM, R.POLICY_RANDOM, SEED, 6, 200, 0, None),
     "env_n6_vs_allin": (6, R.POLICY_RANDOM, R.POLICY_ALLIN, SEED, 6, 150, 0, None),
     "env_n2_random": (2, R.POLICY_RANDOM, R.POLICY_RANDOM, SEED, 8, 200, 0, None),
+    # odd configurations (round 2): per-seat stacks with seat 0 short, nine seats at a high table-id base, blinds above
+    # most stacks against all-in opponents
+    "env_n5_percredits": (5, R.POLICY_RANDOM, R.POLICY_RANDOM, 1234567, 6, 150, 4096,
+                          dict(start_credits=[5, 100, 37.5, 1000, 10], big_blind=3, small_blind=7.5)),
+    "env_n9_random_hi_base": (9, R.POLICY_RANDOM, R.POLICY_RANDOM, 99, 4, 120, 4000000000, None),
+    "env_n3_big_blinds_vs_allin": (3, R.POLICY_RANDOM, R.POLICY_ALLIN, 2026, 6, 120, 0,
+                                   dict(start_credits=[10, 40, 100], big_blind=40, small_blind=2)),
 }
 
 

@@ -158,4 +158,5 @@ GAME_SETS = ["game_n2_random", "game_n6_random", "game_n9_random", "game_n6_alli
 DIGEST_SETS = ["digest_n2_random", "digest_n6_random", "digest_n9_random", "digest_n9_allin", "digest_n6_shard1",
                "digest_n6_shard7"]
 VIEW_SETS = ["views_n6_random", "views_n3_percredits"]
-ENV_SETS = ["env_n4_random", "env_n6_random", "env_n6_vs_allin", "env_n2_random"]
+ENV_SETS = ["env_n4_random", "env_n6_random", "env_n6_vs_allin", "env_n2_random", "env_n5_percredits",
+            "env_n9_random_hi_base", "env_n3_big_blinds_vs_allin"]
