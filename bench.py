@@ -115,16 +115,27 @@ def baseline_config_index(tables, players, policy, world):
 
 
 VALU_PEAK_WAVE_INSTS_PER_S = 256 * 4 * 2.4e9 / 2.0   # 256 CUs x 4 SIMDs, one wave64 VALU instruction per 2 cycles at 2.4 GHz
-#   (guides/MI355X_MICROARCH.md: "v_fma_f32 (wave64) 2 cyc (SIMD-32); one wave alone: 4" -- with the one wave per
-#   SIMD that 65 536 tables give, 0.5 of this peak is the ceiling; tools/microbench/valu_rates.hip measures both)
+#   (guides/MI355X_MICROARCH.md: "v_fma_f32 (wave64) 2 cyc (SIMD-32); one wave alone: 4")
+
+
+def mix_ceiling(waves_per_simd):
+    """Issue rate this kernel's instruction MIX can reach at its occupancy (tools/microbench/valu_rates.hip, measured on
+    MI355X: profiles/r02_valu_rates.txt): a lone wave per SIMD issues an independent instruction every ~5 cycles whatever
+    its type; from two waves per SIMD on, the half-rate kinds that make up the step machine (f64 add / mul / compare,
+    shifts, v_bcnt, 32-bit multiplies, v_cndmask on an SGPR mask) take 4.2-4.6 cycles and only plain 32-bit ALU reaches
+    2.3-2.8.  Returned as (wave-instr/s, cycles per instruction)."""
+    cyc = 5.0 if waves_per_simd < 1.5 else (4.5 if waves_per_simd < 2.5 else 4.25)
+    return 256 * 4 * 2.4e9 / cyc, cyc
 
 
 def profile_summary(tables, players, policy, kern_steps=None):
     """The committed rocprofv3 summary (profiles/*_summary.json: kernel trace + separate PMC passes of THIS bench command,
-    made by tools/profile_gpu.sh + tools/summarize_profile.py) for this workload -- the one profiled at the same launch
-    length if there is one, else the latest; None if none."""
+    made by tools/profile_gpu.sh + tools/summarize_profile.py) for this workload -- the one profiled at the launch length
+    closest to this run's (instructions per wave-step depend a little on it: ramp and tail of every launch), the latest
+    among equals; None if none."""
     import glob
-    best, exact = None, None
+    import math
+    best = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_summary.json"))):
         try:
             d = json.load(open(f))
@@ -132,10 +143,11 @@ def profile_summary(tables, players, policy, kern_steps=None):
             continue
         w = d.get("workload", {})
         if (w.get("tables"), w.get("players"), w.get("policy")) == (tables, players, policy) and w.get("fused", True):
-            best = (d, os.path.basename(f))
-            if w.get("steps_per_launch") == kern_steps:
-                exact = best
-    return exact or best
+            k = w.get("steps_per_launch") or 0
+            dist = abs(math.log(max(k, 1e-9) / kern_steps)) if kern_steps else 0.0
+            if best is None or dist <= best[0] + 1e-9:
+                best = (dist, d, os.path.basename(f))
+    return (best[1], best[2]) if best else None
 
 
 def evaluator_leg(device, log2_m=None, reps=5):
@@ -158,7 +170,7 @@ def evaluator_leg(device, log2_m=None, reps=5):
 def cpu_baseline(n_players, policy, budget_s=None):
     """The scalar C oracle (bit-exact restatement of the reference) timed on ONE host core on a bounded sample of the
     same workload.  Reported beside the GPU number; it is not the target (the roofline fraction is)."""
-    budget_s = float(os.environ.get("PK_BENCH_CPU_BUDGET", "12")) if budget_s is None else budget_s
+    budget_s = float(os.environ.get("PK_BENCH_CPU_BUDGET", "3")) if budget_s is None else budget_s
     import numpy as np
     from oracle import loader as O
     tables, chunk = 2048, 50
@@ -183,7 +195,7 @@ def cpu_baseline(n_players, policy, budget_s=None):
         gg.reset()
 
     def work(gg):
-        n, t_end = 0, time.perf_counter() + budget_s / 2
+        n, t_end = 0, time.perf_counter() + budget_s * 2 / 3
         while time.perf_counter() < t_end:
             n += int(gg.rollout(chunk, policy, True)[0][0])
         return n
@@ -299,8 +311,9 @@ def main():
     ap.add_argument("--reps", type=int, default=0,
                     help="blocks of --steps per timed sample (0 = as many as make a sample >= --min-steps steps, so that a "
                          "short --steps is not one launch-latency sample)")
-    ap.add_argument("--min-steps", type=int, default=131072,
-                    help="a timed sample runs at least this many steps per table (~0.4-0.6 s of GPU work at 65 536 x 6)")
+    ap.add_argument("--min-steps", type=int, default=393216,
+                    help="a timed sample runs at least this many steps per table (~0.8-1.2 s of GPU work at 65 536 x 6, so "
+                         "that the GPU is busy for most of the run)")
     ap.add_argument("--samples", type=int, default=7, help="timed samples; the MEDIAN is reported")
     ap.add_argument("--unfused", action="store_true", help="one launch per step (state round-trips HBM every step)")
     ap.add_argument("--mode", choices=["game", "env"], default="game")
@@ -310,6 +323,9 @@ def main():
     ap.add_argument("--env-unfused", action="store_true", help="--mode env with separate pick / step / reset / obs launches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-evaluator", action="store_true", help="skip the stand-alone evaluator kernel leg")
+    ap.add_argument("--coalesce", type=int, default=-1,
+                    help="host-side merging of asynchronous rollout calls into launches of up to this many steps "
+                         "(pk_set_coalesce; -1: the library default 512, 0: one launch per call)")
     args = ap.parse_args()
 
     ctx = DistContext()
@@ -326,6 +342,8 @@ def main():
     n_local, base = shard(total_tables, ctx)
     game = pokerl_amd.VecGame(n_local, num_players=args.players, device=device, table_id_base=base)
     game.reset()
+    if args.coalesce >= 0:
+        game.set_coalesce(args.coalesce)
     fused = not args.unfused
     K = max(1, args.steps)
     reps = args.reps if args.reps > 0 else max(1, -(-args.min_steps // K))
@@ -345,68 +363,90 @@ def main():
         game.rollout(k, policy, True, fused, counters=False)
         done += k
     game.rollout(0, policy, True, fused, counters=True)  # complete + zero the device counters
-    sample_s = []
+    from pokerl_amd.hipmem import DeviceEvent
+    ev0, ev1 = DeviceEvent(), DeviceEvent()
+    stats_warm = game.launch_stats(reset=True)           # launches so far (reset + warm-up): a profiler sees those too
+    sample_s, sample_dev_ms = [], []
     for _ in range(max(1, args.samples)):
         ctx.barrier(); game.sync()
+        game.record_event(ev0.handle)                    # HIP events on the stream the kernel is launched on
         t0 = time.perf_counter()
         for _ in range(reps):
             block()
-        game.sync(); ctx.barrier()   # sync() completes every deferred step: exactly reps*K steps per table are inside
+        game.record_event(ev1.handle)                    # completes every deferred / host-held step first, then records
+        game.sync(); ctx.barrier()   # exactly reps*K steps per table are inside
         sample_s.append(ctx.aggregate(0, time.perf_counter() - t0)[1])   # MAX over ranks
+        sample_dev_ms.append(DeviceEvent.elapsed_ms(ev0, ev1))
+    stats = game.launch_stats()
     c = game.rollout(0, policy, True, fused, counters=True)
     assert c["steps"] == n_local * K * reps * len(sample_s), (c, n_local, K, reps)
+    assert stats["steps"] == K * reps * len(sample_s), (stats, K, reps)
     seconds = sorted(sample_s)[len(sample_s) // 2]
     total_steps = ctx.aggregate(n_local * K * reps, 0.0)[0]
     scale = 1.0 / (sum(sample_s))   # counters cover all samples
     hands, evals, games = ctx.sum_list([c["hands"], c["evals"], c["games"]])
 
-    # roofline leg (rank 0): HIP events on the handle's own stream around back-to-back launches of the dominant kernel
-    kern_steps = min(args.chunk, K) if fused else 1
-    ev_reps = max(3, min(256, 4096 // kern_steps)) if fused else 1
-    ms_launch, _ = game.time_rollout(kern_steps if fused else min(K, 64), policy, True, fused, ev_reps)
+    # roofline leg (rank 0): the timed region itself, bracketed by HIP events on the handle's stream; the dominant kernel
+    # is the only kernel in it, so its average launch duration (launch gaps included) = event time / launches
+    launches = max(1, stats["launches"])
+    ms_launch = sum(sample_dev_ms) / launches
+    kern_steps = stats["steps"] / float(launches)        # mean Game.step()s per table per launch
     ctx.barrier()
     if ctx.rank == 0:
         alg_bytes = b_step(args.players) * n_local * kern_steps
         achieved = alg_bytes / (ms_launch * 1e-3) / 1e9
         cfg_idx = baseline_config_index(args.tables, args.players, args.policy, ctx.world)
-        prof = profile_summary(args.tables, args.players, args.policy, kern_steps) if fused else None
-        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "traffic_unit": "bytes per launch (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE, KiB)",
-                "kernel_ms": ms_launch, "launches_timed": ev_reps, "algorithmic_bytes_per_launch": alg_bytes,
-                "note": "achieved = ALGORITHMIC bytes ((2*(35N+21)+16) B/env-step x tables x steps per launch, SURVEY 8d) / "
-                        "HIP-event launch time: what a one-HBM-round-trip-per-step design would move. The fused kernel "
-                        "keeps table state in VGPRs for all steps of a launch, so its real HBM traffic (`traffic`: one "
-                        "read + one write of the table state per launch, whatever the launch length) is a small "
-                        "fraction of that and `frac` can exceed what any such design could reach; the binding "
-                        "roofline is VALU issue: see `valu`."}
+        prof = profile_summary(args.tables, args.players, args.policy, int(round(kern_steps))) if fused else None
+        hbm = {"bound": "hbm (algorithmic bytes, SURVEY 8d)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+               "frac": achieved / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": alg_bytes,
+               "note": "ALGORITHMIC bytes ((2*(35N+21)+16) B/env-step x tables x steps per launch) / launch time: what a "
+                       "one-HBM-round-trip-per-step design would move.  The fused kernel keeps the table state in VGPRs "
+                       "for all steps of a launch and really moves `traffic` (one read + one write of the state per "
+                       "launch), so this fraction can exceed 1 and bounds nothing; kept because SURVEY 8d defines it."}
+        roof = {"bound": "valu-issue", "achieved": None, "peak": VALU_PEAK_WAVE_INSTS_PER_S, "unit": "wave-instr/s",
+                "frac": None, "traffic": None,
+                "traffic_unit": "HBM bytes per launch (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE, KiB)",
+                "kernel_ms": ms_launch, "launches_timed": launches, "steps_per_launch": kern_steps,
+                "kernel_ms_source": "HIP events (pk_record_event) around every timed sample on the handle's stream / "
+                                    "launches inside them (pk_get_launch_stats)",
+                "hbm_algorithmic": hbm}
         if prof:
             d, src = prof
             pmc = d.get("pmc_per_full_launch", {})
-            roof["traffic"] = d.get("hbm_traffic_bytes_per_launch")
+            roof["traffic"] = hbm["traffic"] = d.get("hbm_traffic_bytes_per_launch")
             roof["traffic_source"] = src
-            w = d.get("workload", {})
-            k_prof = w.get("steps_per_launch")
-            if "SQ_INSTS_VALU" in pmc and "SQ_WAVES" in pmc and k_prof:
-                waves = pmc["SQ_WAVES"]
-                per_wave_step = pmc["SQ_INSTS_VALU"] / waves / k_prof       # wave-level VALU instructions per step of one wave's tables
-                valu_rate = per_wave_step * waves * (n_local / float(args.tables)) * kern_steps / (ms_launch * 1e-3)
+            per_wave_step = d.get("valu_insts_per_wave_step")
+            waves = pmc.get("SQ_WAVES")
+            if per_wave_step and waves:
+                waves_here = waves * (n_local / float(args.tables))
+                valu_rate = per_wave_step * waves_here * kern_steps / (ms_launch * 1e-3)
                 lanes = pmc.get("SQ_THREAD_CYCLES_VALU", 0) / (64.0 * pmc["SQ_ACTIVE_INST_VALU"]) if pmc.get("SQ_ACTIVE_INST_VALU") else None
-                roof["valu"] = {"bound": "valu-issue", "achieved": valu_rate, "peak": VALU_PEAK_WAVE_INSTS_PER_S,
-                                "unit": "wave-instr/s", "frac": valu_rate / VALU_PEAK_WAVE_INSTS_PER_S,
-                                "valu_insts_per_wave_step": per_wave_step, "lanes_active": lanes,
-                                "waves_per_simd": waves / 1024.0,
-                                "wait_any_frac": d.get("wait_any_frac_of_wave_cycles"), "source": src,
-                                "note": "achieved = SQ_INSTS_VALU per wave-step (from the committed PMC pass of this "
-                                        "workload) x wave-steps per launch / this run's HIP-event launch time; peak = "
-                                        "256 CU x 4 SIMD x 2.4 GHz / 2 cycles per wave64 VALU instruction; one wave "
-                                        "per SIMD cannot exceed 0.5 (4-cycle single-wave issue)"}
+                ceil_rate, ceil_cyc = mix_ceiling(waves / 1024.0)
+                roof.update({"achieved": valu_rate, "frac": valu_rate / VALU_PEAK_WAVE_INSTS_PER_S,
+                             "valu_insts_per_wave_step": per_wave_step, "salu_insts_per_wave_step": d.get("salu_insts_per_wave_step"),
+                             "lanes_active": lanes, "waves_per_simd": waves / 1024.0,
+                             "wait_any_frac": d.get("wait_any_frac_of_wave_cycles"), "source": src,
+                             "ceiling_mix": {"peak": ceil_rate, "frac_of_ceiling": valu_rate / ceil_rate,
+                                             "cycles_per_instruction": ceil_cyc, "source": "profiles/r02_valu_rates.txt",
+                                             "note": "what this instruction mix can issue at this occupancy (see mix_ceiling in bench.py)"},
+                             "note": "achieved = wave-level VALU instructions per wave-step (SQ_INSTS_VALU of the committed "
+                                     "rocprofv3 PMC pass of this workload / waves / steps) x waves x steps per launch / "
+                                     "this run's HIP-event launch time; peak = 256 CU x 4 SIMD x 2.4 GHz / 2 cycles per "
+                                     "wave64 VALU instruction (guides/MI355X_MICROARCH.md)"})
+        if roof["achieved"] is None:   # no committed PMC summary for this shape: only the SURVEY 8d figure can be given
+            roof.update({"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "note": "no rocprofv3 PMC summary of this workload under profiles/: algorithmic-HBM figure only (see hbm_algorithmic)"})
+        kern_desc = ("k_rollout (fused; %d launches in the timed region, mean %.1f steps per launch, min %d, max %d: "
+                     "asynchronous calls of %d steps %s)"
+                     % (launches, kern_steps, stats["min"], stats["max"], min(args.chunk, K),
+                        "merged on the host while two launches are in flight (pk_set_coalesce)" if stats["max"] > min(args.chunk, K) else "launched one by one")
+                     if fused else "k_rollout (1 step/launch)")
         out = {
             "metric": "env-steps/sec (whole node) + showdown hand-evals/sec, 65 536 tables 6-max",
             "value": total_steps / seconds, "unit": "env-steps/s", "n_gpus": ctx.world, "steps": K,
             "warmup": args.warmup, "ms_per_step": seconds / (K * reps) * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "reps": reps, "samples": len(sample_s), "sample_seconds": sample_s,
+            "reps": reps, "samples": len(sample_s), "sample_seconds": sample_s, "sample_device_ms": sample_dev_ms,
             "timing": "each sample = %d block(s) of %d steps per table, launched back to back and completed by a sync inside "
                       "the timed region; value = steps of one sample / MEDIAN sample time (MAX over ranks per sample)" % (reps, K),
             "config": {"workload": "%d tables/GPU x %d GPU(s), num_players=%d, %s agents in-kernel (Philox4x32-10), "
@@ -414,7 +454,7 @@ def main():
                                    % (args.tables, ctx.world, args.players, args.policy,
                                       "BASELINE configs[%d]" % cfg_idx if cfg_idx is not None else "not a BASELINE config"),
                        "tables_per_gpu": args.tables, "num_players": args.players, "policy": args.policy,
-                       "kernel": "k_rollout (fused, %d steps/launch)" % kern_steps if fused else "k_rollout (1 step/launch)",
+                       "kernel": kern_desc, "launch_stats": stats, "launch_stats_before_timed_region": stats_warm,
                        "parallelism": "env-parallel, %d shard(s), no collective on the step path" % ctx.world},
             "hand_evals_per_s": evals * scale, "hands_per_s": hands * scale, "games_per_s": games * scale,
             "roofline": roof,

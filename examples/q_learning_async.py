@@ -98,5 +98,5 @@ torch.cuda.synchronize()
 names = pokerl_amd.HandRanking.as_string
 for r_ in (9, 7, 3):
     print("Q[%-10s] = %s" % (names[r_], [round(x, 3) for x in Q[r_ - 1].tolist()]))
-g.set_stream(None)
+g.use_own_stream()
 g.close()

@@ -85,5 +85,5 @@ print("%d tables x %d env steps on the device; mean reward per env step %.4f" % 
 names = pokerl_amd.HandRanking.as_string
 for r in (9, 7, 3):
     print("Q[%-10s] = %s" % (names[r], [round(x, 3) for x in Q[r - 1].tolist()]))
-g.set_stream(None)
+g.use_own_stream()
 g.close()

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define PK_ABI_VERSION 2
+#define PK_ABI_VERSION 3
 #define PK_MIN_PLAYERS 2
 #define PK_MAX_PLAYERS 10
 #define PK_MAX_DEVICES 64 /* the handle-less judger calls keep one scratch arena per device index below this */
@@ -185,8 +185,18 @@ int pk_pick_actions_d(pk_handle *h, int policy, int32_t *actions_d);
  * pk_step, pk_reset, pk_sync, pk_record_event, ...) first completes it (pk_flush), so no caller can observe a table
  * that has made fewer than the requested steps.  Results do not depend on how the steps were split over launches. */
 int pk_rollout(pk_handle *h, int k_steps, int policy, int auto_reset, int fused, uint64_t *counters);
-/* Diagnostic: the steps each table still owes (out[T]); waits for the launches queued so far but does NOT complete the
- * deferred work. */
+/* Asynchronous fused pk_rollout calls (counters == NULL, auto_reset != 0) are also COALESCED on the host: while the two
+ * most recent launches are still running, a call only adds its steps to a host-side count, which is launched as ONE kernel
+ * as soon as a launch slot frees up, when it reaches `max_steps`, or by the flush every observer issues -- so a stream of
+ * short calls (20 steps each) runs as launches of up to max_steps steps and pays the fixed cost of a launch once per
+ * launch, not per call.  Invisible like deferral: no entry point can observe fewer than the requested steps.
+ * max_steps: 0 = every call launches at once; default 512 (env PK_COALESCE). */
+int pk_set_coalesce(pk_handle *h, int max_steps);
+/* Launches of the rollout kernel since the last reset: out[4] = {launches (including the 0-step flushes of deferred
+ * work), steps summed over them, min and max steps per launch over the launches with steps}.  reset != 0 clears them. */
+int pk_get_launch_stats(pk_handle *h, uint64_t *out, int reset);
+/* Diagnostic: the steps each table still owes ON THE DEVICE (out[T]); waits for the launches queued so far but does NOT
+ * complete the deferred work (and does not see steps a coalescing host still holds back). */
 int pk_get_owed(pk_handle *h, uint32_t *out);
 /* Completes deferred rollout steps now (asynchronous on the handle's stream); a no-op when there are none. */
 int pk_flush(pk_handle *h);
@@ -205,7 +215,11 @@ int pk_env_step(pk_handle *h, const int32_t *actions, int opp_policy, double *re
  * per table: [player, turn, minimum_raise_value, valid_actions[7], player_cards[2], community_cards[5] (-1 where
  * not yet visible: game.py:278), credits[N], bets[N], pending_bets[N]]. */
 #define PK_OBS_DIM(n) (3 + 7 + 2 + 5 + 3 * (n))
-/* player < 0: each table's active player (Game.active_state, game.py:323-332); else StateView(game, player). */
+/* player < 0: each table's active player (Game.active_state, game.py:323-332); 0 <= player < N: that SEAT's view on every
+ * table.  NOTE the one difference from the reference's constructor: StateView(game, 0) there is the ACTIVE player's view
+ * (`player or game.active_player`, game.py:122, treats seat 0 like None); here player == 0 is seat 0 and "the active
+ * player" is spelled -1.  The Python mirror (VecGame.observations_of / state_views) maps 0 and None to -1 like the
+ * reference. */
 int pk_get_obs(pk_handle *h, int player, double *out /* [T][PK_OBS_DIM(N)] */);
 
 /* Device-resident variants for a learner that lives on the same GPU (no host round trip; asynchronous on the handle's
@@ -235,24 +249,33 @@ int pk_env_step_fused_d(pk_handle *h, const int32_t *actions_d, int seat0_policy
  * end (every table ready).  While steps may be in flight (after any call with max_passes > 0) all other entry points
  * that read or change tables return PK_E_BUSY (pk_sync only waits); a call with max_passes <= 0 ends that state.
  * Use auto_reset != 0 with bounded launches: pk_env_reset_d is one of the entry points that are busy meanwhile, so a
- * finished episode could only be reset after a drain. */
+ * finished episode could only be reset after a drain.  Steps in flight keep their agents: while that state lasts every
+ * call must pass the same seat-0 source (actions_d NULL or not, seat0_policy), opp_policy and auto_reset as the call that
+ * started it, else PK_E_INVALID_ARG (nothing done). */
 int pk_env_step_async_d(pk_handle *h, const int32_t *actions_d, int seat0_policy, int opp_policy, int auto_reset,
                         int max_passes, double *reward_d, uint8_t *done_d, uint8_t *hand_d, uint8_t *terr_d,
                         double *obs_d, uint8_t *ready_d);
 
 /* Stream control (no torch types: `stream` is a hipStream_t, `event` a hipEvent_t, passed as void*).  A handle creates
- * its own non-blocking stream.  pk_set_stream makes it run on the caller's stream instead (NULL: back to its own), which
- * orders every `_d` call after the work already queued there; or keep two streams and order them with events:
+ * its own NON-BLOCKING stream (no implicit ordering with the legacy default stream).  pk_set_stream makes it run on the
+ * caller's stream instead, which orders every `_d` call after the work already queued there.  stream == NULL IS a
+ * stream: the legacy default stream -- what `torch.cuda.current_stream().cuda_stream` (0) denotes unless the caller
+ * entered a torch.cuda.Stream -- so the documented pattern g.set_stream(torch.cuda.current_stream().cuda_stream) orders
+ * the handle with torch in every case (ABI 2 silently went back to the handle's own stream for 0: a data race).  A
+ * stream of another device is refused (PK_E_INVALID_ARG).  pk_use_own_stream goes back to the handle's own stream.
+ * Or keep two streams and order them with events:
  * pk_wait_event = the handle's stream waits for `event` (record it on your stream after producing actions_d),
  * pk_record_event = records `event` on the handle's stream (wait for it on your stream before reading obs_d). */
 int pk_get_stream(pk_handle *h, void **stream_out);
 int pk_set_stream(pk_handle *h, void *stream);
+int pk_use_own_stream(pk_handle *h);
 int pk_wait_event(pk_handle *h, void *event);
 int pk_record_event(pk_handle *h, void *event);
 /* Completes deferred rollout steps and waits until everything requested so far has finished. */
 int pk_sync(pk_handle *h);
-/* Runs `reps` back-to-back fused rollouts of k_steps each and returns the average device time of one launch in
- * milliseconds, measured with HIP events on the handle's stream (used by bench.py's roofline leg). */
+/* Runs `reps` back-to-back fused rollouts of k_steps each (never coalesced) plus the flush of what they deferred and
+ * returns the average device time of one launch in milliseconds (events on the handle's stream; the flush, when there is
+ * one, counts as a launch).  Diagnostic (tools/); bench.py's roofline leg brackets its own timed region with events. */
 int pk_time_rollout(pk_handle *h, int k_steps, int policy, int auto_reset, int fused, int reps, double *ms_per_launch,
                     uint64_t *counters);
 

@@ -31,6 +31,19 @@ struct pk_handle {
     // (State::owed, steps in flight).  Every entry point that reads or changes table state flushes first.
     bool pending = false;
     int pend_policy = 0, pend_auto = 0;
+    // Host-side coalescing of asynchronous pk_rollout calls (counters == NULL, auto_reset): while the two most recent
+    // launches are still running, a call only ADDS its steps to `acc`; they are launched as ONE kernel once a launch slot
+    // frees up, at `coalesce` accumulated steps, or by the flush every observer issues.  A stream of 20-step calls thus
+    // runs as launches of up to `coalesce` steps: the fixed cost of a launch (load + store of every table, ramp and
+    // tail: ~8 us of a 60 us 20-step launch) is paid once per launch, not per call.  0: every call launches.
+    int coalesce = 512;
+    int acc = 0;
+    hipEvent_t ev_ring[2] = {nullptr, nullptr};
+    bool ev_used[2] = {false, false};
+    int ev_idx = 0;
+    // launches of the fused rollout kernel since pk_get_launch_stats(reset): count, steps summed, min / max steps per launch
+    uint64_t st_launches = 0, st_steps = 0, st_min = 0, st_max = 0;
+    int env_seat0 = 0, env_opp = 0, env_auto = 0;   // agents / auto_reset of the PokerGameEnv.steps in flight (env_pending)
     // PokerGameEnv.steps left in flight by pk_env_step_async_d (State::env_ctx): every other entry point that touches
     // table state refuses to run until a draining call (max_passes <= 0) has completed them.
     bool env_pending = false;
@@ -118,12 +131,30 @@ static int launch_rollout(pk_handle *h, int k_steps, int policy, int auto_reset,
     HIPCHK(h, hipGetLastError());
     h->pending = slack < PK_WAVE;
     h->pend_policy = policy; h->pend_auto = auto_reset;
+    h->st_launches += 1; h->st_steps += (uint64_t)k_steps;
+    if (k_steps > 0) {
+        h->st_min = (h->st_min == 0 || (uint64_t)k_steps < h->st_min) ? (uint64_t)k_steps : h->st_min;
+        h->st_max = (uint64_t)k_steps > h->st_max ? (uint64_t)k_steps : h->st_max;
+    }
     return PK_OK;
 }
 // Completes whatever deferred rollout launches left undone.  Called by every entry point that reads or mutates tables.
 static int flush_rollout(pk_handle *h) {
-    if (!h->pending) return PK_OK;
-    return launch_rollout(h, 0, h->pend_policy, h->pend_auto, 1);
+    if (!h->pending && h->acc == 0) return PK_OK;
+    const int k = h->acc;
+    h->acc = 0;
+    return launch_rollout(h, k, h->pend_policy, h->pend_auto, 1);
+}
+// One asynchronous, deferring launch of the accumulated steps; remembers it in the two-slot event ring.
+static int launch_coalesced(pk_handle *h, int policy, int auto_reset) {
+    const int k = h->acc;
+    h->acc = 0;
+    int rc = launch_rollout(h, k, policy, auto_reset, h->endk);
+    if (rc) return rc;
+    HIPCHK(h, hipEventRecord(h->ev_ring[h->ev_idx], h->stream));
+    h->ev_used[h->ev_idx] = true;
+    h->ev_idx ^= 1;
+    return PK_OK;
 }
 static int flush(pk_handle *h) {
     if (h->env_pending)
@@ -193,12 +224,15 @@ int pk_create(pk_handle **out, int device, int num_tables, int num_players, cons
     }
     if (const char *pk = getenv("PK_PARK")) { int v = atoi(pk); if (v >= 1 && v <= 64) h->park = v; }
     if (const char *pk = getenv("PK_ENDK")) { int v = atoi(pk); if (v >= 1 && v <= 64) h->endk = v; }
+    if (const char *pk = getenv("PK_COALESCE")) { int v = atoi(pk); if (v >= 0 && v <= (1 << 20)) h->coalesce = v; }
     auto bail = [&](int code) { g_err = h->err; pk_destroy(h); return code; };
     DeviceGuard guard(device);
     if (!guard.ok) return bail(h->fail(PK_E_HIP, "hipSetDevice"));
     if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) return bail(h->fail(PK_E_HIP, "hipStreamCreate"));
     h->stream = h->own_stream;
-    if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) return bail(h->fail(PK_E_HIP, "hipEventCreate"));
+    if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_ring[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_ring[1], hipEventDisableTiming) != hipSuccess) return bail(h->fail(PK_E_HIP, "hipEventCreate"));
     if (hipHostMalloc((void **)&h->h_pinned, (size_t)num_tables, hipHostMallocDefault) != hipSuccess) return bail(h->fail(PK_E_OOM, "hipHostMalloc"));
 
     const size_t T = (size_t)num_tables, N = (size_t)num_players;
@@ -207,37 +241,43 @@ int pk_create(pk_handle **out, int device, int num_tables, int num_players, cons
     size_t obs = (size_t)PK_OBS_DIM(N) * 8;
     h->export_bytes = al(T * (obs > N * 8 ? obs : N * 8));
     const size_t nwaves = (T + (size_t)h->tpb - 1) / (size_t)h->tpb;
-    size_t total = 4 * al(T * N * 8) + 4 * al(T * 8) + 4 * al(T * 4) + al(W * T * 4) + al(N * T * 4) + 2 * al(T) +
-                   al(nwaves * PK_NUM_COUNTERS * 8) + al(PK_NUM_COUNTERS * 8) + al(PF_SLOTS * 8) + al(sizeof(State)) +
-                   al(PK_MAX_PLAYERS * 8) + al(sizeof(Fresh)) + al(T * 4) + 5 * al(T) + al(T * 8) + 2 * al(T * 8) + h->export_bytes;
+    State &S = h->S;
+    double *d_start = nullptr;
+    Fresh *d_fresh = nullptr;
+    // ONE description of the arena, run twice: with base == NULL it only measures (the result is the allocation size),
+    // then it hands out the pointers -- an array added here cannot be forgotten in a separately kept size expression.
+    auto layout = [&](char *base) -> size_t {
+        size_t off = 0;
+        auto take = [&](size_t bytes) { void *r = base ? (void *)(base + off) : nullptr; off += al(bytes); return r; };
+        S.credits = (double *)take(T * N * 8); S.bets = (double *)take(T * N * 8);
+        S.pending = (double *)take(T * N * 8); S.payoffs = (double *)take(T * N * 8);
+        S.min_raise = (double *)take(T * 8);
+        S.seat_states = (uint64_t *)take(T * 8);
+        S.hand_serial = (uint64_t *)take(T * 8); S.step_serial = (uint64_t *)take(T * 8);
+        S.cursors = (uint32_t *)take(T * 4); S.hand = (int32_t *)take(T * 4);
+        S.owed = (uint32_t *)take(T * 4); S.mid = (uint32_t *)take(T * 4);
+        S.env_ctx = (uint64_t *)take(T * 8); S.env_rew = (double *)take(T * 8);
+        S.cards = (uint32_t *)take(W * T * 4);
+        S.show = (uint32_t *)take(N * T * 4);
+        S.valid = (uint8_t *)take(T); S.terr = (uint8_t *)take(T);
+        S.counters = (unsigned long long *)take(nwaves * PK_NUM_COUNTERS * 8);
+        h->d_totals = (unsigned long long *)take(PK_NUM_COUNTERS * 8);
+        S.prof = (unsigned long long *)take(PF_SLOTS * 8);
+        h->d_S = (State *)take(sizeof(State));
+        d_start = (double *)take(PK_MAX_PLAYERS * 8);
+        d_fresh = (Fresh *)take(sizeof(Fresh));
+        h->d_actions = (int32_t *)take(T * 4);
+        h->d_flags = (uint8_t *)take(T); h->d_terr = (uint8_t *)take(T); h->d_mask = (uint8_t *)take(T);
+        h->d_done = (uint8_t *)take(T); h->d_handf = (uint8_t *)take(T);
+        h->d_reward = (double *)take(T * 8);
+        h->d_export = take(h->export_bytes);
+        return off;
+    };
+    const size_t total = layout(nullptr);
     e = hipMalloc(&h->arena, total);
     if (e != hipSuccess) return bail(h->fail(PK_E_OOM, "hipMalloc(table state)", e));
     if (hipMemsetAsync(h->arena, 0, total, h->stream) != hipSuccess) return bail(h->fail(PK_E_HIP, "hipMemset"));
-    char *p = (char *)h->arena;
-    auto take = [&](size_t bytes) { void *r = p; p += al(bytes); return r; };
-    State &S = h->S;
-    S.credits = (double *)take(T * N * 8); S.bets = (double *)take(T * N * 8);
-    S.pending = (double *)take(T * N * 8); S.payoffs = (double *)take(T * N * 8);
-    S.min_raise = (double *)take(T * 8);
-    S.seat_states = (uint64_t *)take(T * 8);
-    S.hand_serial = (uint64_t *)take(T * 8); S.step_serial = (uint64_t *)take(T * 8);
-    S.cursors = (uint32_t *)take(T * 4); S.hand = (int32_t *)take(T * 4);
-    S.owed = (uint32_t *)take(T * 4); S.mid = (uint32_t *)take(T * 4);
-    S.env_ctx = (uint64_t *)take(T * 8); S.env_rew = (double *)take(T * 8);
-    S.cards = (uint32_t *)take(W * T * 4);
-    S.show = (uint32_t *)take(N * T * 4);
-    S.valid = (uint8_t *)take(T); S.terr = (uint8_t *)take(T);
-    S.counters = (unsigned long long *)take(nwaves * PK_NUM_COUNTERS * 8);
-    h->d_totals = (unsigned long long *)take(PK_NUM_COUNTERS * 8);
-    S.prof = (unsigned long long *)take(PF_SLOTS * 8);
-    h->d_S = (State *)take(sizeof(State));
-    double *d_start = (double *)take(PK_MAX_PLAYERS * 8);
-    Fresh *d_fresh = (Fresh *)take(sizeof(Fresh));
-    h->d_actions = (int32_t *)take(T * 4);
-    h->d_flags = (uint8_t *)take(T); h->d_terr = (uint8_t *)take(T); h->d_mask = (uint8_t *)take(T);
-    h->d_done = (uint8_t *)take(T); h->d_handf = (uint8_t *)take(T);
-    h->d_reward = (double *)take(T * 8);
-    h->d_export = take(h->export_bytes);
+    if (layout((char *)h->arena) != total) return bail(h->fail(PK_E_HIP, "arena layout changed between its two passes"));
     for (int i = 0; i < PK_MAX_PLAYERS; ++i)
         S.start_credits[i] = i < num_players ? (start_credits ? start_credits[i] : start_credit_scalar) : 0.0;
     S.big_blind = big_blind; S.small_blind = small_blind;
@@ -282,6 +322,7 @@ int pk_destroy(pk_handle *h) {
     if (h->h_pinned) (void)hipHostFree(h->h_pinned);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
+    for (int i = 0; i < 2; ++i) if (h->ev_ring[i]) (void)hipEventDestroy(h->ev_ring[i]);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
     return PK_OK;
@@ -296,12 +337,27 @@ int pk_get_stream(pk_handle *h, void **stream_out) {
     *stream_out = (void *)h->stream;
     return PK_OK;
 }
+static int switch_stream(pk_handle *h, hipStream_t to) {
+    if (!h->env_pending) FLUSH(h);               // host-side accumulated / deferred rollout steps belong to the old stream
+    HIPCHK(h, hipStreamSynchronize(h->stream));  // nothing of ours may still be running on the stream we leave
+    h->stream = to;
+    h->ev_used[0] = h->ev_used[1] = false;
+    return PK_OK;
+}
 int pk_set_stream(pk_handle *h, void *stream) {
     if (!h) return PK_E_INVALID_ARG;
     ON_DEVICE(h);
-    HIPCHK(h, hipStreamSynchronize(h->stream));  // nothing of ours may still be running on the stream we leave
-    h->stream = stream ? (hipStream_t)stream : h->own_stream;
-    return PK_OK;
+    if (stream) {   // a stream of another device would make every later launch fail (or, worse, run there)
+        hipDevice_t dev = -1;
+        if (hipStreamGetDevice((hipStream_t)stream, &dev) != hipSuccess) { (void)hipGetLastError(); return h->fail(PK_E_INVALID_ARG, "pk_set_stream: not a valid hipStream_t"); }
+        if ((int)dev != h->device) return h->fail(PK_E_INVALID_ARG, "pk_set_stream: the stream belongs to another device than the handle");
+    }
+    return switch_stream(h, (hipStream_t)stream);   // NULL = the legacy default stream (what torch's default stream is)
+}
+int pk_use_own_stream(pk_handle *h) {
+    if (!h) return PK_E_INVALID_ARG;
+    ON_DEVICE(h);
+    return switch_stream(h, h->own_stream);
 }
 int pk_wait_event(pk_handle *h, void *event) {
     if (!h || !event) return PK_E_INVALID_ARG;
@@ -537,6 +593,11 @@ int pk_env_step_async_d(pk_handle *h, const int32_t *actions_d, int seat0_policy
         (!actions_d && (seat0_policy < 0 || seat0_policy > 1)))
         return h ? h->fail(PK_E_INVALID_ARG, "pk_env_step_async_d: bad argument") : PK_E_INVALID_ARG;
     ON_DEVICE(h);
+    const int s0 = actions_d ? -1 : seat0_policy, au = auto_reset ? 1 : 0;
+    // steps in flight keep THEIR agents and reset rule (as owed rollout steps do): a call that would change them is refused
+    if (h->env_pending && (s0 != h->env_seat0 || opp_policy != h->env_opp || au != h->env_auto))
+        return h->fail(PK_E_INVALID_ARG, "pk_env_step_async_d: seat-0 source, opp_policy and auto_reset must stay the same while steps are in flight (drain with max_passes = 0 first)");
+    h->env_seat0 = s0; h->env_opp = opp_policy; h->env_auto = au;
     int rc = flush_rollout(h);
     if (rc) return rc;
     DISPATCH_N(h, k_env_step_async, table_grid(h), (const State *)h->d_S, h->hot, actions_d, actions_d ? -1 : seat0_policy, opp_policy,
@@ -577,9 +638,9 @@ static int fetch_counters(pk_handle *h, uint64_t *counters) {
 
 // fused: one launch that may leave work for later (counters == NULL) or must complete it (counters != NULL);
 // unfused: k_steps complete single-step launches (state round-trips HBM every step).
-static int enqueue_rollout(pk_handle *h, int k_steps, int policy, int auto_reset, int fused, bool complete) {
+static int enqueue_rollout(pk_handle *h, int k_steps, int policy, int auto_reset, int fused, bool complete, bool may_coalesce = true) {
     if (h->env_pending) return flush(h);   // PK_E_BUSY
-    if (h->pending && (policy != h->pend_policy || auto_reset != h->pend_auto)) FLUSH(h);  // owed steps keep THEIR agents
+    if ((h->pending || h->acc) && (policy != h->pend_policy || auto_reset != h->pend_auto)) FLUSH(h);  // owed steps keep THEIR agents
     if (!fused) {
         FLUSH(h);
         for (int k = 0; k < k_steps; ++k) {
@@ -591,7 +652,21 @@ static int enqueue_rollout(pk_handle *h, int k_steps, int policy, int auto_reset
     if (k_steps == 0) return complete ? flush(h) : PK_OK;
     // deferral only in the throughput mode: without auto_reset a table that reports an error stops for the rest of THIS
     // call (and is retried by the next), so calls must not be merged
-    return launch_rollout(h, k_steps, policy, auto_reset, (complete || !auto_reset) ? 1 : h->endk);
+    if (complete || !auto_reset) {
+        k_steps += h->acc; h->acc = 0;
+        return launch_rollout(h, k_steps, policy, auto_reset, 1);
+    }
+    if (k_steps > (1 << 30) - h->acc) FLUSH(h);
+    h->acc += k_steps;
+    h->pend_policy = policy; h->pend_auto = auto_reset;
+    if (may_coalesce && h->coalesce > 0 && h->acc < h->coalesce && h->ev_used[h->ev_idx]) {
+        // the launch before the last one (the ring slot about to be reused) still running: two launches are in flight,
+        // the GPU will not idle if this call just leaves its steps with the host
+        hipError_t q = hipEventQuery(h->ev_ring[h->ev_idx]);
+        if (q == hipErrorNotReady) return PK_OK;
+        if (q != hipSuccess) return h->fail(PK_E_HIP, "hipEventQuery", q);
+    }
+    return launch_coalesced(h, policy, auto_reset);
 }
 
 int pk_rollout(pk_handle *h, int k_steps, int policy, int auto_reset, int fused, uint64_t *counters) {
@@ -600,6 +675,19 @@ int pk_rollout(pk_handle *h, int k_steps, int policy, int auto_reset, int fused,
     int rc = enqueue_rollout(h, k_steps, policy, auto_reset ? 1 : 0, fused, counters != nullptr);
     if (rc) return rc;
     if (counters) return fetch_counters(h, counters);
+    return PK_OK;
+}
+
+int pk_set_coalesce(pk_handle *h, int max_steps) {
+    if (!h || max_steps < 0 || max_steps > (1 << 20)) return h ? h->fail(PK_E_INVALID_ARG, "pk_set_coalesce: 0 <= max_steps <= 2^20") : PK_E_INVALID_ARG;
+    h->coalesce = max_steps;
+    return PK_OK;
+}
+
+int pk_get_launch_stats(pk_handle *h, uint64_t *out, int reset) {
+    if (!h || !out) return PK_E_INVALID_ARG;
+    out[0] = h->st_launches; out[1] = h->st_steps; out[2] = h->st_min; out[3] = h->st_max;
+    if (reset) h->st_launches = h->st_steps = h->st_min = h->st_max = 0;
     return PK_OK;
 }
 
@@ -626,16 +714,17 @@ int pk_time_rollout(pk_handle *h, int k_steps, int policy, int auto_reset, int f
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
     for (int r = 0; r < reps; ++r) {
         // k_steps == 0: empty launches (load the tables, store them) -- the fixed cost of a launch, for diagnostics
-        int rc = k_steps ? enqueue_rollout(h, k_steps, policy, auto_reset ? 1 : 0, fused, false)
+        int rc = k_steps ? enqueue_rollout(h, k_steps, policy, auto_reset ? 1 : 0, fused, false, false)
                          : launch_rollout(h, 0, policy, auto_reset ? 1 : 0, 1);
         if (rc) return rc;
     }
-    FLUSH(h);  // what the deferred launches left is part of the work that is being timed
+    const bool flushed = h->pending;
+    FLUSH(h);  // what the deferred launches left is part of the work that is being timed: one more launch, counted below
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));
     HIPCHK(h, hipEventSynchronize(h->ev1));
     float ms = 0.f;
     HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
-    int launches = reps * (fused ? 1 : k_steps);
+    int launches = reps * (fused ? 1 : k_steps) + (flushed ? 1 : 0);
     *ms_per_launch = launches ? (double)ms / launches : 0.0;
     if (counters) return fetch_counters(h, counters);
     return PK_OK;

@@ -20,6 +20,19 @@ class VecPokerGameEnv:
     def num_tables(self):
         return self.game.num_tables
 
+    def close(self):
+        """Frees the device buffers of step_async and the game's handle."""
+        for b in getattr(self, '_async_buf', {}).values():
+            b.free()
+        self._async_buf = {}
+        self.game.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
     def reset(self, mask=None):
         """game_env.py:20-29 on all tables (or where mask != 0); returns the observation rows (StateView fields)."""
         g = self.game
@@ -75,7 +88,7 @@ class VecPokerGameEnv:
         from .hipmem import DeviceBuffer
         g = self.game
         T, D = g.num_tables, 17 + 3 * g.num_players
-        if not hasattr(self, '_async_buf'):
+        if not getattr(self, '_async_buf', None):
             dev = g.device
             self._async_buf = dict(act=DeviceBuffer(T * 4, dev), rew=DeviceBuffer(T * 8, dev), done=DeviceBuffer(T, dev),
                                    hand=DeviceBuffer(T, dev), terr=DeviceBuffer(T, dev), obs=DeviceBuffer(T * D * 8, dev),

@@ -164,6 +164,17 @@ class VecGame:
     def set_tuning(self, park=0, endk=0):
         L.check(self._lib.pk_set_tuning(self._h, int(park), int(endk)), self._h)
 
+    def set_coalesce(self, max_steps):
+        """Asynchronous rollout calls that arrive while two launches are in flight are merged on the host into launches
+        of up to `max_steps` steps (0: every call launches; default 512)."""
+        L.check(self._lib.pk_set_coalesce(self._h, int(max_steps)), self._h)
+
+    def launch_stats(self, reset=False):
+        """dict(launches, steps, min, max) of the fused rollout launches since the last reset."""
+        out = np.zeros(4, np.uint64)
+        L.check(self._lib.pk_get_launch_stats(self._h, L.ptr(out), int(bool(reset))), self._h)
+        return dict(launches=int(out[0]), steps=int(out[1]), min=int(out[2]), max=int(out[3]))
+
     # ------------------------------------------------------------------ streams (callers with their own HIP stream)
     @property
     def stream(self):
@@ -172,8 +183,13 @@ class VecGame:
         return s.value
 
     def set_stream(self, stream):
-        """Run on the caller's hipStream_t (int / c_void_p; None: back to the handle's own stream)."""
+        """Run on the caller's hipStream_t (int / c_void_p).  0 / None IS a stream -- the legacy default stream, which is
+        what torch.cuda.current_stream().cuda_stream returns outside a torch.cuda.Stream context; use_own_stream() goes
+        back to the handle's own non-blocking stream."""
         L.check(self._lib.pk_set_stream(self._h, C.c_void_p(stream) if isinstance(stream, int) else stream), self._h)
+
+    def use_own_stream(self):
+        L.check(self._lib.pk_use_own_stream(self._h), self._h)
 
     def wait_event(self, event):
         L.check(self._lib.pk_wait_event(self._h, C.c_void_p(event) if isinstance(event, int) else event), self._h)

@@ -53,3 +53,33 @@ class DeviceBuffer:
             self.free()
         except Exception:
             pass
+
+
+class DeviceEvent:
+    """A hipEvent_t for timing a region of a stream: pass `.handle` to VecGame.record_event (which records it on the
+    handle's stream after completing deferred work); elapsed_ms(start, stop) waits for `stop`."""
+
+    def __init__(self):
+        self.handle = C.c_void_p()
+        if _lib().hipEventCreate(C.byref(self.handle)) != 0:
+            raise RuntimeError("hipEventCreate failed")
+
+    @staticmethod
+    def elapsed_ms(start, stop):
+        if _lib().hipEventSynchronize(stop.handle) != 0:
+            raise RuntimeError("hipEventSynchronize failed")
+        ms = C.c_float(0.0)
+        if _lib().hipEventElapsedTime(C.byref(ms), start.handle, stop.handle) != 0:
+            raise RuntimeError("hipEventElapsedTime failed")
+        return float(ms.value)
+
+    def destroy(self):
+        if self.handle and self.handle.value:
+            _lib().hipEventDestroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass

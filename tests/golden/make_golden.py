@@ -74,7 +74,21 @@ class _StableArgsortNumpy:
         return np.argsort(a, *args, **kwargs)
 
 
-G.np = _StableArgsortNumpy()
+class _ReversedTieArgsortNumpy:
+    """The opposite deterministic tie rule (ascending values, DESCENDING seat index among equal bets): used only to show
+    that a TIE_SETS fixture really depends on the rule."""
+
+    def __getattr__(self, name):
+        return getattr(np, name)
+
+    @staticmethod
+    def argsort(a, *args, **kwargs):
+        a = np.asarray(a)
+        return len(a) - 1 - np.argsort(a[::-1], kind="stable")
+
+
+_STABLE_NP = _StableArgsortNumpy()
+G.np = _STABLE_NP
 
 _eval_sink = []
 _real_eval = G.eval_hand
@@ -446,6 +460,14 @@ ODD_SETS = {
     "game_n7_blinds_gt_stacks": (7, R.POLICY_RANDOM, 23, 6, 150, 4000000000, dict(start_credits=5, big_blind=40, small_blind=250), 6),
     "game_n8_mixed_allin": (8, R.POLICY_ALLIN, 24, 6, 100, 0, dict(start_credits=[1, 2, 3, 5, 10, 100, 1000, 0.5], big_blind=3, small_blind=1), 0),
 }
+# Configurations whose payoffs DEPEND on the order in which np.argsort(bets) (game.py:495) returns seats with EQUAL bets
+# (found with the fuzz generator): the reference with its pinned numpy (stable), which the fixtures pin, differs from the
+# reversed tie rule AND from the un-injected numpy 2.2.6 of this AVX-512 host (x86-simd-sort is not stable).  The
+# generator asserts both, so these vectors are the reference-held evidence for "ascending seat index among equal bets".
+TIE_SETS = {
+    "game_n8_argsort_tie": (8, R.POLICY_RANDOM, 349423999861, 4, 100, 0, dict(start_credits=1, big_blind=40, small_blind=2)),
+    "game_n9_argsort_tie": (9, R.POLICY_RANDOM, 141532477888, 4, 100, 0, dict(start_credits=10, big_blind=7.5, small_blind=40)),
+}
 NORESET_SETS = {
     "game_n2_noreset": (2, R.POLICY_RANDOM, 11, 6, 150, 0, None),
     "game_n3_noreset": (3, R.POLICY_RANDOM, 12, 6, 200, 0, dict(start_credits=20, big_blind=2, small_blind=1)),
@@ -498,6 +520,30 @@ def main():
             out = game_trajectory(n, pol, seed, tables, steps, base, cfg, dealer=dealer)
             np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
             print(name, "resets:", len(out["reset_idx"]), "hands:", int(out["post_hand_serial"].max()))
+    for name, (n, pol, seed, tables, steps, base, cfg) in TIE_SETS.items():
+        if want(name):
+            out = game_trajectory(n, pol, seed, tables, steps, base, cfg)
+
+            def first_diff(other_np):
+                G.np = other_np
+                try:
+                    alt = game_trajectory(n, pol, seed, tables, steps, base, cfg)
+                finally:
+                    G.np = _STABLE_NP
+                diff = (out["post_payoffs"].view(np.uint64) != alt["post_payoffs"].view(np.uint64)).any(axis=(1, 2))
+                return int(np.argmax(diff)) if diff.any() else -1
+
+            rev, native = first_diff(_ReversedTieArgsortNumpy()), first_diff(np)
+            assert rev >= 0, "%s does not depend on the argsort tie rule" % name
+            native_is_stable = list(np.argsort(np.array([2., 1, 0, 0, 0, 0, 1]))) == [2, 3, 4, 5, 1, 6, 0]
+            assert native >= 0 or native_is_stable, "%s: the un-injected numpy is unstable here yet gives the same payoffs" % name
+            meta = json.loads(str(out["meta"]))
+            meta["tie_rule"] = dict(rule="ascending seat index among equal bets (np.argsort of the reference's pinned numpy 1.18.4)",
+                                    first_step_where_reversed_tie_rule_differs=rev,
+                                    first_step_where_uninjected_numpy_differs=native, numpy=np.__version__)
+            out["meta"] = np.array(json.dumps(meta))
+            np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+            print(name, "resets:", len(out["reset_idx"]), "reversed tie rule differs from step", rev, "| un-injected numpy from step", native)
     for name, (n, pol, seed, tables, steps, base, cfg, sbase) in SERIAL_SETS.items():
         if want(name):
             out = game_trajectory(n, pol, seed, tables, steps, base, cfg, serial_base=sbase)

@@ -199,7 +199,10 @@ def test_deferred_launches_are_invisible(HB, O):
     launches).  Whatever the split and the tuning, an observer sees exactly the requested steps: many short deferred
     launches == one complete launch == the oracle, at BASELINE's headline size and on a ragged batch."""
     for T, N, policy, auto in [(65536, 6, 0, True), (1000, 9, 1, True), (3000, 3, 0, True), (700, 2, 0, False)]:
-        for endk, park, plan in [(64, 40, [20] * 12), (48, 40, [1, 7, 32, 200]), (33, 20, [60] * 4), (1, 40, [240]), (64, 64, [3] * 80)]:
+        # coalesce: asynchronous calls that arrive while two launches are in flight are merged on the host into launches
+        # of up to that many steps (0: never; -1: the library default)
+        for endk, park, plan, coalesce in [(64, 40, [20] * 12, 0), (48, 40, [1, 7, 32, 200], -1), (33, 20, [60] * 4, 0), (1, 40, [240], -1),
+                                           (64, 64, [3] * 80, 0), (48, 28, [6] * 40, 48), (48, 28, [20] * 12, 512), (40, 32, [3] * 80, 7)]:
             o = O.OracleGame(T, N, seed=5)
             o.reset()
             co = np.zeros(4, np.uint64)
@@ -209,13 +212,24 @@ def test_deferred_launches_are_invisible(HB, O):
                 co += o.rollout(k, policy, auto)[0]
             h = HB(T, N, seed=5)
             h.g.set_tuning(park, endk)
+            if coalesce >= 0:
+                h.g.set_coalesce(coalesce)
             h.reset()
+            h.g.launch_stats(reset=True)
             for k in plan:
-                h.g.rollout(k, policy, auto, True, counters=False)      # asynchronous, may defer
+                h.g.rollout(k, policy, auto, True, counters=False)      # asynchronous, may defer, may be held by the host
             c = h.rollout(0, policy, auto)                              # completes everything, fetches the counters
-            assert c.tolist() == co.tolist(), (T, N, endk, park)
+            assert c.tolist() == co.tolist(), (T, N, endk, park, coalesce)
+            st = h.g.launch_stats()
+            assert st["steps"] == sum(plan) and st["launches"] <= len(plan) + 1, st
+            if coalesce == 0 or not auto:
+                assert st["max"] == max(plan) and st["launches"] >= len(plan), st       # one launch per call
+            elif T == 65536 and coalesce > plan[0]:
+                # a launch of the whole chip lasts far longer than a ctypes call: calls pile up behind the two launches in flight
+                assert st["max"] > plan[0] and st["launches"] < len(plan), st
+                assert st["max"] < coalesce + plan[0], st
             snap = h.snapshot()
-            assert_same(o.snapshot(), snap, "T=%d N=%d endk=%d park=%d" % (T, N, endk, park))
+            assert_same(o.snapshot(), snap, "T=%d N=%d endk=%d park=%d coalesce=%d" % (T, N, endk, park, coalesce))
             if auto:
                 assert (snap["step_serial"] == 240).all()
             h.g.close()
@@ -665,20 +679,29 @@ def test_bench_json_contract():
     assert r["scaling"] == "weak" and r["vs_baseline"] is None and r["dtype"] == "f64" and r["data"] == "synthetic"
     assert "workload" in r["config"] and "model" not in r["config"] and "BASELINE configs[2]" in r["config"]["workload"]
     assert abs(r["value"] - 65536 * 256 / (r["ms_per_step"] * 256 / 1e3)) / r["value"] < 1e-6
-    assert r["reps"] == 512 and r["samples"] == 7 and len(r["sample_seconds"]) == 7   # 512 blocks of 256 steps = 131 072 per sample
+    assert r["reps"] == 1536 and r["samples"] == 7 and len(r["sample_seconds"]) == 7   # 1 536 blocks of 256 steps = 393 216 per sample
     rf = r["roofline"]
-    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
-    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
-    assert abs(rf["achieved"] - rf["algorithmic_bytes_per_launch"] / (rf["kernel_ms"] * 1e-3) / 1e9) / rf["achieved"] < 1e-6
-    # measured HBM traffic and the binding (VALU issue) roofline come from the committed rocprofv3 PMC summary of this workload
+    # the binding roofline leads: VALU issue, from the committed rocprofv3 PMC summary of this workload x this run's launch time
+    assert rf["bound"] == "valu-issue" and rf["unit"] == "wave-instr/s" and rf["peak"] == 256 * 4 * 2.4e9 / 2
+    assert 0.0 < rf["frac"] <= 0.5 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+    assert rf["waves_per_simd"] == 1.0 and 0.3 < rf["lanes_active"] <= 1.0 and rf["source"].endswith("_summary.json")
+    cm = rf["ceiling_mix"]
+    assert cm["peak"] < rf["peak"] and 0.0 < cm["frac_of_ceiling"] <= 1.0 and abs(cm["frac_of_ceiling"] - rf["achieved"] / cm["peak"]) < 1e-9
+    # self-consistent timing: HIP-event time per launch / steps per launch can never exceed the wall-clock time per step
+    assert rf["kernel_ms"] / rf["steps_per_launch"] <= r["ms_per_step"] * 1.0005, (rf["kernel_ms"], rf["steps_per_launch"], r["ms_per_step"])
+    st = r["config"]["launch_stats"]
+    assert st["steps"] == 256 * 1536 * 7 and abs(rf["steps_per_launch"] - st["steps"] / st["launches"]) < 1e-9 and rf["launches_timed"] == st["launches"]
+    # measured HBM traffic (one read + one write of the table state per launch) and SURVEY 8d's algorithmic figure, nested
     assert rf["traffic"] and 0.5 < rf["traffic"] / (65536 * 2 * 290) < 1.5 and rf["traffic_source"].endswith("_summary.json")
-    va = rf["valu"]
-    assert va["bound"] == "valu-issue" and 0.0 < va["frac"] <= 0.5 and abs(va["frac"] - va["achieved"] / va["peak"]) < 1e-9
-    assert va["peak"] == 256 * 4 * 2.4e9 / 2 and va["waves_per_simd"] == 1.0 and 0.3 < va["lanes_active"] <= 1.0
+    hb = rf["hbm_algorithmic"]
+    assert hb["unit"] == "GB/s" and hb["peak"] == 8000.0 and abs(hb["frac"] - hb["achieved"] / hb["peak"]) < 1e-9
+    assert abs(hb["achieved"] - hb["algorithmic_bytes_per_launch"] / (rf["kernel_ms"] * 1e-3) / 1e9) / hb["achieved"] < 1e-6
+    assert abs(hb["algorithmic_bytes_per_launch"] - 478 * 65536 * rf["steps_per_launch"]) < 1.0
     cb = r["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and cb["unit"] == "env-steps/s" and cb["sample"]
+    assert "all_cores" in cb and cb["all_cores"]["cores"] >= 1
     ev = r["evaluator"]
-    assert ev["roofline"]["bytes_per_eval"] == 12 and ev["hand_evals_per_s"] > 0
+    assert ev["roofline"]["bytes_per_eval"] == 12 and ev["hand_evals_per_s"] > 0 and 0.0 < ev["roofline"]["frac"] <= 1.0
 
 
 @pytest.mark.parametrize("N,policy", [(6, 0), (9, 1), (2, 0), (10, 0)])

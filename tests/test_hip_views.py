@@ -175,18 +175,23 @@ dev = torch.device("cuda", 0)
 hip = C.CDLL("libamdhip64.so")
 done = C.c_void_p()
 assert hip.hipEventCreate(C.byref(done)) == 0
-for variant in ("events", "set_stream"):
+for variant in ("events", "set_stream", "default_stream"):
     g = pokerl_amd.VecGame(T, num_players=N, seed=77)
     o = O.OracleGame(T, N, seed=77)
     g.reset(); o.reset()
     lib = g._lib
-    side = torch.cuda.Stream(device=dev)
+    # "default_stream": the producer is torch's DEFAULT stream, whose handle value is 0 (the ADVICE r02 case: ABI 2 took 0
+    # for "back to the handle's own stream" and raced); pk_set_stream(0) must mean the legacy default stream itself
+    side = torch.cuda.Stream(device=dev) if variant != "default_stream" else torch.cuda.current_stream(dev)
+    if variant == "default_stream":
+        assert side.cuda_stream == 0
     actions = torch.full((T,), -1, dtype=torch.int32, device=dev)      # -1 = invalid: a stale read is detected
     flags = torch.zeros(T, dtype=torch.uint8, device=dev)
     terr = torch.zeros(T, dtype=torch.uint8, device=dev)
     ballast = torch.randn(4096, 4096, device=dev)
-    if variant == "set_stream":
+    if variant != "events":
         g.set_stream(side.cuda_stream)
+        assert (g.stream or 0) == side.cuda_stream
     for s in range(12):
         a = o.pick_actions(0)
         fo, eo = o.step(a)
@@ -218,8 +223,9 @@ for variant in ("events", "set_stream"):
             o.reset(mask=over); g.reset(mask=over)
     g.sync()
     assert np.ascontiguousarray(o.f64(0)).tobytes() == np.ascontiguousarray(g.credits).tobytes()
-    if variant == "set_stream":
-        g.set_stream(None)
+    if variant != "events":
+        g.use_own_stream()
+        assert g.stream not in (None, 0, side.cuda_stream)
     g.close()
 print("STREAMS-OK")
 '''

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     L = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(L, name), name
-    assert _lib.lib().pk_abi_version() == _lib.ABI_VERSION == 2
+    assert _lib.lib().pk_abi_version() == _lib.ABI_VERSION == 3
 
 
 def test_no_device_fails_loudly():
@@ -82,12 +82,14 @@ sys.path.insert(0, %r)
 import bench
 rank = int(os.environ["RANK"]); world = int(os.environ["WORLD_SIZE"])
 ctx = bench.DistContext(backend="gloo")
-n, base = bench.shard(131072, ctx)
+n, base = bench.shard(65536 * world, ctx)
 # stand-in workload: rank r "runs" n*10 steps in (1 + r) seconds
 total_steps, seconds = ctx.aggregate(n * 10, 1.0 + rank)
+bases = ctx.sum_list([base if r == rank else 0 for r in range(world)])     # every rank's table_id_base, gathered by SUM
 ctx.barrier()
 if rank == 0:
-    print(json.dumps(dict(n=n, base=base, total=total_steps, seconds=seconds, world=world)))
+    print(json.dumps(dict(n=n, base=base, total=total_steps, seconds=seconds, world=world, bases=bases,
+                          cfg=bench.baseline_config_index(65536, 6, "random", world))))
 ctx.close()
 '''
 
@@ -106,6 +108,24 @@ def test_bench_aggregation_gloo_world2(tmp_path):
     assert r["world"] == 2 and r["n"] == 65536 and r["base"] == 0
     assert r["total"] == 131072 * 10          # units of ALL ranks
     assert r["seconds"] == 2.0                # MAX over ranks
+
+
+def test_bench_aggregation_gloo_world8(tmp_path):
+    """BASELINE configs[3] end to end without a node: the `--gpus 8` code path of bench.py (DistContext, contiguous shards by
+    global table id, barrier, SUM of units, MAX of seconds) with eight gloo ranks -- shards (65 536, r * 65 536)."""
+    script = tmp_path / "w8.py"
+    script.write_text(WORKER % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", OMP_NUM_THREADS="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8",
+                          "--master-addr", "127.0.0.1", "--master-port", "29541", str(script)],
+                         capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    import json
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert r["world"] == 8 and r["n"] == 65536 and r["base"] == 0 and r["cfg"] == 3
+    assert r["bases"] == [k * 65536 for k in range(8)]          # rank k hosts tables [k * 65 536, (k + 1) * 65 536)
+    assert r["total"] == 524288 * 10                            # units of ALL ranks
+    assert r["seconds"] == 8.0                                  # MAX over ranks (rank 7: 1 + 7 s)
 
 
 def test_state_view_mirror_fields_and_pickle():
