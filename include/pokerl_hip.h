@@ -67,6 +67,13 @@ extern "C" {
 /* in-kernel agents (synthetic workload; RandomAgent semantics of pokerl/agents/random.py:12-16) */
 #define PK_POLICY_RANDOM 0 /* uniform over the valid mask */
 #define PK_POLICY_ALLIN 1  /* always PokerMoves.ALL_IN */
+#define PK_POLICY_CALL 2   /* the calling station: CALL if valid, else CHECK if valid, else ALL_IN (no random draw) */
+#define PK_NUM_POLICIES 3
+/* One agent per seat, as PokerGameEnv(agents=[...]) has (pokerl/envs/game_env.py:13-18, :25, :43, :51): a 64-bit word with
+ * the policy of seat p in nibble p (bits 4p..4p+3).  PK_POLICY_EXTERNAL: the CALLER plays that seat (pk_env_step_multi_d). */
+#define PK_POLICY_EXTERNAL 15
+#define PK_SEAT_POLICY(word, p) ((int)(((word) >> (4 * (p))) & 15))
+#define PK_ACTION_SKIP (-2) /* pk_env_step_multi_d: "no action for this (idle) table" */
 
 /* f64 [T][N] fields of pk_get_f64 = Game attributes, pokerl/game.py:260-264 */
 #define PK_F_CREDITS 0
@@ -255,6 +262,32 @@ int pk_env_step_fused_d(pk_handle *h, const int32_t *actions_d, int seat0_policy
 int pk_env_step_async_d(pk_handle *h, const int32_t *actions_d, int seat0_policy, int opp_policy, int auto_reset,
                         int max_passes, double *reward_d, uint8_t *done_d, uint8_t *hand_d, uint8_t *terr_d,
                         double *obs_d, uint8_t *ready_d);
+
+/* PokerGameEnv with ONE AGENT PER SEAT, some of them played by the CALLER (self-play, league opponents, a learner's
+ * earlier checkpoints): pokerl/envs/game_env.py:13-18 takes a list of agent callables and calls
+ * self.agents[active_player](state) wherever an opponent is to act (:25, :43, :51).  seat_policies holds the agent of seat p
+ * in nibble p: an in-kernel policy, or PK_POLICY_EXTERNAL.  The call is pk_env_step_async_d with two more outcomes per table:
+ *   ready_d[t] = 1  PokerGameEnv.step (or .reset) has returned: reward / done / hand / terr / obs row written; the next
+ *                   call reads actions_d[t] as seat 0's action (ignored if seat 0's nibble is an in-kernel policy);
+ *   ready_d[t] = 2  an EXTERNAL opponent seat is to act inside the env call, which stays in flight: who_d[t] = that
+ *                   seat, the obs row is ITS StateView, terr_d[t] = 0; the next call reads actions_d[t] as ITS action.  An
+ *                   invalid one is refused: ready 2 again, terr_d[t] = PK_TERR_INVALID_ACTION, table untouched;
+ *   ready_d[t] = 0  the pass budget ran out first (only with max_passes > 0); supply nothing;
+ *   ready_d[t] = 3  the table was idle and actions_d[t] was PK_ACTION_SKIP: left alone, no output written (how a caller
+ *                   that serves the yielded tables keeps the tables that have already returned out of further launches).
+ * who_d[t] is always the seat to act next.  reset_d (may be NULL): reset_d[t] != 0 starts PokerGameEnv.reset()
+ * (game_env.py:20-29) on table t instead of a step -- delivered like a step, with reward 0, done 0, hand 0 -- dropping
+ * whatever that table had in flight.  max_passes <= 0: run until every table has returned or yielded.
+ * Per table the Game.steps, their order and every RNG draw are those of the reference's loop with the same agents; external
+ * seats whose caller plays an in-kernel policy's rule reproduce that policy's trajectory bit for bit (tested).
+ * While tables may be in flight all other entry points that read or change tables return PK_E_BUSY (as after
+ * pk_env_step_async_d); with an external seat that state lasts until pk_env_end_multi_d, which drains and ABANDONS the env
+ * calls still waiting for an external action (their tables stay where they are, between two Game.steps); call it after a
+ * drain (max_passes <= 0) so that no delivered step is lost.  seat_policies and auto_reset must not change meanwhile. */
+int pk_env_step_multi_d(pk_handle *h, const int32_t *actions_d, const uint8_t *reset_d, uint64_t seat_policies, int auto_reset,
+                        int max_passes, double *reward_d, uint8_t *done_d, uint8_t *hand_d, uint8_t *terr_d, double *obs_d,
+                        uint8_t *who_d, uint8_t *ready_d);
+int pk_env_end_multi_d(pk_handle *h);
 
 /* Stream control (no torch types: `stream` is a hipStream_t, `event` a hipEvent_t, passed as void*).  A handle creates
  * its own NON-BLOCKING stream (no implicit ordering with the legacy default stream).  pk_set_stream makes it run on the

@@ -51,6 +51,9 @@ def lib():
     L.orc_env_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     L.orc_env_step.argtypes = [C.c_void_p, _i32p, C.c_int, _f64p, _u8p, _u8p, _u8p]
     L.orc_env_step.restype = C.c_int
+    L.orc_env_reset_seats.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+    L.orc_env_step_seats.argtypes = [C.c_void_p, _i32p, C.c_uint64, _f64p, _u8p, _u8p, _u8p]
+    L.orc_env_step_seats.restype = C.c_int
     L.orc_get_f64.argtypes = [C.c_void_p, C.c_int, _f64p]
     L.orc_get_min_raise.argtypes = [C.c_void_p, _f64p]
     L.orc_get_states.argtypes = [C.c_void_p, _u8p]
@@ -128,9 +131,18 @@ class OracleGame:
         e = self.L.orc_rollout(self.h, int(K), int(policy), int(bool(auto_reset)), c)
         return c, e
 
+    @staticmethod
+    def _seats(opp_policy):
+        """int: every opponent plays that policy; list: one policy per OPPONENT seat (seat 1 first), as the reference's
+        PokerGameEnv(agents=[...]) takes them."""
+        if isinstance(opp_policy, (list, tuple)):
+            from . import rng_spec as R
+            return R.seat_policies([0] + list(opp_policy))
+        return 0x1111111111111111 * (int(opp_policy) & 15)
+
     def env_reset(self, mask=None, opp_policy=0):
         keep, p = self._mask(mask)
-        self.L.orc_env_reset(self.h, p, int(opp_policy))
+        self.L.orc_env_reset_seats(self.h, p, self._seats(opp_policy))
 
     def env_step(self, actions, opp_policy=0):
         a = np.ascontiguousarray(actions, np.int32)
@@ -138,7 +150,7 @@ class OracleGame:
         done = np.zeros(self.T, np.uint8)
         hand = np.zeros(self.T, np.uint8)
         err = np.zeros(self.T, np.uint8)
-        self.L.orc_env_step(self.h, a, int(opp_policy), reward, done, hand, err)
+        self.L.orc_env_step_seats(self.h, a, self._seats(opp_policy), reward, done, hand, err)
         return reward, done, hand, err
 
     def set_serials(self, hand_serial=None, step_serial=None):

@@ -81,6 +81,7 @@ void orc_deck(uint64_t seed, uint32_t table_id, uint64_t hand_serial, uint8_t ou
 
 static int pick_action(uint64_t seed, const table_t *t, int policy, unsigned mask) {
     if (policy == 1) return MV_ALL_IN;
+    if (policy == 2) return ((mask >> MV_CALL) & 1) ? MV_CALL : (((mask >> MV_CHECK) & 1) ? MV_CHECK : MV_ALL_IN); /* call agent, rng_spec.py */
     uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)}, o[4];
     uint64_t q = t->step_serial >> 3;
     int j = (int)(t->step_serial & 7);
@@ -525,12 +526,15 @@ int orc_rollout(orc_game *g, int K, int policy, int auto_reset, uint64_t *counte
 }
 
 /* envs/game_env.py:20-29 */
-static void env_reset_table(orc_game *g, table_t *t, int opp_policy) {
+/* self.agents[active_player] (:25, :43, :51): policy nibble of the seat to act */
+static inline int seat_policy(uint64_t seatpol, const table_t *t) { return (int)((seatpol >> (4 * t->active_player)) & 15); }
+
+static void env_reset_table(orc_game *g, table_t *t, uint64_t seatpol) {
     reset_table(g, t, 0);                                                          /* :23 */
     int budget = ORC_ENV_STEP_CAP;
     while (t->active_player != 0) {                                                /* :24 */
         uint8_t fl;
-        int a = pick_action(g->seed, t, opp_policy, valid_actions(g, t, t->active_player)); /* :25 */
+        int a = pick_action(g->seed, t, seat_policy(seatpol, t), valid_actions(g, t, t->active_player)); /* :25 */
         int e = step_table(g, t, a, &fl);                                          /* :26 */
         if (--budget < 0) t->err |= ORC_ERR_ENV_CAP;
         if (e || t->err) return;
@@ -538,12 +542,20 @@ static void env_reset_table(orc_game *g, table_t *t, int opp_policy) {
     }
 }
 
-void orc_env_reset(orc_game *g, const uint8_t *mask, int opp_policy) {
-    for (int i = 0; i < g->T; ++i) if (!mask || mask[i]) env_reset_table(g, &g->t[i], opp_policy);
+static uint64_t uniform_seats(int policy) { return 0x1111111111111111ull * (uint64_t)(policy & 15); }
+
+void orc_env_reset_seats(orc_game *g, const uint8_t *mask, uint64_t seatpol) {
+    for (int i = 0; i < g->T; ++i) if (!mask || mask[i]) env_reset_table(g, &g->t[i], seatpol);
 }
+void orc_env_reset(orc_game *g, const uint8_t *mask, int opp_policy) { orc_env_reset_seats(g, mask, uniform_seats(opp_policy)); }
 
 int orc_env_step(orc_game *g, const int32_t *actions, int opp_policy, double *reward, uint8_t *done_out, uint8_t *hand_out,
-                 uint8_t *err) { /* envs/game_env.py:31-53 */
+                 uint8_t *err) {
+    return orc_env_step_seats(g, actions, uniform_seats(opp_policy), reward, done_out, hand_out, err);
+}
+
+int orc_env_step_seats(orc_game *g, const int32_t *actions, uint64_t seatpol, double *reward, uint8_t *done_out, uint8_t *hand_out,
+                       uint8_t *err) { /* envs/game_env.py:31-53 */
     int any = 0;
     for (int i = 0; i < g->T; ++i) {
         table_t *t = &g->t[i];
@@ -559,7 +571,7 @@ int orc_env_step(orc_game *g, const int32_t *actions, int opp_policy, double *re
         }
         int budget = ORC_ENV_STEP_CAP;
         while (!hand && t->active_player != 0) {                                   /* :41-44 */
-            int a = pick_action(g->seed, t, opp_policy, valid_actions(g, t, t->active_player));
+            int a = pick_action(g->seed, t, seat_policy(seatpol, t), valid_actions(g, t, t->active_player));
             e = step_table(g, t, a, &fl);
             if (--budget < 0) { t->err |= ORC_ERR_ENV_CAP; e |= ORC_ERR_ENV_CAP; }
             if (e) break;
@@ -567,7 +579,7 @@ int orc_env_step(orc_game *g, const int32_t *actions, int opp_policy, double *re
         }
         if (!e && hand) rew = t->payoffs[0];                                       /* :47 */
         while (!e && !done && t->active_player != 0) {                             /* :49-52 */
-            int a = pick_action(g->seed, t, opp_policy, valid_actions(g, t, t->active_player));
+            int a = pick_action(g->seed, t, seat_policy(seatpol, t), valid_actions(g, t, t->active_player));
             e = step_table(g, t, a, &fl);
             if (--budget < 0) { t->err |= ORC_ERR_ENV_CAP; e |= ORC_ERR_ENV_CAP; }
             if (e) break;

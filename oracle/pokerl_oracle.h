@@ -45,7 +45,7 @@ void orc_valid_actions(const orc_game *g, uint8_t *mask);
 /* the same for seat `player` of every table (player < 0: the active player), get_valid_actions(player) game.py:339-383 */
 void orc_valid_actions_for(const orc_game *g, int player, uint8_t *mask);
 
-/* Synthetic agents of rng_spec.py: policy 0 random, 1 all-in. Writes the action each table would take now. */
+/* Synthetic agents of rng_spec.py: policy 0 random, 1 all-in, 2 call. Writes the action each table would take now. */
 void orc_pick_actions(const orc_game *g, int policy, int32_t *actions);
 
 /* K lockstep steps with in-library agents; auto_reset != 0 resets finished games (dealer 0).
@@ -57,6 +57,11 @@ int orc_rollout(orc_game *g, int K, int policy, int auto_reset, uint64_t *counte
 void orc_env_reset(orc_game *g, const uint8_t *mask, int opp_policy);
 int orc_env_step(orc_game *g, const int32_t *actions, int opp_policy, double *reward, uint8_t *done, uint8_t *hand,
                  uint8_t *err);
+/* The same with one agent per seat, as PokerGameEnv(agents=[...]) has (envs/game_env.py:13-18, :25, :43, :51): seat p plays
+ * policy nibble (seat_policies >> 4p) & 15 (rng_spec.py; seat 0's nibble is not used: its actions are the arguments). */
+void orc_env_reset_seats(orc_game *g, const uint8_t *mask, uint64_t seat_policies);
+int orc_env_step_seats(orc_game *g, const int32_t *actions, uint64_t seat_policies, double *reward, uint8_t *done, uint8_t *hand,
+                       uint8_t *err);
 
 /* State reads, table-major [T][N] (or [T]). */
 enum { ORC_F_CREDITS = 0, ORC_F_BETS = 1, ORC_F_PENDING = 2, ORC_F_PAYOFFS = 3 };

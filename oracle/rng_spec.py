@@ -27,6 +27,14 @@ RNG seeds" is defined by THIS counter-based spec instead:
       n = popcount(valid_mask);  k = (r * n) >> 16;  action = k-th set bit (ascending)
       (n <= 7, so the bias of the bounded draw is at most 7/65536 per action.)
 
+  deterministic agents (no random draw; a step played by one still advances step_serial):
+      all-in agent (policy 1): always ALL_IN (6).
+      call agent   (policy 2): CALL (2) if it is valid, else CHECK (1) if it is valid, else ALL_IN (6) -- the passive
+      "calling station"; CALL is invalid exactly when high_bet >= credit (game.py:376), CHECK when high_bet != 0 (:375).
+
+  per-seat agents (PokerGameEnv with a list of agents, envs/game_env.py:13-18): seat p plays policy nibble
+  (seat_policies >> 4p) & 15 of a 64-bit word; 15 = the caller supplies that seat's actions.
+
 Pure-Python ints here (small cases only); the C restatement lives in pokerl_oracle.c.
 """
 
@@ -43,6 +51,16 @@ DEFAULT_SEED = 0x706F6B65726C  # 'pokerl'
 
 POLICY_RANDOM = 0
 POLICY_ALLIN = 1
+POLICY_CALL = 2
+POLICY_EXTERNAL = 15
+
+
+def seat_policies(policies):
+    """Packs one policy per seat (seat 0 first) into the 64-bit word the oracle / the C ABI take."""
+    w = 0
+    for p, pol in enumerate(policies):
+        w |= (int(pol) & 15) << (4 * p)
+    return w
 
 
 def philox4x32_10(ctr, key):
@@ -99,6 +117,8 @@ def pick_action(seed, table_id, step_serial, valid_mask_bits, policy=POLICY_RAND
     """Action of the synthetic agents. valid_mask_bits: bit a set iff action a valid."""
     if policy == POLICY_ALLIN:
         return 6
+    if policy == POLICY_CALL:
+        return 2 if (valid_mask_bits >> 2) & 1 else (1 if (valid_mask_bits >> 1) & 1 else 6)
     q, j = step_serial >> 3, step_serial & 7
     w = philox4x32_10((table_id & MASK32, q & MASK32, STREAM_ACTION, (q >> 32) & MASK32), seed_key(seed))
     r = (w[j >> 1] >> (16 * (j & 1))) & 0xFFFF

@@ -14,6 +14,8 @@ FLAG_GAME_OVER, FLAG_HAND_OVER, FLAG_TURN_OVER = 1, 2, 4
 F_CREDITS, F_BETS, F_PENDING_BETS, F_PAYOFFS = 0, 1, 2, 3
 I_ACTIVE_PLAYER, I_TURN, I_DEALER_IDX, I_SMALL_BLIND_IDX, I_BIG_BLIND_IDX, I_HAND = range(6)
 TF_POT, TF_HIGH_BET, TF_MIN_RAISE = 0, 1, 2
+ACTION_SKIP = -2   # pk_env_step_multi_d: leave an idle table alone (PK_ACTION_SKIP)
+POLICY_EXTERNAL = 15
 ABI_VERSION = 3
 NUM_COUNTERS = 4
 MIN_PLAYERS, MAX_PLAYERS = 2, 10
@@ -27,7 +29,7 @@ SYMBOLS = ["pk_abi_version", "pk_device_count", "pk_last_error", "pk_create", "p
            "pk_get_valid_actions_d", "pk_env_step_d", "pk_env_reset_d", "pk_eval7_d", "pk_make_hands_d", "pk_time_eval7_d",
            "pk_get_serials", "pk_set_serials", "pk_get_table_f64", "pk_get_game_over", "pk_eval_hands_d",
            "pk_pick_actions_d", "pk_flush", "pk_get_owed", "pk_env_step_fused_d", "pk_env_step_async_d", "pk_set_tuning", "pk_get_stream", "pk_set_stream", "pk_wait_event",
-           "pk_record_event", "pk_use_own_stream", "pk_set_coalesce", "pk_get_launch_stats"]
+           "pk_record_event", "pk_use_own_stream", "pk_set_coalesce", "pk_get_launch_stats", "pk_env_step_multi_d", "pk_env_end_multi_d"]
 
 
 class PokerlHipError(RuntimeError):
@@ -91,6 +93,8 @@ def lib():
     L.pk_flush.argtypes = [_vp]
     L.pk_env_step_fused_d.argtypes = [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]
     L.pk_env_step_async_d.argtypes = [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]
+    L.pk_env_step_multi_d.argtypes = [_vp, _vp, _vp, C.c_uint64, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
+    L.pk_env_end_multi_d.argtypes = [_vp]
     L.pk_get_owed.argtypes = [_vp, _vp]
     L.pk_set_tuning.argtypes = [_vp, C.c_int, C.c_int]
     L.pk_get_stream.argtypes = [_vp, C.POINTER(_vp)]

@@ -44,6 +44,8 @@ struct pk_handle {
     // launches of the fused rollout kernel since pk_get_launch_stats(reset): count, steps summed, min / max steps per launch
     uint64_t st_launches = 0, st_steps = 0, st_min = 0, st_max = 0;
     int env_seat0 = 0, env_opp = 0, env_auto = 0;   // agents / auto_reset of the PokerGameEnv.steps in flight (env_pending)
+    bool env_multi = false;                         // ... they belong to pk_env_step_multi_d, with these per-seat agents:
+    uint64_t env_seats = 0;
     // PokerGameEnv.steps left in flight by pk_env_step_async_d (State::env_ctx): every other entry point that touches
     // table state refuses to run until a draining call (max_passes <= 0) has completed them.
     bool env_pending = false;
@@ -107,6 +109,9 @@ struct DeviceGuard {
         }                                                                                                        \
     } while (0)
 
+static inline bool bad_policy(int policy) { return policy < 0 || policy >= PK_NUM_POLICIES; }
+// every seat plays `policy`: the per-seat word of the entry points that take ONE opponent policy
+static inline uint64_t uniform_seats(int policy) { return 0x1111111111111111ull * (uint64_t)(policy & 15); }
 static inline int table_grid(const pk_handle *h) { return (h->T + h->tpb - 1) / h->tpb; }
 // parking threshold for waves that hold h->tpb tables instead of 64
 static inline int scaled_park(const pk_handle *h, int dflt = 32) {
@@ -120,7 +125,8 @@ static inline int flat_grid(size_t n) { return (int)((n + 255) / 256); }
 static int launch_rollout(pk_handle *h, int k_steps, int policy, int auto_reset, int endk) {
     const int slack = endk <= 1 ? PK_WAVE : ((PK_WAVE - endk) * h->tpb) / PK_WAVE;   // lanes allowed to idle before a launch ends
 #define ROLLOUT_ARGS (const State *)h->d_S, h->hot, k_steps, auto_reset, scaled_park(h, policy == PK_POLICY_RANDOM ? 28 : 32), slack, h->pending ? 0 : 1
-    if (!h->occ3) {
+    if (policy == PK_POLICY_CALL) DISPATCH_N(h, k_rollout_call, table_grid(h), ROLLOUT_ARGS);
+    else if (!h->occ3) {
         if (policy == PK_POLICY_RANDOM) DISPATCH_N(h, k_rollout, table_grid(h), ROLLOUT_ARGS);
         else DISPATCH_N(h, k_rollout_allin, table_grid(h), ROLLOUT_ARGS);
     } else {
@@ -555,33 +561,33 @@ int pk_get_valid_actions_d(pk_handle *h, int player, uint8_t *out_d) {
 }
 
 int pk_env_reset_d(pk_handle *h, const uint8_t *mask_d, int opp_policy) {
-    if (!h || opp_policy < 0 || opp_policy > 1) return h ? h->fail(PK_E_INVALID_ARG, "pk_env_reset_d: bad argument") : PK_E_INVALID_ARG;
+    if (!h || bad_policy(opp_policy)) return h ? h->fail(PK_E_INVALID_ARG, "pk_env_reset_d: bad argument") : PK_E_INVALID_ARG;
     ON_DEVICE(h);
     FLUSH(h);
-    DISPATCH_N(h, k_env_reset, table_grid(h), (const State *)h->d_S, h->hot, mask_d, opp_policy, scaled_park(h));
+    DISPATCH_N(h, k_env_reset, table_grid(h), (const State *)h->d_S, h->hot, mask_d, uniform_seats(opp_policy), scaled_park(h));
     HIPCHK(h, hipGetLastError());
     return PK_OK;
 }
 
 int pk_env_step_d(pk_handle *h, const int32_t *actions_d, int opp_policy, double *reward_d, uint8_t *done_d,
                   uint8_t *hand_d, uint8_t *terr_d) {
-    if (!h || !actions_d || !reward_d || !done_d || !hand_d || !terr_d || opp_policy < 0 || opp_policy > 1)
+    if (!h || !actions_d || !reward_d || !done_d || !hand_d || !terr_d || bad_policy(opp_policy))
         return h ? h->fail(PK_E_INVALID_ARG, "pk_env_step_d: bad argument") : PK_E_INVALID_ARG;
     ON_DEVICE(h);
     FLUSH(h);
-    DISPATCH_N(h, k_env_step, table_grid(h), (const State *)h->d_S, h->hot, actions_d, -1, opp_policy, 0, reward_d, done_d, hand_d, terr_d, (double *)nullptr, scaled_park(h));
+    DISPATCH_N(h, k_env_step, table_grid(h), (const State *)h->d_S, h->hot, actions_d, -1, uniform_seats(opp_policy), 0, reward_d, done_d, hand_d, terr_d, (double *)nullptr, scaled_park(h));
     HIPCHK(h, hipGetLastError());
     return PK_OK;
 }
 
 int pk_env_step_fused_d(pk_handle *h, const int32_t *actions_d, int seat0_policy, int opp_policy, int auto_reset,
                         double *reward_d, uint8_t *done_d, uint8_t *hand_d, uint8_t *terr_d, double *obs_d) {
-    if (!h || !reward_d || !done_d || !hand_d || !terr_d || opp_policy < 0 || opp_policy > 1 ||
-        (!actions_d && (seat0_policy < 0 || seat0_policy > 1)))
+    if (!h || !reward_d || !done_d || !hand_d || !terr_d || bad_policy(opp_policy) ||
+        (!actions_d && (bad_policy(seat0_policy))))
         return h ? h->fail(PK_E_INVALID_ARG, "pk_env_step_fused_d: bad argument") : PK_E_INVALID_ARG;
     ON_DEVICE(h);
     FLUSH(h);
-    DISPATCH_N(h, k_env_step, table_grid(h), (const State *)h->d_S, h->hot, actions_d, actions_d ? -1 : seat0_policy, opp_policy,
+    DISPATCH_N(h, k_env_step, table_grid(h), (const State *)h->d_S, h->hot, actions_d, actions_d ? -1 : seat0_policy, uniform_seats(opp_policy),
                auto_reset ? 1 : 0, reward_d, done_d, hand_d, terr_d, obs_d, scaled_park(h));
     HIPCHK(h, hipGetLastError());
     return PK_OK;
@@ -589,26 +595,78 @@ int pk_env_step_fused_d(pk_handle *h, const int32_t *actions_d, int seat0_policy
 
 int pk_env_step_async_d(pk_handle *h, const int32_t *actions_d, int seat0_policy, int opp_policy, int auto_reset, int max_passes,
                         double *reward_d, uint8_t *done_d, uint8_t *hand_d, uint8_t *terr_d, double *obs_d, uint8_t *ready_d) {
-    if (!h || !reward_d || !done_d || !hand_d || !terr_d || !ready_d || opp_policy < 0 || opp_policy > 1 ||
-        (!actions_d && (seat0_policy < 0 || seat0_policy > 1)))
+    if (!h || !reward_d || !done_d || !hand_d || !terr_d || !ready_d || bad_policy(opp_policy) ||
+        (!actions_d && (bad_policy(seat0_policy))))
         return h ? h->fail(PK_E_INVALID_ARG, "pk_env_step_async_d: bad argument") : PK_E_INVALID_ARG;
     ON_DEVICE(h);
     const int s0 = actions_d ? -1 : seat0_policy, au = auto_reset ? 1 : 0;
     // steps in flight keep THEIR agents and reset rule (as owed rollout steps do): a call that would change them is refused
-    if (h->env_pending && (s0 != h->env_seat0 || opp_policy != h->env_opp || au != h->env_auto))
+    if (h->env_pending && (h->env_multi || s0 != h->env_seat0 || opp_policy != h->env_opp || au != h->env_auto))
         return h->fail(PK_E_INVALID_ARG, "pk_env_step_async_d: seat-0 source, opp_policy and auto_reset must stay the same while steps are in flight (drain with max_passes = 0 first)");
     h->env_seat0 = s0; h->env_opp = opp_policy; h->env_auto = au;
     int rc = flush_rollout(h);
     if (rc) return rc;
-    DISPATCH_N(h, k_env_step_async, table_grid(h), (const State *)h->d_S, h->hot, actions_d, actions_d ? -1 : seat0_policy, opp_policy,
+    DISPATCH_N(h, k_env_step_async, table_grid(h), (const State *)h->d_S, h->hot, actions_d, actions_d ? -1 : seat0_policy, uniform_seats(opp_policy),
                auto_reset ? 1 : 0, reward_d, done_d, hand_d, terr_d, obs_d, scaled_park(h), ready_d, max_passes > 0 ? max_passes : 0);
     HIPCHK(h, hipGetLastError());
     h->env_pending = max_passes > 0;
+    h->env_multi = false;
+    return PK_OK;
+}
+
+static int check_seat_policies(pk_handle *h, uint64_t seat_policies, bool *any_external) {
+    *any_external = false;
+    for (int p = 0; p < h->N; ++p) {
+        const int pol = PK_SEAT_POLICY(seat_policies, p);
+        if (pol == PK_POLICY_EXTERNAL) *any_external = true;
+        else if (bad_policy(pol)) return h->fail(PK_E_INVALID_ARG, "seat_policies: nibble p must be PK_POLICY_RANDOM / _ALLIN / _CALL or PK_POLICY_EXTERNAL for every seat p < num_players");
+    }
+    return PK_OK;
+}
+
+int pk_env_step_multi_d(pk_handle *h, const int32_t *actions_d, const uint8_t *reset_d, uint64_t seat_policies, int auto_reset,
+                        int max_passes, double *reward_d, uint8_t *done_d, uint8_t *hand_d, uint8_t *terr_d, double *obs_d,
+                        uint8_t *who_d, uint8_t *ready_d) {
+    if (!h || !reward_d || !done_d || !hand_d || !terr_d || !ready_d || !who_d)
+        return h ? h->fail(PK_E_INVALID_ARG, "pk_env_step_multi_d: NULL buffer") : PK_E_INVALID_ARG;
+    bool ext = false;
+    int rc = check_seat_policies(h, seat_policies, &ext);
+    if (rc) return rc;
+    if (ext && !actions_d) return h->fail(PK_E_INVALID_ARG, "pk_env_step_multi_d: actions_d is required when a seat is PK_POLICY_EXTERNAL");
+    ON_DEVICE(h);
+    const int au = auto_reset ? 1 : 0;
+    // steps in flight keep THEIR agents and reset rule: a call that would change them is refused
+    if (h->env_pending && (!h->env_multi || seat_policies != h->env_seats || au != h->env_auto))
+        return h->fail(PK_E_INVALID_ARG, "pk_env_step_multi_d: seat_policies and auto_reset must stay the same while steps are in flight (pk_env_end_multi_d first)");
+    rc = flush_rollout(h);
+    if (rc) return rc;
+    const int pol0 = PK_SEAT_POLICY(seat_policies, 0);
+    DISPATCH_N(h, k_env_step_multi, table_grid(h), (const State *)h->d_S, h->hot, actions_d, pol0 == PK_POLICY_EXTERNAL ? -1 : pol0, seat_policies,
+               au, reward_d, done_d, hand_d, terr_d, obs_d, scaled_park(h), ready_d, max_passes > 0 ? max_passes : 0, reset_d, who_d, 0);
+    HIPCHK(h, hipGetLastError());
+    // a table may be waiting for the caller's action for an external seat even after a drain: in flight until pk_env_end_multi_d
+    h->env_pending = max_passes > 0 || ext;
+    h->env_multi = true; h->env_seats = seat_policies; h->env_auto = au;
+    return PK_OK;
+}
+
+int pk_env_end_multi_d(pk_handle *h) {
+    if (!h) return PK_E_INVALID_ARG;
+    ON_DEVICE(h);
+    if (!h->env_pending) return PK_OK;
+    if (!h->env_multi) return h->fail(PK_E_INVALID_ARG, "pk_env_end_multi_d: the steps in flight belong to pk_env_step_async_d (drain them with max_passes = 0)");
+    const int pol0 = PK_SEAT_POLICY(h->env_seats, 0);
+    // drain; what is still in flight afterwards waits for an external seat's action between two Game.steps and is abandoned.
+    // Outputs of steps that return during this drain go to the handle's own staging buffers, i.e. are dropped.
+    DISPATCH_N(h, k_env_step_multi, table_grid(h), (const State *)h->d_S, h->hot, (const int32_t *)nullptr, pol0 == PK_POLICY_EXTERNAL ? -1 : pol0, h->env_seats,
+               h->env_auto, h->d_reward, h->d_done, h->d_handf, h->d_terr, (double *)nullptr, scaled_park(h), h->d_flags, 0, (const uint8_t *)nullptr, h->d_mask, 1);
+    HIPCHK(h, hipGetLastError());
+    h->env_pending = false; h->env_multi = false;
     return PK_OK;
 }
 
 int pk_pick_actions_d(pk_handle *h, int policy, int32_t *actions_d) {
-    if (!h || !actions_d || policy < 0 || policy > 1) return h ? h->fail(PK_E_INVALID_ARG, "pk_pick_actions_d: bad argument") : PK_E_INVALID_ARG;
+    if (!h || !actions_d || bad_policy(policy)) return h ? h->fail(PK_E_INVALID_ARG, "pk_pick_actions_d: bad argument") : PK_E_INVALID_ARG;
     ON_DEVICE(h);
     FLUSH(h);
     DISPATCH_N(h, k_pick, table_grid(h), h->S, h->hot, policy, actions_d);
@@ -617,7 +675,7 @@ int pk_pick_actions_d(pk_handle *h, int policy, int32_t *actions_d) {
 }
 
 int pk_pick_actions(pk_handle *h, int policy, int32_t *actions) {
-    if (!h || !actions || policy < 0 || policy > 1) return h ? h->fail(PK_E_INVALID_ARG, "pk_pick_actions: bad argument") : PK_E_INVALID_ARG;
+    if (!h || !actions || bad_policy(policy)) return h ? h->fail(PK_E_INVALID_ARG, "pk_pick_actions: bad argument") : PK_E_INVALID_ARG;
     ON_DEVICE(h);
     int rc = pk_pick_actions_d(h, policy, h->d_actions);
     if (rc) return rc;
@@ -670,7 +728,7 @@ static int enqueue_rollout(pk_handle *h, int k_steps, int policy, int auto_reset
 }
 
 int pk_rollout(pk_handle *h, int k_steps, int policy, int auto_reset, int fused, uint64_t *counters) {
-    if (!h || k_steps < 0 || policy < 0 || policy > 1) return h ? h->fail(PK_E_INVALID_ARG, "pk_rollout: bad argument") : PK_E_INVALID_ARG;
+    if (!h || k_steps < 0 || bad_policy(policy)) return h ? h->fail(PK_E_INVALID_ARG, "pk_rollout: bad argument") : PK_E_INVALID_ARG;
     ON_DEVICE(h);
     int rc = enqueue_rollout(h, k_steps, policy, auto_reset ? 1 : 0, fused, counters != nullptr);
     if (rc) return rc;
@@ -707,7 +765,7 @@ int pk_flush(pk_handle *h) {
 
 int pk_time_rollout(pk_handle *h, int k_steps, int policy, int auto_reset, int fused, int reps, double *ms_per_launch,
                     uint64_t *counters) {
-    if (!h || !ms_per_launch || reps < 1 || k_steps < 0 || policy < 0 || policy > 1)
+    if (!h || !ms_per_launch || reps < 1 || k_steps < 0 || bad_policy(policy))
         return h ? h->fail(PK_E_INVALID_ARG, "pk_time_rollout: bad argument") : PK_E_INVALID_ARG;
     ON_DEVICE(h);
     FLUSH(h);
@@ -731,7 +789,7 @@ int pk_time_rollout(pk_handle *h, int k_steps, int policy, int auto_reset, int f
 }
 
 int pk_env_reset(pk_handle *h, const uint8_t *mask, int opp_policy) {
-    if (!h || opp_policy < 0 || opp_policy > 1) return h ? h->fail(PK_E_INVALID_ARG, "pk_env_reset: bad argument") : PK_E_INVALID_ARG;
+    if (!h || bad_policy(opp_policy)) return h ? h->fail(PK_E_INVALID_ARG, "pk_env_reset: bad argument") : PK_E_INVALID_ARG;
     ON_DEVICE(h);
     const uint8_t *dmask;
     int rc = upload_mask(h, mask, &dmask);
@@ -744,7 +802,7 @@ int pk_env_reset(pk_handle *h, const uint8_t *mask, int opp_policy) {
 
 int pk_env_step(pk_handle *h, const int32_t *actions, int opp_policy, double *reward, uint8_t *done, uint8_t *hand,
                 uint8_t *terr) {
-    if (!h || !actions || !reward || !done || !hand || opp_policy < 0 || opp_policy > 1)
+    if (!h || !actions || !reward || !done || !hand || bad_policy(opp_policy))
         return h ? h->fail(PK_E_INVALID_ARG, "pk_env_step: bad argument") : PK_E_INVALID_ARG;
     ON_DEVICE(h);
     const size_t T = (size_t)h->T;

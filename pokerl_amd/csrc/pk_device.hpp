@@ -510,11 +510,18 @@ __device__ __forceinline__ int action_from_draw(uint32_t r16, uint32_t mask) {
     return __ffs(m) - 1;
 }
 
+// The call agent of the RNG / agent spec: CALL if valid, else CHECK if valid, else ALL_IN.
+__device__ __forceinline__ int call_action(uint32_t mask) {
+    return ((mask >> MV_CALL) & 1) ? (int)MV_CALL : (((mask >> MV_CHECK) & 1) ? (int)MV_CHECK : (int)MV_ALL_IN);
+}
 // Synthetic agents (RandomAgent semantics of pokerl/agents/random.py:12-16 under the RNG spec).
 __device__ __forceinline__ int pick_action(const Hot &S, ActionRng &rng, uint32_t table_id, uint64_t step_serial, uint32_t mask, int policy) {
     if (policy == PK_POLICY_ALLIN) return MV_ALL_IN;
+    if (policy == PK_POLICY_CALL) return call_action(mask);
     return action_from_draw(rng.draw16(S, table_id, step_serial), mask);
 }
+// policy nibble of seat p in a per-seat policy word (PokerGameEnv's agents list, envs/game_env.py:13-18)
+__device__ __forceinline__ int seat_policy(uint64_t seatpol, int p) { return (int)((seatpol >> (4 * p)) & 15); }
 
 template <int N>
 struct Table {

@@ -193,7 +193,8 @@ __device__ __forceinline__ void rollout_body(const State *__restrict__ Sp, const
             if (go) {
                 uint32_t mask = tb.valid_mask(high_bet);
                 tb.begin_step(H, policy == PK_POLICY_ALLIN ? (int)MV_ALL_IN
-                                                           : action_from_draw_lds(lds, ActionRing::half_of(word, tb.step_serial), mask), high_bet);
+                               : policy == PK_POLICY_CALL ? call_action(mask)
+                                                          : action_from_draw_lds(lds, ActionRing::half_of(word, tb.step_serial), mask), high_bet);
             }
             PK_PROF(tb.prof.lap(PF_ACTION);)
             tb.scan_first();      // every lane in LS_SCAN: the steps just begun and the ones end_block carried into a new hand
@@ -236,6 +237,10 @@ template <int N>
 __global__ void __launch_bounds__(PK_TABLE_BLOCK, 2) PK_ROLLOUT_ATTR k_rollout_allin(const State *__restrict__ Sp, Hot H, int K, int auto_reset, int park, int slack, int clear_terr) {
     rollout_body<N, true, PK_POLICY_ALLIN>(Sp, H, K, auto_reset, park, slack, clear_terr);
 }
+template <int N>
+__global__ void __launch_bounds__(PK_TABLE_BLOCK, 2) PK_ROLLOUT_ATTR k_rollout_call(const State *__restrict__ Sp, Hot H, int K, int auto_reset, int park, int slack, int clear_terr) {
+    rollout_body<N, true, PK_POLICY_CALL>(Sp, H, K, auto_reset, park, slack, clear_terr);
+}
 // ... the same capped at 168 registers for three waves per SIMD.  Up to six seats k_rollout is below the cap anyway
 // (three resident waves are what give 49 G at 1 M x 6); the cap pays at seven seats (175 -> 168 without a spill: 44.3 vs
 // 40.3 G at 1 M x 7) and at eight (39.5 vs 36.8 G at 1 M x 8), and costs 10..35 % at nine and ten seats, where it spills
@@ -260,7 +265,7 @@ __global__ void __launch_bounds__(PK_TABLE_BLOCK, PK_OCC_CAP) k_rollout_occ3_all
 // PokerGameEnv.reset: Game.reset() (:23), then opponents play until seat 0 is to act (:24-26); a game that ends before
 // seat 0 ever acts is reset again (:27).
 template <int N>
-__global__ void __launch_bounds__(PK_TABLE_BLOCK) k_env_reset(const State *__restrict__ Sp, Hot H, const uint8_t *mask, int opp_policy, int park) {
+__global__ void __launch_bounds__(PK_TABLE_BLOCK) k_env_reset(const State *__restrict__ Sp, Hot H, const uint8_t *mask, uint64_t seatpol, int park) {
     const State &S = *Sp;
     __shared__ Lds<N> lds;
     const int t = blockIdx.x * H.tpb + threadIdx.x;
@@ -286,7 +291,7 @@ __global__ void __launch_bounds__(PK_TABLE_BLOCK) k_env_reset(const State *__res
             more = tb.active != 0;                                                 // :24
             if (more) {
                 uint32_t vm = tb.valid_mask(high_bet);
-                tb.begin_step(H, pick_action(H, rng, table_id, tb.step_serial, vm, opp_policy), high_bet);  // :25-26
+                tb.begin_step(H, pick_action(H, rng, table_id, tb.step_serial, vm, seat_policy(seatpol, tb.active)), high_bet);  // :25-26
             }
         }
         tb.cursor();
@@ -321,8 +326,15 @@ __global__ void __launch_bounds__(PK_TABLE_BLOCK) k_env_reset(const State *__res
 // their outputs and ready[t] = 1.  One env.step of a whole batch lasts as long as its slowest table (a seat 0 that
 // busts during an opponent's step waits for the end of the game, game_env.py:49-52); a learner that acts on the ready
 // tables only never waits for those.  Per table the sequence of steps, outputs and RNG draws is the synchronous one.
-template <int N, bool ASYNC>
-__device__ __forceinline__ void env_step_body(const State *__restrict__ Sp, const Hot &H, const int32_t *actions, int seat0_policy, int opp_policy, int auto_reset, double *reward, uint8_t *done_out, uint8_t *hand_out, uint8_t *terr, double *obs, int park, uint8_t *ready, int max_passes) {
+//
+// MULTI (pk_env_step_multi_d): one agent PER SEAT (PokerGameEnv's `agents` list, game_env.py:13-18): seat p plays the
+// in-kernel policy in nibble p of `seatpol`, or -- PK_POLICY_EXTERNAL -- is played by the CALLER: when such a seat is
+// to act inside a PokerGameEnv.step / .reset, the table YIELDS (ready[t] = 2, who[t] = the seat, obs row = that seat's
+// StateView), its env call stays in flight exactly like a step that ran out of passes, and the next launch takes
+// actions[t] as that seat's action.  reset_req[t] != 0 starts PokerGameEnv.reset() on that table instead of a step.
+template <int N, bool ASYNC, bool MULTI>
+__device__ __forceinline__ void env_step_body(const State *__restrict__ Sp, const Hot &H, const int32_t *actions, int seat0_policy, uint64_t seatpol, int auto_reset, double *reward, uint8_t *done_out, uint8_t *hand_out, uint8_t *terr, double *obs, int park, uint8_t *ready, int max_passes, const uint8_t *reset_req, uint8_t *who_out, int abandon) {
+    static_assert(ASYNC || !MULTI, "yielding to the caller needs the in-flight context of the asynchronous form");
     const State &S = *Sp;
     __shared__ Lds<N> lds;
     const int t = blockIdx.x * H.tpb + threadIdx.x;
@@ -332,16 +344,22 @@ __device__ __forceinline__ void env_step_body(const State *__restrict__ Sp, cons
     if (live) tb.load(S, t); else tb.blank();
     uint64_t ctx = 0;                                          // != 0: a PokerGameEnv.step of this table is in flight
     if (ASYNC && live) ctx = S.env_ctx[t];
+    const bool want_reset = MULTI && live && reset_req && reset_req[t];
+    if (want_reset) { ctx = 0; tb.idle(); }                    // PokerGameEnv.reset(): whatever was in flight is dropped
     const bool carried = ctx != 0;
+    bool yielded = MULTI && carried && ((ctx >> 6) & 1);       // waiting for the caller's action for seat tb.active
     ActionRing ring;
     stage_nth(lds);
     double high_bet;
     const uint32_t vm0 = tb.valid_mask(high_bet);
-    // seat 0's action: supplied (checked here, game.py:648-651) or drawn in the loop like the opponents' (always valid)
-    const int action = (!live || carried || !actions) ? -1 : actions[t];
-    const bool ok = carried || (live && (!actions || (action >= 0 && action < PK_NUM_MOVES && ((vm0 >> action) & 1))));
+    // the action this call supplies: seat 0's for a new PokerGameEnv.step (checked here, game.py:648-651), or the
+    // yielded seat's; ignored for a step that is simply still in flight
+    const int action = (!live || !actions || want_reset || (carried && !yielded)) ? -1 : actions[t];
+    const bool action_ok = action >= 0 && action < PK_NUM_MOVES && ((vm0 >> action) & 1);
+    const bool skip = MULTI && live && !carried && !want_reset && action == PK_ACTION_SKIP;   // an idle table the caller leaves alone
+    const bool ok = carried || want_reset || (live && !skip && (seat0_policy >= 0 || action_ok));
     enum { PH_SEAT0 = 0, PH_HAND = 1, PH_TURN = 2, PH_RESET = 3, PH_RESET_PLAY = 4, PH_END = 5 };
-    int phase = ok ? PH_SEAT0 : PH_END;
+    int phase = ok ? (want_reset ? PH_RESET : PH_SEAT0) : PH_END;
     double rew = 0.0;                                                              // :34
     bool done = false, hand = false;
     uint32_t terr_step = 0;
@@ -352,6 +370,9 @@ __device__ __forceinline__ void env_step_body(const State *__restrict__ Sp, cons
         rew = S.env_rew[t];
         tb.hands_this_step = (int)S.mid[t];
     }
+    bool have_ext = MULTI && yielded && action_ok;             // the yielded seat's action has arrived and is valid
+    const bool ext_invalid = MULTI && yielded && !action_ok;   // ... is invalid: the table is untouched and keeps waiting
+    yielded = yielded && !have_ext;
     int passes = 0;
     const uint32_t caps = PK_TERR_HAND_CAP | PK_TERR_ENV_CAP;
     auto step_finished = [&]() {   // PokerGameEnv.step has returned: its outputs are final; maybe reset the episode
@@ -394,7 +415,8 @@ __device__ __forceinline__ void env_step_body(const State *__restrict__ Sp, cons
 #ifndef PK_ENV_PASSES
 #define PK_ENV_PASSES 4   // betting passes between two looks at the parked lanes, as in k_rollout
 #endif
-    const bool draws = seat0_policy == PK_POLICY_RANDOM || opp_policy == PK_POLICY_RANDOM;   // wave-uniform
+    bool draws = seat0_policy == PK_POLICY_RANDOM;                                 // wave-uniform: some agent draws from the ring
+    PK_FOR(p, N) if (p > 0) draws = draws || seat_policy(seatpol, p) == PK_POLICY_RANDOM; PK_END
     for (;;) {
         // ASYNC, pass budget used up: no lane begins another Game.step; the hands that are ending are still brought to
         // their end (a lane parked at end_hand would otherwise wait for 'park' neighbours launch after launch)
@@ -404,24 +426,29 @@ __device__ __forceinline__ void env_step_body(const State *__restrict__ Sp, cons
             phase = tb.active != 0 ? PH_RESET_PLAY : PH_END;                       // :24
         }
         if (draws) __builtin_amdgcn_s_waitcnt(0);   // as in k_rollout: no stray full wait behind the passes' LDS reads
-        if (draws) ring.ensure(lds, H, table_id, tb.step_serial, live && phase != PH_END, PK_ENV_PASSES);
+        if (draws) ring.ensure(lds, H, table_id, tb.step_serial, live && phase != PH_END && !yielded, PK_ENV_PASSES);
 #pragma unroll
         for (int pass = 0; pass < PK_ENV_PASSES; ++pass) {
             const bool open = !(ASYNC && max_passes > 0 && passes + pass >= max_passes);
             const uint32_t word = draws ? ActionRing::peek(lds, tb.step_serial) : 0u;
-            if (open && phase != PH_END && phase != PH_RESET && tb.lstate == LS_DONE) {   // begin this lane's next Game.step()
+            if (open && phase != PH_END && phase != PH_RESET && tb.lstate == LS_DONE && !yielded) {   // begin this lane's next Game.step()
                 const uint32_t vm = tb.valid_mask(high_bet);
-                const int pol = phase == PH_SEAT0 ? seat0_policy : opp_policy;
-                const int a = (phase == PH_SEAT0 && actions) ? action
+                // self.agents[active_player] (:25, :43, :51); seat 0's own step (:35) takes the caller's action when supplied
+                const int pol = phase == PH_SEAT0 ? seat0_policy : seat_policy(seatpol, tb.active);
+                const bool supplied = (phase == PH_SEAT0 && pol < 0) || (MULTI && phase != PH_SEAT0 && pol == PK_POLICY_EXTERNAL);
+                const bool begin = !supplied || phase == PH_SEAT0 || have_ext;     // an external seat without an action: yield
+                const int a = supplied ? action
                             : pol == PK_POLICY_ALLIN ? (int)MV_ALL_IN
-                                                     : action_from_draw_lds(lds, ActionRing::half_of(word, tb.step_serial), vm);
-                tb.begin_step(H, a, high_bet);                                     // :35 / :43-44 / :51-52 / :25-26
+                            : pol == PK_POLICY_CALL ? call_action(vm)
+                                                    : action_from_draw_lds(lds, ActionRing::half_of(word, tb.step_serial), vm);
+                if (MULTI && supplied && phase != PH_SEAT0) { yielded = !have_ext; have_ext = false; }
+                if (begin) tb.begin_step(H, a, high_bet);                          // :35 / :43-44 / :51-52 / :25-26
             }
             tb.cursor();
             retire();
         }
         const int parked = __popcll(__ballot(tb.parked()));
-        const int runnable = draining ? 0 : __popcll(__ballot(phase != PH_END && tb.lstate == LS_DONE));
+        const int runnable = draining ? 0 : __popcll(__ballot(phase != PH_END && tb.lstate == LS_DONE && !yielded));
         if (parked == 0 && runnable == 0) break;                                   // draining: the rest stays in flight
         passes += PK_ENV_PASSES;
         if (parked >= park || runnable == 0) {
@@ -430,26 +457,41 @@ __device__ __forceinline__ void env_step_body(const State *__restrict__ Sp, cons
         }
     }
     if (!live) return;
+    if (MULTI && skip) {                                       // nothing ran, nothing is written but the two status bytes
+        if (ready) ready[t] = 3;
+        if (who_out) who_out[t] = (uint8_t)tb.active;
+        return;
+    }
     if (ok) {
         tb.store(S, t);
         tb.store_show(S.show, S.T, t, lds);
     }
     const uint32_t vmask = tb.valid_mask(high_bet);
+    const bool returned = !ASYNC || phase == PH_END;
     if (ASYNC) {
-        const bool returned = phase == PH_END;
-        S.env_ctx[t] = returned ? 0ull
-                                : (1ull | ((uint64_t)phase << 1) | ((uint64_t)done << 4) | ((uint64_t)hand << 5) | ((uint64_t)(terr_step & 0xff) << 8) |
-                                   ((uint64_t)(budget + 1) << 16) | ((uint64_t)(budget_reset + 1) << 32));
-        S.mid[t] = returned ? 0u : (uint32_t)tb.hands_this_step;
+        // pk_env_end_multi_d: after a drain only yielded tables (between two Game.steps) are still in flight; their env
+        // call is abandoned and the table is an ordinary idle table again
+        const bool keep = !returned && !(MULTI && abandon);
+        S.env_ctx[t] = keep ? (1ull | ((uint64_t)phase << 1) | ((uint64_t)done << 4) | ((uint64_t)hand << 5) | ((uint64_t)(yielded ? 1 : 0) << 6) |
+                               ((uint64_t)(terr_step & 0xff) << 8) | ((uint64_t)(budget + 1) << 16) | ((uint64_t)(budget_reset + 1) << 32))
+                            : 0ull;
+        S.mid[t] = keep ? (uint32_t)tb.hands_this_step : 0u;
         S.valid[t] = (uint8_t)vmask;
-        ready[t] = returned;
-        if (!returned) { S.env_rew[t] = rew; return; }
+        if (ready) ready[t] = returned ? 1 : ((MULTI && yielded) ? 2 : 0);
+        if (MULTI && who_out) who_out[t] = (uint8_t)tb.active;
+        if (!returned) {
+            S.env_rew[t] = rew;
+            if (!(MULTI && yielded) || !terr) return;
+            terr[t] = ext_invalid ? (uint8_t)PK_TERR_INVALID_ACTION : (uint8_t)0;   // the yielded seat's action was refused / is awaited
+        }
     }
-    const uint32_t te = ok ? (terr_step | tb.terr) : (uint32_t)PK_TERR_INVALID_ACTION;
-    reward[t] = ok ? rew : 0.0; done_out[t] = ok && done; hand_out[t] = ok && hand;  // :53
-    if (ok) S.valid[t] = (uint8_t)vmask;
-    S.terr[t] = (uint8_t)te; terr[t] = (uint8_t)te;
-    if (obs) {  // Game.StateView(active player), game.py:117-131, from registers (same row k_obs builds from HBM)
+    if (returned) {
+        const uint32_t te = ok ? (terr_step | tb.terr) : (uint32_t)PK_TERR_INVALID_ACTION;
+        reward[t] = ok ? rew : 0.0; done_out[t] = ok && done; hand_out[t] = ok && hand;  // :53
+        if (ok) S.valid[t] = (uint8_t)vmask;
+        S.terr[t] = (uint8_t)te; terr[t] = (uint8_t)te;
+    }
+    if (obs) {  // Game.StateView(player to act), game.py:117-131, from registers (same row k_obs builds from HBM)
         double *o = obs + (size_t)t * PK_OBS_DIM(N);
         const int who = tb.active;
         o[0] = who; o[1] = tb.turn; o[2] = tb.min_raise;
@@ -462,12 +504,16 @@ __device__ __forceinline__ void env_step_body(const State *__restrict__ Sp, cons
     }
 }
 template <int N>
-__global__ void __launch_bounds__(PK_TABLE_BLOCK) k_env_step(const State *__restrict__ Sp, Hot H, const int32_t *actions, int seat0_policy, int opp_policy, int auto_reset, double *reward, uint8_t *done_out, uint8_t *hand_out, uint8_t *terr, double *obs, int park) {
-    env_step_body<N, false>(Sp, H, actions, seat0_policy, opp_policy, auto_reset, reward, done_out, hand_out, terr, obs, park, nullptr, 0);
+__global__ void __launch_bounds__(PK_TABLE_BLOCK) k_env_step(const State *__restrict__ Sp, Hot H, const int32_t *actions, int seat0_policy, uint64_t seatpol, int auto_reset, double *reward, uint8_t *done_out, uint8_t *hand_out, uint8_t *terr, double *obs, int park) {
+    env_step_body<N, false, false>(Sp, H, actions, seat0_policy, seatpol, auto_reset, reward, done_out, hand_out, terr, obs, park, nullptr, 0, nullptr, nullptr, 0);
 }
 template <int N>
-__global__ void __launch_bounds__(PK_TABLE_BLOCK, (N <= 6 ? 3 : 2)) k_env_step_async(const State *__restrict__ Sp, Hot H, const int32_t *actions, int seat0_policy, int opp_policy, int auto_reset, double *reward, uint8_t *done_out, uint8_t *hand_out, uint8_t *terr, double *obs, int park, uint8_t *ready, int max_passes) {
-    env_step_body<N, true>(Sp, H, actions, seat0_policy, opp_policy, auto_reset, reward, done_out, hand_out, terr, obs, park, ready, max_passes);
+__global__ void __launch_bounds__(PK_TABLE_BLOCK, (N <= 6 ? 3 : 2)) k_env_step_async(const State *__restrict__ Sp, Hot H, const int32_t *actions, int seat0_policy, uint64_t seatpol, int auto_reset, double *reward, uint8_t *done_out, uint8_t *hand_out, uint8_t *terr, double *obs, int park, uint8_t *ready, int max_passes) {
+    env_step_body<N, true, false>(Sp, H, actions, seat0_policy, seatpol, auto_reset, reward, done_out, hand_out, terr, obs, park, ready, max_passes, nullptr, nullptr, 0);
+}
+template <int N>
+__global__ void __launch_bounds__(PK_TABLE_BLOCK, 2) k_env_step_multi(const State *__restrict__ Sp, Hot H, const int32_t *actions, int seat0_policy, uint64_t seatpol, int auto_reset, double *reward, uint8_t *done_out, uint8_t *hand_out, uint8_t *terr, double *obs, int park, uint8_t *ready, int max_passes, const uint8_t *reset_req, uint8_t *who_out, int abandon) {
+    env_step_body<N, true, true>(Sp, H, actions, seat0_policy, seatpol, auto_reset, reward, done_out, hand_out, terr, obs, park, ready, max_passes, reset_req, who_out, abandon);
 }
 
 // ---- exports: device-side conversion from the SoA/bitmask layout to the reference's table-major arrays

@@ -101,3 +101,4 @@ class Policy(enum.IntEnum):
     """In-kernel synthetic agents (include/pokerl_hip.h PK_POLICY_*)."""
     RANDOM = 0   # uniform over the valid actions, the reference's RandomAgent (agents/random.py:12-16)
     ALL_IN = 1   # always PokerMoves.ALL_IN
+    CALL = 2     # CALL if valid, else CHECK if valid, else ALL_IN

@@ -12,19 +12,53 @@ from .game import VecGame
 
 class VecPokerGameEnv:
     def __init__(self, agents=Policy.RANDOM, num_tables=1, **game_config):
+        """`PokerGameEnv(agents, **game_config)` (game_env.py:13-18) for num_tables tables.  agents: the reference's list
+        with one agent per OPPONENT seat (seat 1 first) -- in-kernel agents (pokerl_amd.agents.RandomAgent / AllInAgent /
+        CallAgent or a Policy value) and / or host callables, see pokerl_amd/agents.py -- or, as a shorthand, ONE Policy
+        that every opponent plays."""
         self.game = VecGame(num_tables, **game_config)  # game_env.py:16
-        self.opp_policy = int(agents)
         self.player_agent = 0                           # game_env.py:18
+        self.set_agents(agents)
+
+    def set_agents(self, agents):
+        from .agents import kernel_policy
+        n = self.game.num_players
+        if isinstance(agents, (list, tuple)):
+            if len(agents) != n - 1:
+                raise ValueError('agents: one per opponent seat, %d expected' % (n - 1))
+            agents = list(agents)
+        else:
+            agents = [Policy(int(agents))] * (n - 1)
+        self.agents = [None, *agents]                   # game_env.py:17
+        pols = [kernel_policy(a) for a in agents]
+        self._external = [p + 1 for p, pol in enumerate(pols) if pol is None]
+        for p in self._external:
+            if not callable(self.agents[p]):
+                raise TypeError('agent of seat %d is neither an in-kernel agent / Policy nor callable' % p)
+        # seat 0 is the caller's (PK_POLICY_EXTERNAL = 15); an opponent is its in-kernel policy or external as well
+        self.seat_policies = 15 | sum((15 if pol is None else pol) << (4 * (p + 1)) for p, pol in enumerate(pols))
+        uniform = not self._external and len(set(pols)) == 1
+        self._opp_policy = pols[0] if uniform else None  # one policy for every opponent: the single-launch entry points
+
+    @property
+    def opp_policy(self):
+        """The one in-kernel policy every opponent plays, or None (per-seat agents: the pk_env_step_multi_d path)."""
+        return self._opp_policy
+
+    @opp_policy.setter
+    def opp_policy(self, agents):
+        self.set_agents(agents)
 
     @property
     def num_tables(self):
         return self.game.num_tables
 
     def close(self):
-        """Frees the device buffers of step_async and the game's handle."""
-        for b in getattr(self, '_async_buf', {}).values():
-            b.free()
-        self._async_buf = {}
+        """Frees the device buffers of step_async / the multi-agent path and the game's handle."""
+        for name in ('_async_buf', '_multi_buf'):
+            for b in (getattr(self, name, None) or {}).values():
+                b.free()
+            setattr(self, name, {})
         self.game.close()
 
     def __del__(self):
@@ -33,13 +67,68 @@ class VecPokerGameEnv:
         except Exception:
             pass
 
+    # ------------------------------------------------------------------ per-seat agents (pk_env_step_multi_d)
+    def _call_agent(self, agent, rows, tables):
+        if getattr(agent, 'batched', False):
+            return np.asarray(agent(rows, tables), np.int32)
+        from .state_view import StateView
+        n = self.game.num_players
+        return np.array([int(agent(StateView(row, n))) for row in rows], np.int32)   # agent(state), agents/agent.py:11-13
+
+    def _multi_run(self, actions=None, reset_mask=None):
+        """One PokerGameEnv.step (or .reset where reset_mask != 0) on every table with one agent per seat: launches run
+        until every table has returned or waits for a host agent; the host agents are called for the tables that wait
+        for them, and so on until every table has returned.  Returns (reward, done, hand, terr)."""
+        from .hipmem import DeviceBuffer
+        g = self.game
+        T, D, lib, h = g.num_tables, 17 + 3 * g.num_players, g._lib, g._h
+        if not getattr(self, '_multi_buf', None):
+            dev = g.device
+            self._multi_buf = dict(act=DeviceBuffer(T * 4, dev), reset=DeviceBuffer(T, dev), rew=DeviceBuffer(T * 8, dev),
+                                   done=DeviceBuffer(T, dev), hand=DeviceBuffer(T, dev), terr=DeviceBuffer(T, dev),
+                                   obs=DeviceBuffer(T * D * 8, dev), who=DeviceBuffer(T, dev), ready=DeviceBuffer(T, dev))
+        b = self._multi_buf
+        acts = np.full(T, L.ACTION_SKIP, np.int32) if actions is None else actions
+        if reset_mask is not None:
+            b['reset'].upload(np.ascontiguousarray(reset_mask, np.uint8))
+        reset_ptr = b['reset'].ptr if reset_mask is not None else None
+        try:
+            while True:
+                b['act'].upload(acts)
+                L.check(lib.pk_env_step_multi_d(h, b['act'].ptr, reset_ptr, self.seat_policies, 0, 0, b['rew'].ptr, b['done'].ptr,
+                                                b['hand'].ptr, b['terr'].ptr, b['obs'].ptr, b['who'].ptr, b['ready'].ptr), h)
+                g.sync()
+                ready = b['ready'].download(np.uint8, T)
+                waiting = ready == 2
+                if not waiting.any():
+                    break
+                who = b['who'].download(np.uint8, T)
+                bad = waiting & (b['terr'].download(np.uint8, T) != 0)
+                if bad.any():      # a host agent returned an action Game.step refuses (game.py:649-651)
+                    t = int(np.argmax(bad))
+                    raise ValueError('Player %d invalid move: `%d` (table %d)' % (int(who[t]), int(acts[t]), t))
+                obs = b['obs'].download(np.float64, T * D).reshape(T, D)
+                acts = np.full(T, L.ACTION_SKIP, np.int32)      # tables that have returned are left alone
+                for seat in self._external:
+                    idx = np.nonzero(waiting & (who == seat))[0]
+                    if len(idx):
+                        acts[idx] = self._call_agent(self.agents[seat], obs[idx], idx)
+                reset_ptr = None
+        finally:
+            L.check(lib.pk_env_end_multi_d(h), h)     # nothing is left in flight: getters and the other entry points work again
+        return (b['rew'].download(np.float64, T), b['done'].download(np.uint8, T), b['hand'].download(np.uint8, T),
+                b['terr'].download(np.uint8, T))
+
     def reset(self, mask=None):
         """game_env.py:20-29 on all tables (or where mask != 0); returns the observation rows (StateView fields)."""
         g = self.game
         m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
         if m is not None and m.shape != (g.num_tables,):
             raise ValueError('mask must have shape (num_tables,)')
-        L.check(g._lib.pk_env_reset(g._h, L.ptr(m), self.opp_policy), g._h)
+        if self._opp_policy is None:
+            self._multi_run(reset_mask=np.ones(g.num_tables, np.uint8) if m is None else m)
+        else:
+            L.check(g._lib.pk_env_reset(g._h, L.ptr(m), self._opp_policy), g._h)
         return g.observations
 
     def step(self, actions, strict=True):
@@ -58,17 +147,31 @@ class VecPokerGameEnv:
             if not ok.all():
                 t = int(np.argmin(ok))
                 raise ValueError('Player %d invalid move: `%d` (table %d)' % (int(g.active_player[t]), int(a[t]), t))
-        reward = np.zeros(T, np.float64)
-        done = np.zeros(T, np.uint8)
-        hand = np.zeros(T, np.uint8)
-        terr = np.zeros(T, np.uint8)
-        rc = g._lib.pk_env_step(g._h, L.ptr(a), self.opp_policy, L.ptr(reward), L.ptr(done), L.ptr(hand), L.ptr(terr))
-        L.check(rc, g._h, allow_table_errors=True)
+        if self._opp_policy is None:
+            reward, done, hand, terr = self._multi_run(actions=a)
+        else:
+            reward = np.zeros(T, np.float64)
+            done = np.zeros(T, np.uint8)
+            hand = np.zeros(T, np.uint8)
+            terr = np.zeros(T, np.uint8)
+            rc = g._lib.pk_env_step(g._h, L.ptr(a), self._opp_policy, L.ptr(reward), L.ptr(done), L.ptr(hand), L.ptr(terr))
+            L.check(rc, g._h, allow_table_errors=True)
         if not strict:
             return g.observations, reward, done != 0, hand != 0, terr
         if terr.any():
             raise L.PokerlHipError('table error bits %s' % np.unique(terr))
         return g.observations, reward, done != 0, hand != 0
+
+    def step_multi_d(self, actions_d, reset_d, reward_d, done_d, hand_d, terr_d, obs_d, who_d, ready_d, max_passes=0, auto_reset=True):
+        """pk_env_step_multi_d on DEVICE pointers with this env's per-seat agents (self.seat_policies): tables yield
+        (ready 2, who = seat) where a host agent's seat is to act; see include/pokerl_hip.h.  end_multi() leaves the mode."""
+        g = self.game
+        vp = lambda x: x if x is None or isinstance(x, L.C.c_void_p) else L.C.c_void_p(int(x))
+        L.check(g._lib.pk_env_step_multi_d(g._h, vp(actions_d), vp(reset_d), self.seat_policies, 1 if auto_reset else 0, int(max_passes),
+                                           vp(reward_d), vp(done_d), vp(hand_d), vp(terr_d), vp(obs_d), vp(who_d), vp(ready_d)), g._h)
+
+    def end_multi(self):
+        L.check(self.game._lib.pk_env_end_multi_d(self.game._h), self.game._h)
 
     def step_async_d(self, actions_d, reward_d, done_d, hand_d, terr_d, obs_d, ready_d, max_passes=8, seat0_policy=Policy.RANDOM,
                      auto_reset=True):
@@ -77,7 +180,9 @@ class VecPokerGameEnv:
         the others in flight.  max_passes <= 0 drains.  See include/pokerl_hip.h."""
         g = self.game
         vp = lambda x: x if x is None or isinstance(x, L.C.c_void_p) else L.C.c_void_p(int(x))
-        L.check(g._lib.pk_env_step_async_d(g._h, vp(actions_d), int(seat0_policy), self.opp_policy, 1 if auto_reset else 0,
+        if self._opp_policy is None:
+            raise ValueError('step_async needs ONE in-kernel policy for all opponents; per-seat / host agents: step_multi_d')
+        L.check(g._lib.pk_env_step_async_d(g._h, vp(actions_d), int(seat0_policy), self._opp_policy, 1 if auto_reset else 0,
                                            int(max_passes), vp(reward_d), vp(done_d), vp(hand_d), vp(terr_d), vp(obs_d),
                                            vp(ready_d)), g._h)
 

@@ -199,8 +199,35 @@ def view_record(game):
 
 
 # --------------------------------------------------------------------------- Game trajectories
+class _HandCapProbe:
+    """The cap rule ("Steps that never return", rule (b)): a Game.step that rolls more than `cap` hands
+    is ended by the product right after its (cap+1)-th setup_hand() with PK_TERR_HAND_CAP, although the reference -- on the
+    configuration pinned here -- does return, thousands of hands later.  This probe wraps the reference game's setup_hand
+    (called as self.setup_hand() by end_hand, game.py:539) and snapshots the table right after that call: what the product
+    must hold when it stops."""
+
+    def __init__(self, table, cap):
+        self.t, self.cap, self.calls, self.mid = table, cap, 0, None
+        real = table.game.setup_hand
+
+        def counted():
+            real()
+            self.calls += 1
+            if self.calls == self.cap + 1:
+                t = self.t
+                last = _eval_sink[-t.n:] if _eval_sink else []        # rankings of the last showdown so far (game.py:488-489)
+                for p, (rank, kick) in enumerate(last):
+                    t.srank[p] = rank
+                    t.skick[p] = J.get_kickers_value(kick)
+                self.mid = t.snapshot()
+                self.mid["step_serial"] = t.step_serial + 1          # the product's step returns here (one completed step)
+                self.mid_srank, self.mid_skick = t.srank.copy(), t.skick.copy()
+
+        table.game.setup_hand = counted
+
+
 def game_trajectory(n, policy, seed, tables, steps, table_id_base=0, cfg=None, full=True, digest_every=0,
-                    auto_reset=True, dealer=0, serial_base=(0, 0), views=None):
+                    auto_reset=True, dealer=0, serial_base=(0, 0), views=None, hand_cap=None):
     """auto_reset=False: finished games are NOT reset (the lone survivor keeps being stepped, which the
     reference allows); a survivor's FOLD then trips `assert num_potential_winners > 0` (game.py:473):
     recorded as err=2 with the partially mutated state, after which that table is reset."""
@@ -208,6 +235,8 @@ def game_trajectory(n, policy, seed, tables, steps, table_id_base=0, cfg=None, f
     ts = [Table(seed, table_id_base + i, n, serial_base=serial_base, **cfg) for i in range(tables)]
     for t in ts:
         t.game.reset(dealer=dealer)          # only the FIRST reset takes the dealer; auto-resets use the default (0)
+    probes = [_HandCapProbe(t, hand_cap) for t in ts] if hand_cap else None
+    max_hands_in_step = 0
     init = [t.snapshot() for t in ts]
     out = {}
     meta = dict(kind="game", n=n, policy=policy, seed=seed, tables=tables, steps=steps,
@@ -222,12 +251,23 @@ def game_trajectory(n, policy, seed, tables, steps, table_id_base=0, cfg=None, f
         for i, t in enumerate(ts):
             a = t.pick(policy)
             actions[s, i] = a
+            if probes:
+                probes[i].calls, probes[i].mid = 0, None
             try:
                 over, hand, turn = t.game.step(int(a))
                 flags[s, i] = int(bool(over)) | int(bool(hand)) << 1 | int(bool(turn)) << 2
             except AssertionError:
                 assert not auto_reset
                 errs[s, i] = 2
+            if probes and probes[i].mid is not None:
+                # the reference returned after probes[i].calls hands; the pinned rule stops the step after hand_cap + 1 of them:
+                # record the table as it was THERE and rewind the harness' deck stream to it (the reset below deals from there)
+                max_hands_in_step = max(max_hands_in_step, probes[i].calls)
+                errs[s, i], flags[s, i] = 4, 0
+                t.hand_serial = int(probes[i].mid["hand_serial"])
+                t.srank, t.skick = probes[i].mid_srank, probes[i].mid_skick
+                row.append(probes[i].mid)
+                continue
             row.append(t.snapshot())
         if views is not None:
             views.append([view_record(t.game) for t in ts])
@@ -254,21 +294,31 @@ def game_trajectory(n, policy, seed, tables, steps, table_id_base=0, cfg=None, f
     if digest_every:
         meta["digest_every"] = digest_every
         meta["digests"] = digests
+    if hand_cap:
+        meta["hand_cap"] = hand_cap
+        meta["reference_hands_in_its_longest_step"] = max_hands_in_step
     out["meta"] = np.array(json.dumps(meta))
     return out
 
 
 # --------------------------------------------------------------------------- PokerGameEnv trajectories
 def env_trajectory(n, policy, opp_policy, seed, tables, steps, table_id_base=0, cfg=None):
+    """opp_policy: one rng_spec policy for every opponent, or a list with one per opponent seat (seat 1 first) -- the
+    reference's own `agents` list (envs/game_env.py:13-18) then holds a different callable per seat."""
     cfg = cfg or dict(start_credits=100, big_blind=2, small_blind=1)
+    per_seat = list(opp_policy) if isinstance(opp_policy, (list, tuple)) else [opp_policy] * (n - 1)
+    assert len(per_seat) == n - 1
     envs, ts = [], []
     for i in range(tables):
         holder = {}
 
-        def agent(state, holder=holder):
-            return holder["t"].pick(opp_policy)
+        def make_agent(pol, holder=holder):
+            def agent(state):
+                assert state.player == holder["t"].game.active_player
+                return holder["t"].pick(pol)
+            return agent
 
-        env = PokerGameEnv([agent] * (n - 1), num_players=n, **cfg)
+        env = PokerGameEnv([make_agent(pol) for pol in per_seat], num_players=n, **cfg)
         t = Table(seed, table_id_base + i, n, game=env.game)
         holder["t"] = t
         envs.append(env)
@@ -468,6 +518,14 @@ TIE_SETS = {
     "game_n8_argsort_tie": (8, R.POLICY_RANDOM, 349423999861, 4, 100, 0, dict(start_credits=1, big_blind=40, small_blind=2)),
     "game_n9_argsort_tie": (9, R.POLICY_RANDOM, 141532477888, 4, 100, 0, dict(start_credits=10, big_blind=7.5, small_blind=40)),
 }
+# The one configuration of the fuzz (tests/golden/fuzz_oracle_vs_reference.py, round 200 of its generator) on which the
+# reference DOES return from a Game.step that rolls more than PK_HAND_CAP = 4 096 hands (5 204 of them, step 9): the product
+# ends that step after 4 097 hands with PK_TERR_HAND_CAP (errs == 4) -- the documented divergence, pinned here with the
+# reference's own table state at that point (_HandCapProbe) and the reset that follows.
+CAP_SETS = {
+    "game_n6_hand_cap": (6, R.POLICY_RANDOM, 3107974733015276566, 1, 12, 551120854,
+                         dict(start_credits=[37.5, 5, 1, 2, 2, 0.5], big_blind=0.5, small_blind=250), 5),
+}
 NORESET_SETS = {
     "game_n2_noreset": (2, R.POLICY_RANDOM, 11, 6, 150, 0, None),
     "game_n3_noreset": (3, R.POLICY_RANDOM, 12, 6, 200, 0, dict(start_credits=20, big_blind=2, small_blind=1)),
@@ -493,6 +551,12 @@ ENV_SETS = {
     "env_n9_random_hi_base": (9, R.POLICY_RANDOM, R.POLICY_RANDOM, 99, 4, 120, 4000000000, None),
     "env_n3_big_blinds_vs_allin": (3, R.POLICY_RANDOM, R.POLICY_ALLIN, 2026, 6, 120, 0,
                                    dict(start_credits=[10, 40, 100], big_blind=40, small_blind=2)),
+    # round 3: the call agent (rng_spec policy 2) and a DIFFERENT agent per opponent seat, as PokerGameEnv(agents=[...]) takes them
+    "env_n3_vs_call": (3, R.POLICY_RANDOM, R.POLICY_CALL, 31337, 6, 150, 0, None),
+    "env_n4_mixed_opponents": (4, R.POLICY_RANDOM, [R.POLICY_CALL, R.POLICY_RANDOM, R.POLICY_ALLIN], SEED ^ 0x1234, 6, 150, 0, None),
+    "env_n6_mixed_percredits": (6, R.POLICY_RANDOM, [R.POLICY_CALL, R.POLICY_CALL, R.POLICY_ALLIN, R.POLICY_RANDOM, R.POLICY_CALL],
+                                424242, 6, 150, 123456, dict(start_credits=[50, 100, 20, 200, 100, 75], big_blind=4, small_blind=2)),
+    "env_n2_call_vs_call": (2, R.POLICY_CALL, R.POLICY_CALL, 5, 4, 120, 0, dict(start_credits=6, big_blind=2, small_blind=1)),
 }
 
 
@@ -544,6 +608,14 @@ def main():
             out["meta"] = np.array(json.dumps(meta))
             np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
             print(name, "resets:", len(out["reset_idx"]), "reversed tie rule differs from step", rev, "| un-injected numpy from step", native)
+    for name, (n, pol, seed, tables, steps, base, cfg, dealer) in CAP_SETS.items():
+        if want(name):
+            out = game_trajectory(n, pol, seed, tables, steps, base, cfg, dealer=dealer, hand_cap=4096)
+            meta = json.loads(str(out["meta"]))
+            assert (out["errs"] == 4).sum() == 1 and meta["reference_hands_in_its_longest_step"] > 4097, meta
+            np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+            print(name, "capped steps:", int((out["errs"] == 4).sum()), "at", np.argwhere(out["errs"] == 4).tolist(),
+                  "reference rolled", meta["reference_hands_in_its_longest_step"], "hands there")
     for name, (n, pol, seed, tables, steps, base, cfg, sbase) in SERIAL_SETS.items():
         if want(name):
             out = game_trajectory(n, pol, seed, tables, steps, base, cfg, serial_base=sbase)

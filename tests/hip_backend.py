@@ -46,6 +46,9 @@ class HipBackend:
         done = np.zeros(self.T, np.uint8)
         hand = np.zeros(self.T, np.uint8)
         terr = np.zeros(self.T, np.uint8)
+        if isinstance(opp_policy, (list, tuple)) or self.env.opp_policy is None:   # one agent per seat: the multi-agent entry point
+            out = self.env.step(a, strict=False)
+            return out[1], out[2].astype(np.uint8), out[3].astype(np.uint8), out[4]
         rc = g._lib.pk_env_step(g._h, L.ptr(a), opp_policy, L.ptr(reward), L.ptr(done), L.ptr(hand), L.ptr(terr))
         L.check(rc, g._h, allow_table_errors=True)
         return reward, done, hand, terr

@@ -1,0 +1,272 @@
+"""GPU tests of PokerGameEnv with ONE AGENT PER SEAT (reference pokerl/envs/game_env.py:13-18: a list of agent callables,
+`self.agents[active_player](state)` at :25, :43, :51): in-kernel agents per seat, seats played by the caller
+(pk_env_step_multi_d: tables yield where such a seat is to act), the call agent, and the reference-style constructor.
+Everything bit-exact against the oracle (itself pinned to reference-generated fixtures with mixed agent lists)."""
+import numpy as np
+import pytest
+
+import golden_util as GU
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import loader
+    return loader
+
+
+@pytest.fixture(scope="module")
+def R():
+    from oracle import rng_spec
+    return rng_spec
+
+
+def mask_bits(rows):
+    return (rows[:, 3:10] > 0).astype(np.uint32) @ (1 << np.arange(7, dtype=np.uint32))
+
+
+class SpecAgent:
+    """A HOST agent that plays an rng_spec policy by the book: the action the in-kernel agent of that policy would take for
+    the table's current step serial and valid mask.  Batched: gets the observation rows of all the tables that wait for it."""
+    batched = True
+
+    def __init__(self, R, env_ref, policy, seed, base=0):
+        self.R, self.env_ref, self.policy, self.seed, self.base, self.calls = R, env_ref, policy, seed, base, 0
+
+    def __call__(self, rows, tables):
+        self.calls += 1
+        serial = self.env_ref[0].game.step_serial          # readable while env calls are in flight (pk_get_serials)
+        bits = mask_bits(rows)
+        return np.array([self.R.pick_action(self.seed, self.base + int(t), int(serial[t]), int(b), self.policy)
+                         for t, b in zip(tables, bits)], np.int32)
+
+
+def test_reference_style_constructor_and_in_kernel_agent_lists(O):
+    """VecPokerGameEnv(agents=[...]) takes the reference's list form: one agent per opponent seat.  In-kernel agents per
+    seat (RandomAgent / CallAgent / AllInAgent markers or Policy values) against the oracle with the same list."""
+    import pokerl_amd
+    from pokerl_amd import AllInAgent, CallAgent, Policy, RandomAgent
+    with pytest.raises(ValueError):
+        pokerl_amd.VecPokerGameEnv([RandomAgent()] * 2, num_tables=4, num_players=4)       # three opponents expected
+    with pytest.raises(TypeError):
+        pokerl_amd.VecPokerGameEnv([RandomAgent(), "nope", RandomAgent()], num_tables=4, num_players=4)
+    for T, N, agents, pols in [(2048, 4, [RandomAgent()] * 3, [0, 0, 0]),                          # the reference's examples
+                               (1000, 4, [CallAgent(), RandomAgent(), AllInAgent()], [2, 0, 1]),
+                               (700, 6, [Policy.CALL, Policy.RANDOM, CallAgent(), Policy.ALL_IN, RandomAgent()], [2, 0, 2, 1, 0]),
+                               (512, 2, [CallAgent()], [2])]:
+        env = pokerl_amd.VecPokerGameEnv(agents, num_tables=T, num_players=N, seed=2024)
+        assert env.agents[0] is None and len(env.agents) == N and env.player_agent == 0   # game_env.py:17-18
+        o = O.OracleGame(T, N, seed=2024)
+        obs = env.reset(); o.env_reset(None, pols)
+        assert GU.bits_equal(o.f64(0), env.game.credits) and (obs[:, 0] == 0).all()
+        for s in range(40):
+            a = o.pick_actions(0)
+            ro, do, ho, eo = o.env_step(a, pols)
+            obs, r, d, h, e = env.step(a, strict=False)
+            assert GU.bits_equal(ro, r) and np.array_equal(do != 0, d) and np.array_equal(ho != 0, h) and np.array_equal(eo, e), (N, s)
+            m = (do != 0).astype(np.uint8)
+            if m.any():
+                o.env_reset(m, pols); env.reset(m)
+        snap_o = o.snapshot()
+        g = env.game
+        for k, got in (("credits", g.credits), ("payoffs", g.payoffs), ("cards", g.deck), ("states", g.player_states),
+                       ("step_serial", g.step_serial), ("hand_serial", g.hand_serial)):
+            assert GU.bits_equal(snap_o[k], got), (N, k)
+        env.close()
+
+
+def test_host_agents_reproduce_the_in_kernel_agents(O, R):
+    """Seats played by the CALLER: whenever such a seat is to act the table yields, the host agent is called with that
+    seat's StateView rows and its action goes back.  Host agents that apply an in-kernel policy's rule must reproduce that
+    policy's trajectory bit for bit -- every opponent external; a mix of external and in-kernel seats; per-table
+    (non-batched) reference-style callables that get a StateView."""
+    import pokerl_amd
+    from pokerl_amd import AllInAgent, CallAgent, RandomAgent
+    seed = 777
+
+    def call_rule(state):                 # a plain reference-style agent: agent(state: StateView) -> int (agents/agent.py:11-13)
+        assert state.player != 0 and len(state.player_cards) == 2
+        return 2 if state.valid_actions[2] else (1 if state.valid_actions[1] else 6)
+
+    for T, N, pols, external in [(1024, 4, [0, 2, 1], [1, 2, 3]), (600, 6, [0, 2, 0, 1, 2], [1, 4]), (300, 3, [2, 2], [1]),
+                                 (2048 + 5, 5, [0, 0, 0, 0], [2, 3])]:
+        ref = []
+        agents = []
+        for seat, pol in enumerate(pols, start=1):
+            if seat in external:
+                agents.append(call_rule if (pol == 2 and N == 3) else SpecAgent(R, ref, pol, seed))
+            else:
+                agents.append([RandomAgent(), AllInAgent(), CallAgent()][pol])
+        env = pokerl_amd.VecPokerGameEnv(agents, num_tables=T, num_players=N, seed=seed)
+        ref.append(env)
+        assert sorted(env._external) == external
+        o = O.OracleGame(T, N, seed=seed)
+        env.reset(); o.env_reset(None, pols)
+        assert GU.bits_equal(o.f64(0), env.game.credits)
+        for s in range(25):
+            a = o.pick_actions(0)
+            ro, do, ho, eo = o.env_step(a, pols)
+            obs, r, d, h, e = env.step(a, strict=False)
+            assert GU.bits_equal(ro, r) and np.array_equal(do != 0, d) and np.array_equal(ho != 0, h) and np.array_equal(eo, e), (N, s)
+            m = (do != 0).astype(np.uint8)
+            if m.any():
+                o.env_reset(m, pols); env.reset(m)
+        snap_o = o.snapshot()
+        g = env.game
+        for k, got in (("credits", g.credits), ("payoffs", g.payoffs), ("bets", g.bets), ("cards", g.deck),
+                       ("states", g.player_states), ("step_serial", g.step_serial), ("hand_serial", g.hand_serial)):
+            assert GU.bits_equal(snap_o[k], got), (N, k)
+        assert all(a.calls > 0 for a in agents if isinstance(a, SpecAgent))
+        env.close()
+
+
+def test_host_agent_errors_and_busy_contract():
+    """An invalid action from a host agent is refused like Game.step refuses it (game.py:649-651): ValueError, the table
+    untouched and nothing left in flight; while tables wait for a host agent the other entry points are busy."""
+    import pokerl_amd
+    from pokerl_amd import _lib as L
+    from pokerl_amd.hipmem import DeviceBuffer
+
+    class Bad:
+        batched = True
+
+        def __call__(self, rows, tables):
+            return np.full(len(tables), 1, np.int32)      # CHECK: invalid pre-flop (high_bet != 0)
+
+    T, N = 256, 3
+    env = pokerl_amd.VecPokerGameEnv([Bad(), Bad()], num_tables=T, num_players=N, seed=3)
+    with pytest.raises(ValueError, match="invalid move"):
+        env.reset()
+    g = env.game
+    assert (g.step_serial == 0).all() and (g.hand_serial == 1).all()      # Game.reset() ran, no opponent step did
+    g.credits                                                              # nothing is in flight any more
+    env.close()
+    # raw API: yielded tables keep every other entry point busy until pk_env_end_multi_d
+    T, N = 512, 4
+    env = pokerl_amd.VecPokerGameEnv([Bad(), pokerl_amd.RandomAgent(), Bad()], num_tables=T, num_players=N, seed=3)   # seats 1 and 3 are the caller's
+    g = env.game
+    D = 17 + 3 * N
+    rew, done, hand, terr, obs, who, ready, act, rst = (DeviceBuffer(T * 8), DeviceBuffer(T), DeviceBuffer(T), DeviceBuffer(T),
+                                                        DeviceBuffer(T * D * 8), DeviceBuffer(T), DeviceBuffer(T), DeviceBuffer(T * 4), DeviceBuffer(T))
+
+    def call_rule(rows):
+        v = rows[:, 3:10] > 0
+        return np.where(v[:, 2], 2, np.where(v[:, 1], 1, 6)).astype(np.int32)
+
+    def launch(a, reset=False):
+        act.upload(a)
+        env.step_multi_d(act.ptr, rst.ptr if reset else None, rew.ptr, done.ptr, hand.ptr, terr.ptr, obs.ptr, who.ptr, ready.ptr,
+                         max_passes=0, auto_reset=False)
+        g.sync()
+        return ready.download(np.uint8, T), who.download(np.uint8, T), obs.download(np.float64, T * D).reshape(T, D)
+
+    rst.upload(np.ones(T, np.uint8))
+    r, w, rows = launch(np.full(T, L.ACTION_SKIP, np.int32), reset=True)
+    idle = np.zeros(T, bool)
+    for _ in range(40):           # everybody calls until some tables wait for the caller's opponent seats while others have returned
+        assert set(np.unique(r)) <= {1, 2, 3}
+        idle |= r == 1
+        assert np.array_equal(rows[r != 3, 0].astype(np.uint8), w[r != 3])          # the row is the view of the seat to act
+        assert (w[r == 1] == 0).all() and np.isin(w[r == 2], [1, 3]).all()
+        if (r == 2).any() and idle.sum() > T // 8:
+            break
+        a = np.full(T, L.ACTION_SKIP, np.int32)
+        a[r == 2] = call_rule(rows[r == 2])
+        if not (r == 2).any():    # every table has returned: seat 0 calls on all of them
+            a = call_rule(rows); idle[:] = False
+        r, w, rows = launch(a)
+    waiting = r == 2
+    assert waiting.any() and idle.any() and not (waiting & idle).any()
+    with pytest.raises(L.PokerlHipError):
+        g.credits
+    with pytest.raises(L.PokerlHipError):                                 # the agents may not change while calls are in flight
+        L.check(g._lib.pk_env_step_multi_d(g._h, act.ptr, None, env.seat_policies ^ (15 << 8), 0, 0, rew.ptr, done.ptr, hand.ptr,
+                                           terr.ptr, obs.ptr, who.ptr, ready.ptr), g._h)
+    # an idle table with PK_ACTION_SKIP is left alone (ready 3); a yielded one that gets no valid action keeps waiting
+    serial = g.step_serial.copy()
+    r2, w2, _ = launch(np.full(T, L.ACTION_SKIP, np.int32))
+    assert (r2[idle] == 3).all() and (r2[waiting] == 2).all() and np.array_equal(w2[waiting], w[waiting])
+    assert (terr.download(np.uint8, T)[waiting] == L.TERR_INVALID_ACTION).all()
+    assert np.array_equal(serial, g.step_serial)
+    env.end_multi()
+    assert np.array_equal(serial, g.step_serial)
+    g.credits
+    env.close()
+
+
+def test_multi_agent_bounded_launches_deliver_the_synchronous_sequences(O, R):
+    """pk_env_step_multi_d with a pass budget and auto-reset, seat 0 and two opponent seats played by the caller with
+    rules that are functions of the delivered row: per table the sequence of delivered (reward, done, hand) is the
+    oracle's, whatever launch delivers it; yields, returns and budget-exhausted tables mix freely."""
+    import pokerl_amd
+    from pokerl_amd import CallAgent, RandomAgent, _lib as L
+    from pokerl_amd.hipmem import DeviceBuffer
+
+    def call_rule(rows):
+        v = rows[:, 3:10] > 0
+        return np.where(v[:, 2], 2, np.where(v[:, 1], 1, 6)).astype(np.int32)
+
+    # (calling stations as the caller's seats would need one launch per Game.step of the endless games they play once
+    # seat 0 is broke -- 8 192 launches up to PK_TERR_ENV_CAP -- so the caller's opponent seats shove instead)
+    for T, N, pols, passes in [(4096, 6, [1, 0, 1, 2, 0], 6), (1000, 4, [1, 1, 0], 2), (2048, 3, [1, 0], 9)]:
+        K = 30
+        ext_seats = [s for s, p in enumerate(pols, start=1) if p == 1]          # the all-in seats are played by the caller
+        agents = [(lambda st: 6) if p == 1 else (RandomAgent() if p == 0 else CallAgent()) for p in pols]
+        o = O.OracleGame(T, N, seed=99)
+        o.env_reset(None, pols)
+        want = dict(rew=np.zeros((T, K)), done=np.zeros((T, K), np.uint8), hand=np.zeros((T, K), np.uint8), err=np.zeros((T, K), np.uint8))
+        for k in range(K):
+            a = o.pick_actions(2)                                                # seat 0 plays the call rule as well
+            ro, do, ho, eo = o.env_step(a, pols)
+            # calling stations can play on for ever once seat 0 is broke: the reference's loops (game_env.py:41, :49) would
+            # spin, PK_TERR_ENV_CAP ends the step and auto_reset starts a new episode, like a finished one
+            assert not (eo & ~np.uint8(O.ERR_ENV_CAP | O.ERR_HAND_CAP)).any()
+            m = ((do != 0) | (eo != 0)).astype(np.uint8)
+            if m.any():
+                o.env_reset(m, pols)
+            want["rew"][:, k], want["done"][:, k], want["hand"][:, k], want["err"][:, k] = ro, do, ho, eo
+        env = pokerl_amd.VecPokerGameEnv(agents, num_tables=T, num_players=N, seed=99)
+        g = env.game
+        D = 17 + 3 * N
+        rew, done, hand, terr, obs, who, ready, act, rst = (DeviceBuffer(T * 8), DeviceBuffer(T), DeviceBuffer(T), DeviceBuffer(T),
+                                                            DeviceBuffer(T * D * 8), DeviceBuffer(T), DeviceBuffer(T), DeviceBuffer(T * 4), DeviceBuffer(T))
+        got = {k: np.zeros_like(v) for k, v in want.items()}
+        count = np.full(T, -1, np.int64)                  # -1: the delivery of the initial reset is still to come
+        rst.upload(np.ones(T, np.uint8))
+        a = np.full(T, L.ACTION_SKIP, np.int32)
+        seen = {0: 0, 1: 0, 2: 0}
+        launches = 0
+        first = True
+        while count.min() < K:
+            launches += 1
+            assert launches < 400 * K, "no progress"
+            act.upload(a)
+            env.step_multi_d(act.ptr, rst.ptr if first else None, rew.ptr, done.ptr, hand.ptr, terr.ptr, obs.ptr, who.ptr, ready.ptr,
+                             max_passes=passes, auto_reset=True)
+            first = False
+            g.sync()
+            r, w = ready.download(np.uint8, T), who.download(np.uint8, T)
+            for v in (0, 1, 2):
+                seen[v] += int((r == v).sum())
+            te = terr.download(np.uint8, T)
+            assert not te[r == 2].any()
+            rows = obs.download(np.float64, T * D).reshape(T, D)
+            ret = r == 1
+            idx = np.nonzero(ret & (count >= 0) & (count < K))[0]
+            c = count[idx]
+            got["err"][idx, c] = te[idx]
+            got["rew"][idx, c] = rew.download(np.float64, T)[idx]
+            got["done"][idx, c] = done.download(np.uint8, T)[idx]
+            got["hand"][idx, c] = hand.download(np.uint8, T)[idx]
+            count[ret] += 1
+            assert (w[ret] == 0).all() and np.isin(w[r == 2], ext_seats).all()
+            a = np.full(T, -1, np.int32)                  # garbage for tables in flight (ready 0): must be ignored
+            a[r == 1] = call_rule(rows[r == 1])           # seat 0: the call rule on its delivered row
+            a[r == 2] = 6                                 # the caller's opponent seats: all-in
+        assert seen[0] > 0 and seen[2] > 0, seen          # budget-exhausted and yielded tables both occurred
+        for k in want:
+            same = GU.bits_equal(want[k], got[k]) if want[k].dtype == np.float64 else np.array_equal(want[k], got[k])
+            assert same, (T, N, k)
+        env.end_multi()
+        env.close()
