@@ -150,9 +150,10 @@ def profile_summary(tables, players, policy, kern_steps=None):
     return (best[1], best[2]) if best else None
 
 
-def evaluator_leg(device, log2_m=None, reps=5):
+def evaluator_leg(device, log2_m=None, reps=20):
     """Second half of the metric as a stand-alone kernel: pk_eval7_d streams 2^28 device-resident 7-card hands
-    (2 GiB in, 1 GiB out: far beyond L2 / Infinity Cache) -- 12 algorithmic bytes per evaluation, HBM-bound."""
+    (2 GiB in, 1 GiB out: far beyond L2 / Infinity Cache) -- 12 algorithmic bytes per evaluation, HBM by definition.
+    Counter evidence (what bounds it in practice) comes from the committed rocprofv3 PMC summary of the same kernel."""
     log2_m = int(os.environ.get("PK_BENCH_EVAL_LOG2", "28")) if log2_m is None else log2_m
     from pokerl_amd import judger
     from pokerl_amd.hipmem import DeviceBuffer
@@ -162,9 +163,23 @@ def evaluator_leg(device, log2_m=None, reps=5):
     ms = judger.time_eval7_stream(hands.ptr, m, out.ptr, True, reps, device)
     hands.free(); out.free()
     gbs = 12.0 * m / (ms * 1e-3) / 1e9
-    return {"kernel": "k_eval7_stream (pk_eval7_d, 7 distinct cards)", "hands": m, "hand_evals_per_s": m / (ms * 1e-3),
-            "kernel_ms": ms, "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                          "frac": gbs / HBM_PEAK_GBS, "bytes_per_eval": 12}}
+    roof = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+            "bytes_per_eval": 12, "traffic": None}
+    src = os.path.join(ROOT, "profiles", "r03_eval7_summary.json")
+    if os.path.exists(src):
+        d = json.load(open(src))
+        per_eval = d.get("hbm_traffic_bytes_per_launch", 0) / float(d.get("hands_per_launch", 1))
+        roof.update({"traffic": per_eval * m, "traffic_unit": "HBM bytes per launch of this size (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE, KiB), = %.3f x algorithmic" % (per_eval / 12.0),
+                     "source": os.path.basename(src), "valu_insts_per_eval": d.get("valu_wave_insts_per_eval_x64"),
+                     "lds_lookups_per_eval": d.get("lds_wave_insts_per_eval_x64"),
+                     "valu_issue_frac_of_peak": d.get("valu_issue_frac_of_peak"),
+                     "wait_inst_any_frac": d.get("wait_inst_any_frac_of_wave_cycles"),
+                     "note": "streams exactly its algorithmic bytes; what keeps it below the HBM roofline is VALU issue: %.0f wave "
+                             "instructions per 64 evaluations, mostly half-rate kinds (shifts, v_bcnt, v_cndmask), issue-stalled "
+                             "%.0f %% of the wave cycles (SQ_WAIT_INST_ANY)" % (d.get("valu_wave_insts_per_eval_x64", 0),
+                                                                               100 * d.get("wait_inst_any_frac_of_wave_cycles", 0))})
+    return {"kernel": "k_eval7_tab_stream (pk_eval7_d, 7 distinct cards, 32 KB rank-mask table in LDS)", "hands": m,
+            "hand_evals_per_s": m / (ms * 1e-3), "kernel_ms": ms, "roofline": roof}
 
 
 def cpu_baseline(n_players, policy, budget_s=None):

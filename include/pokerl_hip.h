@@ -176,7 +176,8 @@ int pk_time_eval7_d(int device, const uint64_t *hands_d, size_t m, uint32_t *out
 
 /* Exhaustive-check hook for the evaluators: v = HandRanking<<20 | kickers value of every 7-card hand whose two lowest
  * canonical deck indices (pokerl/cards.py:77 order) are (a, b), in lexicographic order; out holds C(51-b, 5) words.
- * fast != 0: the 7-distinct-card evaluator the showdown kernels use; fast == 0: the general one behind pk_eval_hands. */
+ * fast == 1: the 7-distinct-card evaluator the showdown kernels use; fast == 0: the general one behind pk_eval_hands;
+ * fast == 2: the table-driven 7-distinct-card evaluator of pk_eval7_d (cards of hand i rotated by i inside the packed word). */
 int pk_eval7_prefix(int device, int a, int b, int fast, uint32_t *out, size_t *count_out);
 
 /* Actions the in-kernel agent `policy` would take now (one per table) -- lets a host loop reproduce rollouts. */

@@ -934,10 +934,39 @@ int pk_compare_rankings(int device, const uint8_t *rank, const uint32_t *kick, i
     return PK_OK;
 }
 
-static int launch_eval7(const uint64_t *hands_d, size_t m, uint32_t *out_d, int distinct) {
+// The 32 KB table of the table-driven evaluator (eval7_tab), one per device, built on first use.
+static uint32_t *g_eval_tab[PK_MAX_DEVICES];
+static const uint32_t *eval7_table(int device) {   // the device is current
+    if (device < 0 || device >= PK_MAX_DEVICES) return nullptr;
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (!g_eval_tab[device]) {
+        uint32_t *p = nullptr;
+        if (hipMalloc((void **)&p, EVAL7_TAB_WORDS * 4) != hipSuccess) return nullptr;
+        hipLaunchKernelGGL(k_make_eval7_tab, dim3(EVAL7_TAB_WORDS / 256), dim3(256), 0, 0, p);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(0) != hipSuccess) { (void)hipFree(p); return nullptr; }
+        g_eval_tab[device] = p;
+    }
+    return g_eval_tab[device];
+}
+
+static int launch_eval7(int device, const uint64_t *hands_d, size_t m, uint32_t *out_d, int distinct) {
     const unsigned grid = 256 * 16;  // 16 workgroups per CU, grid-stride over the rest
     const bool vec = (((uintptr_t)hands_d & 15) | ((uintptr_t)out_d & 7)) == 0;  // 16-byte loads / 8-byte stores need it
-    if (distinct) {
+    static const bool no_tab = getenv("PK_EVAL7_NOTAB") != nullptr;   // A/B knob: the register-only evaluator of the table kernels
+    const uint32_t *tab = (distinct && !no_tab) ? eval7_table(device) : nullptr;
+    if (tab) {   // four 512-thread workgroups per CU (LDS: 4 x 32 KB), two rounds of them
+        // A/B knob (bit 0 clear: software prefetch of the next hands; bit 1 clear: both hands' lookups issued before either is used):
+        // all four within 1.5 % of each other at 2^28 hands; the plain form is the default
+        static const int variant = getenv("PK_EVAL7_VARIANT") ? atoi(getenv("PK_EVAL7_VARIANT")) : 3;
+        static const int grid_max = getenv("PK_EVAL7_GRID") ? atoi(getenv("PK_EVAL7_GRID")) : 256 * 32;
+        const size_t want = (m / 2 + 511) / 512;     // every workgroup copies the 32 KB table: no more of them than have hands
+        const unsigned gridx = (unsigned)(want < 1 ? 1 : (want < (size_t)grid_max ? want : (size_t)grid_max));
+        if (vec && variant == 1) hipLaunchKernelGGL((k_eval7_tab_stream<true, 1>), dim3(gridx), dim3(512), 0, 0, hands_d, m, out_d, tab);
+        else if (vec && variant == 2) hipLaunchKernelGGL((k_eval7_tab_stream<true, 2>), dim3(gridx), dim3(512), 0, 0, hands_d, m, out_d, tab);
+        else if (vec && variant == 0) hipLaunchKernelGGL((k_eval7_tab_stream<true, 0>), dim3(gridx), dim3(512), 0, 0, hands_d, m, out_d, tab);
+        else if (vec) hipLaunchKernelGGL((k_eval7_tab_stream<true, 3>), dim3(gridx), dim3(512), 0, 0, hands_d, m, out_d, tab);
+        else hipLaunchKernelGGL((k_eval7_tab_stream<false, 3>), dim3(gridx), dim3(512), 0, 0, hands_d, m, out_d, tab);
+    } else if (distinct) {
         if (vec) hipLaunchKernelGGL((k_eval7_stream<true, true>), dim3(grid), dim3(256), 0, 0, hands_d, m, out_d);
         else hipLaunchKernelGGL((k_eval7_stream<true, false>), dim3(grid), dim3(256), 0, 0, hands_d, m, out_d);
     } else {
@@ -954,7 +983,7 @@ int pk_eval7_d(int device, const uint64_t *hands_d, size_t m, uint32_t *out_d, i
     DeviceGuard guard(device);
     if (!guard.ok) { g_err = "hipSetDevice failed"; return PK_E_HIP; }
     if (m == 0) return PK_OK;
-    if (launch_eval7(hands_d, m, out_d, distinct) != PK_OK || hipDeviceSynchronize() != hipSuccess) { g_err = "pk_eval7_d: launch failed"; return PK_E_HIP; }
+    if (launch_eval7(device, hands_d, m, out_d, distinct) != PK_OK || hipDeviceSynchronize() != hipSuccess) { g_err = "pk_eval7_d: launch failed"; return PK_E_HIP; }
     return PK_OK;
 }
 
@@ -980,9 +1009,9 @@ int pk_time_eval7_d(int device, const uint64_t *hands_d, size_t m, uint32_t *out
     if (!guard.ok) { g_err = "hipSetDevice failed"; return PK_E_HIP; }
     hipEvent_t e0, e1;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { g_err = "hipEventCreate failed"; return PK_E_HIP; }
-    launch_eval7(hands_d, m, out_d, distinct);  // warm (instruction cache, clocks)
+    launch_eval7(device, hands_d, m, out_d, distinct);  // warm (instruction cache, clocks)
     (void)hipEventRecord(e0, 0);
-    for (int r = 0; r < reps; ++r) launch_eval7(hands_d, m, out_d, distinct);
+    for (int r = 0; r < reps; ++r) launch_eval7(device, hands_d, m, out_d, distinct);
     (void)hipEventRecord(e1, 0);
     hipError_t e = hipEventSynchronize(e1);
     float ms = 0.f;
@@ -1007,10 +1036,12 @@ int pk_eval7_prefix(int device, int a, int b, int fast, uint32_t *out, size_t *c
     if (count_out) *count_out = count;
     if (!count) return PK_OK;
     tmp_handle th;
+    const uint32_t *tab = fast == 2 ? eval7_table(device) : nullptr;   // (takes g_scratch_mu itself)
+    if (fast == 2 && !tab) { g_err = "pk_eval7_prefix: out of device memory"; return PK_E_OOM; }
     std::lock_guard<std::mutex> lock(g_scratch_mu);
     uint32_t *d = (uint32_t *)scratch(device, count * 4);
     if (!d) { g_err = "pk_eval7_prefix: out of device memory"; return PK_E_OOM; }
-    hipLaunchKernelGGL(k_eval7_prefix, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, 0, a, b, fast, (uint32_t)count, d);
+    hipLaunchKernelGGL(k_eval7_prefix, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, 0, a, b, fast, (uint32_t)count, d, tab);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpy(out, d, count * 4, hipMemcpyDeviceToHost);
     if (e != hipSuccess) return th.fail(PK_E_HIP, "pk_eval7_prefix", e);

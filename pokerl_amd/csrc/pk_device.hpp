@@ -342,6 +342,106 @@ __device__ __forceinline__ uint32_t eval7_distinct(const uint32_t (&c)[7]) {
     return (cat << 20) | kick;
 }
 
+// ---------------------------------------------------------------------------------------------- table-driven evaluator
+// The same function as eval7_distinct for the STREAMING evaluator (k_eval7_stream: eight waves per SIMD hide the LDS
+// latency that made a lookup table a dead end inside k_rollout's one-wave-per-SIMD loop): the five-iteration `clz`
+// extraction of the top five ranks, the straight detection and the lowest-run scan become one 32-bit table entry per
+// 13-bit rank mask, and the category cascade becomes a max over candidates.  8 192 entries x 4 B = 32 KB of LDS.
+//
+// Entry of a RAW rank mask m (bit r0 set = a card of Card rank0 r0 present; bit 0 is the ace, cards.py:14) describing
+// the ace-high mask a (bit k = rank k+1, ace = bit 12) -- indexing by the raw mask folds the ace-high conversion into
+// the table, and every other operation of the evaluator is position-agnostic:
+//   bits  0..19  the five highest ranks of a as nibbles, highest first (rank 1..13, 0 = none left)    judger.py:94, :99
+//   bits 20..23  top rank (5..13) of the highest run of five in a, 0 = none (no wheel)                 judger.py:71-72, :95
+//   bits 24..27  length, bits 28..31 top bit index (0..12) of the LOWEST run of a: where the reference's `both`
+//                tracker ends up inside the flush group (judger.py:56-57), and (length 4, top 3) = "exactly 5-4-3-2"
+__device__ inline uint32_t eval7_tab_entry(uint32_t m) {
+    const uint32_t a = ((m >> 1) & 0xfffu) | ((m & 1u) << 12);
+    uint32_t k5 = 0, x = a;
+    for (int i = 0; i < 5; ++i) {
+        const uint32_t lz = (uint32_t)__clz((int)x);
+        k5 = (k5 << 4) | (32u - lz);
+        x &= ~(0x80000000u >> (lz & 31));
+    }
+    const uint32_t m5 = a & (a >> 1) & (a >> 2) & (a >> 3) & (a >> 4);
+    const uint32_t st = m5 ? (uint32_t)(31 - __clz((int)m5) + 5) : 0u;
+    const uint32_t run = a & ~(a + (a & (0u - a)));
+    const uint32_t len = (uint32_t)__popc(run), top = run ? (uint32_t)(31 - __clz((int)run)) : 0u;
+    return k5 | (st << 20) | (len << 24) | (top << 28);
+}
+constexpr int EVAL7_TAB_WORDS = 8192;
+
+// lo = card bytes 0..3, hi = card bytes 4..6 (byte 7 ignored) of 7 DISTINCT cards; T = the table above (LDS).
+// Candidates are encoded stronger = larger -- c' = 10 - HandRanking in bits 24..27, then (shift of the tail lookup)/4
+// in bits 20..22, then the leading kickers -- so that the category cascade of judger.py:90-99 is a max.
+// Two halves, so that a caller with several hands per lane can issue the lookups of all of them before any is used.
+struct Eval7Front {
+    uint32_t um, gm, pairs, trips, quads;
+    uint32_t e_um, e_gm, e_p, e_t, e_q;
+    bool has_flush;
+};
+// Every mask below is kept SHIFTED LEFT BY TWO (rank0 r0 = bit r0 + 2 of a 16-bit suit lane), i.e. it is already the byte
+// offset of its table entry: six address shifts per evaluation less.
+__device__ __forceinline__ uint32_t eval7_tab_at(const uint32_t *T, uint32_t mask4) {
+    return *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(T) + mask4);
+}
+__device__ __forceinline__ Eval7Front eval7_tab_front(uint32_t lo, uint32_t hi, const uint32_t *T) {
+    Eval7Front f;
+    const uint64_t bits = (4ull << (lo & 63)) | (4ull << ((lo >> 8) & 63)) | (4ull << ((lo >> 16) & 63)) | (4ull << ((lo >> 24) & 63)) |
+                          (4ull << (hi & 63)) | (4ull << ((hi >> 8) & 63)) | (4ull << ((hi >> 16) & 63));
+    const uint32_t w01 = (uint32_t)bits, w23 = (uint32_t)(bits >> 32);
+    const uint32_t sa = w01 & 0xffffu, sb = w01 >> 16, sc = w23 & 0xffffu, sd = w23 >> 16;   // raw rank masks per suit (x 4)
+    f.um = sa | sb | sc | sd;
+    const uint32_t s1 = sa ^ sb, c1 = sa & sb, s2 = sc ^ sd, c2 = sc & sd;        // per-rank count = bit0 + 2*t + 4*quads
+    const uint32_t bit0 = s1 ^ s2, t = c1 ^ c2 ^ (s1 & s2);
+    f.quads = c1 & c2; f.pairs = t & ~bit0; f.trips = t & bit0;
+    // `flush` group (judger.py:52-58): the suit with >= 5 cards, else the lowest suit present
+    const uint32_t ka = ((uint32_t)__popc(sa) << 15) | sa, kb = ((uint32_t)__popc(sb) << 15) | sb;
+    const uint32_t kc = ((uint32_t)__popc(sc) << 15) | sc, kd = ((uint32_t)__popc(sd) << 15) | sd;
+    const uint32_t gk = max(max(ka, kb), max(kc, kd));
+    f.has_flush = gk >= (5u << 15);
+    const uint32_t lp = sa ? sa : (sb ? sb : (sc ? sc : sd));
+    f.gm = f.has_flush ? (gk & 0x7fffu) : lp;
+    f.e_um = eval7_tab_at(T, f.um); f.e_gm = eval7_tab_at(T, f.gm); f.e_p = eval7_tab_at(T, f.pairs);
+    f.e_t = eval7_tab_at(T, f.trips); f.e_q = eval7_tab_at(T, f.quads);
+    return f;
+}
+__device__ __forceinline__ uint32_t eval7_tab_back(const Eval7Front &f, const uint32_t *T) {
+    const uint32_t p1 = (f.e_p >> 16) & 15u, p12 = (f.e_p >> 12) & 0xffu, p2 = p12 & 15u, p3 = (f.e_p >> 8) & 15u;
+    const uint32_t t1 = (f.e_t >> 16) & 15u, t2 = (f.e_t >> 12) & 15u, q1 = (f.e_q >> 16) & 15u;
+    const uint32_t st = (f.e_um >> 20) & 15u;
+    // an empty mask's entry is 0, so "the family exists" is "its first rank is not 0"
+    uint32_t W = 1u << 24;                                                                     // :99 HIGH, tail = top five of um
+    const uint32_t w_p = p2 ? ((3u << 24) | (4u << 20) | (p12 << 4))                           // :97 TWO_PAIR [p1, p2, x]
+                            : ((2u << 24) | (2u << 20) | (p1 << 12));                          // :98 PAIR [p1, x, x, x]
+    W = max(W, p1 ? w_p : 0u);
+    const uint32_t x2 = t2 ? t2 : p1;                                                          // :92 second trips, else :93 highest pair
+    const uint32_t w_t = (x2 ? ((7u << 24) | (5u << 20) | x2) : ((4u << 24) | (3u << 20)))    // FULL [t1, x2] / :96 TRIS [t1, x, x]
+                         | (t1 << (x2 ? 4u : 8u));
+    W = max(W, t1 ? w_t : 0u);
+    W = max(W, st ? ((5u << 24) | (5u << 20) | st) : 0u);                                      // :95 STRAIGHT
+    W = max(W, f.has_flush ? ((6u << 24) | (5u << 20) | (f.e_gm & 0xfffffu)) : 0u);            // :94 FLUSH, five highest of the suit
+    W = max(W, q1 ? ((8u << 24) | (4u << 20) | (q1 << 4)) : 0u);                               // :91 POKER [q, x]
+    W = max(W, ((f.e_gm >> 24) & 15u) >= 5u ? ((9u << 24) | (5u << 20) | ((f.e_gm >> 28) + 1u)) : 0u);   // :90 STRAIGHT_FLUSH
+    // ranks the tail must skip: the quads / the trips / the pair or the two highest pairs (a third pair p3 is the lowest
+    // and never the ace, so its raw bit is 1 << p3 -- 4 << p3 in the shifted masks; p3 == 0 must clear nothing)
+    const uint32_t taken2 = f.pairs & ~((4u << p3) & ~4u);
+    const uint32_t taken = q1 ? f.quads : (t1 ? f.trips : taken2);
+    const uint32_t tail = (eval7_tab_at(T, f.um & ~taken) & 0xfffffu) >> (((W >> 20) & 7u) << 2);
+    uint32_t v = ((10u - (W >> 24)) << 20) | (W & 0xfffffu) | tail;
+    // wheel checks of judger.py:83-88, if / elif: a 5-4-3-2 run as the flush group's lowest run decides alone
+    const bool low4 = (f.e_gm >> 24) == 0x34u;
+    const bool wheel_sf = low4 && (f.gm & 4u);
+    const bool wheel_st = !low4 && st == 0 && (f.e_um >> 24) == 0x34u && (f.um & 4u);
+    v = wheel_st ? (((uint32_t)HR_STRAIGHT << 20) | 4u) : v;
+    v = wheel_sf ? (((uint32_t)HR_SF << 20) | 4u) : v;
+    return v;
+}
+__device__ __forceinline__ uint32_t eval7_tab(uint32_t lo, uint32_t hi, const uint32_t *T) {
+    const Eval7Front f = eval7_tab_front(lo, hi, T);
+    return eval7_tab_back(f, T);
+}
+
 // ---------------------------------------------------------------------------------------------- the table
 // One table per lane.  Game.step's nested calls (next_player -> next_turn -> end_hand -> setup_hand, game.py:578-619)
 // are flattened into a per-lane state machine so that a wavefront executes each expensive block ONCE per step for all

@@ -693,6 +693,42 @@ __global__ void __launch_bounds__(256) k_eval7_stream(const uint64_t *__restrict
         for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride) out[i] = eval1(hands[i]);
     }
 }
+// The table of eval7_tab (pk_device.hpp), built once per device into global memory; every workgroup of the streaming
+// kernel below copies it into its LDS.
+__global__ void k_make_eval7_tab(uint32_t *tab) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (uint32_t)EVAL7_TAB_WORDS) tab[i] = eval7_tab_entry(i);
+}
+// Streaming evaluator for 7 DISTINCT cards, table-driven (eval7_tab): 512-thread workgroups, four per CU (4 x 32 KB of LDS),
+// eight waves per SIMD under the 64-register cap; same two-hands-per-lane 16-byte loads / 8-byte stores as above.
+template <bool VEC, int VARIANT>
+__global__ void __launch_bounds__(512, 8) k_eval7_tab_stream(const uint64_t *__restrict__ hands, size_t m, uint32_t *__restrict__ out, const uint32_t *__restrict__ tab) {
+    __shared__ uint32_t T[EVAL7_TAB_WORDS];
+    for (int i = threadIdx.x; i < EVAL7_TAB_WORDS / 4; i += 512) reinterpret_cast<uint4 *>(T)[i] = reinterpret_cast<const uint4 *>(tab)[i];
+    __syncthreads();
+    const size_t pairs = VEC ? m / 2 : 0, stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    constexpr bool PREFETCH = (VARIANT & 1) == 0, TWO_PHASE = (VARIANT & 2) == 0;
+    uint4 w = i < pairs ? reinterpret_cast<const uint4 *>(hands)[i] : uint4{0, 0, 0, 0};
+    for (; i < pairs; i += stride) {
+        const size_t nx = i + stride;                       // the next iteration's hands are in flight while these are evaluated
+        uint4 wn = uint4{0, 0, 0, 0};
+        if (PREFETCH) { if (nx < pairs) wn = reinterpret_cast<const uint4 *>(hands)[nx]; }
+        uint2 r;
+        if (TWO_PHASE) {
+            const Eval7Front f0 = eval7_tab_front(w.x, w.y, T), f1 = eval7_tab_front(w.z, w.w, T);   // ten lookups issued ...
+            r.x = eval7_tab_back(f0, T); r.y = eval7_tab_back(f1, T);                                // ... before the first is used
+        } else { r.x = eval7_tab(w.x, w.y, T); r.y = eval7_tab(w.z, w.w, T); }
+        reinterpret_cast<uint2 *>(out)[i] = r;
+        if (PREFETCH) w = wn;
+        else if (nx < pairs) w = reinterpret_cast<const uint4 *>(hands)[nx];
+    }
+    if constexpr (VEC) {
+        if ((m & 1) && blockIdx.x == 0 && threadIdx.x == 0) out[m - 1] = eval7_tab((uint32_t)hands[m - 1], (uint32_t)(hands[m - 1] >> 32), T);
+    } else {
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride) out[i] = eval7_tab((uint32_t)hands[i], (uint32_t)(hands[i] >> 32), T);
+    }
+}
 // hand i = first 7 cards of the RNG-spec deck of (table_id = i, hand_serial = 0): the deal of a 1-seat table
 __global__ void __launch_bounds__(256) k_make_hands(Hot H, size_t m, uint64_t *out) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -706,7 +742,7 @@ __global__ void __launch_bounds__(256) k_make_hands(Hot H, size_t m, uint64_t *o
 
 // Exhaustive 7-card sweep used by tests (digest definition: tests/golden/make_eval_digest.py): all hands with prefix
 // (a, b); hand index within the prefix -> combination of 5 from the cards above b is decoded per lane.
-__global__ void k_eval7_prefix(int a, int b, int fast, uint32_t count, uint32_t *out) {
+__global__ void k_eval7_prefix(int a, int b, int fast, uint32_t count, uint32_t *out, const uint32_t *tab) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     // unrank i among 5-subsets of {b+1..51} in lexicographic order
@@ -729,6 +765,12 @@ __global__ void k_eval7_prefix(int a, int b, int fast, uint32_t count, uint32_t 
     uint32_t h[7] = {canon(a), canon(b), canon(b + 1 + sel5[0]), canon(b + 1 + sel5[1]), canon(b + 1 + sel5[2]),
                      canon(b + 1 + sel5[3]), canon(b + 1 + sel5[4])};
     int nk;
-    out[i] = fast ? eval7_distinct(h) : eval_hand(h, 7, nk);  // in-game evaluator / general (multiset) evaluator
+    // fast 1: the in-game evaluator; 0: the general (multiset) evaluator; 2: the table-driven evaluator of the streaming
+    // kernel (cards rotated by the hand index so that every byte position of the packed word is exercised)
+    if (fast == 2) {
+        uint32_t r[7];
+        for (int j = 0; j < 7; ++j) r[j] = h[(j + i) % 7];
+        out[i] = eval7_tab(r[0] | (r[1] << 8) | (r[2] << 16) | (r[3] << 24), r[4] | (r[5] << 8) | (r[6] << 16) | 0xAB000000u, tab);
+    } else out[i] = fast ? eval7_distinct(h) : eval_hand(h, 7, nk);
 }
 

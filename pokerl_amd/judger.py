@@ -79,13 +79,14 @@ def compare_hands(hands, device=0):
 
 def eval7_prefix(a, b, fast=True, device=0):
     """Values rank<<20|kick of all 7-card hands whose two lowest canonical indices are (a, b) (exhaustive checks).
-    fast=True: the distinct-card evaluator used by the showdown kernels; False: the general evaluator."""
+    fast=True / 1: the distinct-card evaluator used by the showdown kernels; False / 0: the general evaluator;
+    2: the table-driven distinct-card evaluator of the streaming kernel (eval7_stream)."""
     import ctypes as C
     import math
     n = math.comb(51 - b, 5)
     out = np.zeros(max(n, 1), np.uint32)
     cnt = C.c_size_t(0)
-    L.check(L.lib().pk_eval7_prefix(int(device), int(a), int(b), int(bool(fast)), L.ptr(out), C.byref(cnt)))
+    L.check(L.lib().pk_eval7_prefix(int(device), int(a), int(b), int(fast), L.ptr(out), C.byref(cnt)))
     return out[:cnt.value]
 
 

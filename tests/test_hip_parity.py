@@ -75,10 +75,11 @@ def test_golden_judger_vectors(HB):
         assert [[r, k] for r, k in out[2]] == case["rankings"]
 
 
-@pytest.mark.parametrize("fast", [True, False], ids=["showdown_evaluator", "general_evaluator"])
+@pytest.mark.parametrize("fast", [1, 0, 2], ids=["showdown_evaluator", "general_evaluator", "table_evaluator_of_the_streaming_kernel"])
 def test_eval7_exhaustive_digest(HB, fast):
     """All C(52,7) = 133 784 560 hands on the GPU against the digest computed from the imported reference, for both
-    device evaluators (the bitmask one the showdown kernels use and the general multiset one of pk_eval_hands)."""
+    device evaluators (the bitmask one the showdown kernels use, the general multiset one of pk_eval_hands, and the
+    LDS-table one of the streaming kernel pk_eval7_d)."""
     from pokerl_amd import judger
     gold = GU.load_json("eval7_digest")
     GOLD = np.uint64(0x9E3779B97F4A7C15)

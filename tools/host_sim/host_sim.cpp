@@ -99,7 +99,7 @@ static int run(int T, int K, int policy, uint64_t seed, Cfg cfg = default_cfg(),
 }
 
 // exhaustive: eval7_distinct (host build of the device function) vs the oracle over all C(52,7) hands
-static int check_eval7() {
+static int check_eval7(const uint32_t *tab = nullptr) {
     std::vector<uint32_t> out(2200000);
     size_t total = 0, bad = 0;
     for (int a = 0; a < 52; ++a)
@@ -111,12 +111,16 @@ static int check_eval7() {
             for (int f = e + 1; f < 52; ++f) for (int g = f + 1; g < 52; ++g) {
                 uint32_t h[7] = {canon(a), canon(b), canon(c), canon(d), canon(e), canon(f), canon(g)};
                 uint32_t v = eval7_distinct(h);
+                if (tab) {   // the table-driven variant of the streaming evaluator, cards in any order (rotate by the hand index)
+                    uint32_t r[7]; for (int j = 0; j < 7; ++j) r[j] = h[(j + i) % 7];
+                    v = eval7_tab(r[0] | r[1] << 8 | r[2] << 16 | r[3] << 24, r[4] | r[5] << 8 | r[6] << 16 | 0xAB000000u, tab);
+                }
                 if (v != out[i]) { if (bad++ < 5) printf("eval7 MISMATCH %d %d %d %d %d %d %d: %x vs %x\n", a, b, c, d, e, f, g, v, out[i]); }
                 ++i; ++total;
             }
             if (i != n) { printf("count mismatch\n"); return 1; }
         }
-    printf("eval7_distinct vs oracle: %zu hands, %zu mismatches\n", total, bad);
+    printf("%s vs oracle: %zu hands, %zu mismatches\n", tab ? "eval7_tab" : "eval7_distinct", total, bad);
     return bad != 0;
 }
 
@@ -154,6 +158,11 @@ static int fuzz(int rounds, int T, int K) {
 
 int main(int argc, char **argv) {
     if (argc > 1 && !strcmp(argv[1], "eval7")) return check_eval7();
+    if (argc > 1 && !strcmp(argv[1], "eval7tab")) {
+        std::vector<uint32_t> tab(EVAL7_TAB_WORDS);
+        for (int m = 0; m < EVAL7_TAB_WORDS; ++m) tab[m] = eval7_tab_entry((uint32_t)m);
+        return check_eval7(tab.data());
+    }
     if (argc > 1 && !strcmp(argv[1], "fuzz")) return fuzz(argc > 2 ? atoi(argv[2]) : 90, argc > 3 ? atoi(argv[3]) : 64, argc > 4 ? atoi(argv[4]) : 300);
     int T = argc > 1 ? atoi(argv[1]) : 256, K = argc > 2 ? atoi(argv[2]) : 400;
     int rc = 0;
