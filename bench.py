@@ -381,7 +381,7 @@ def main():
     from pokerl_amd.hipmem import DeviceEvent
     ev0, ev1 = DeviceEvent(), DeviceEvent()
     stats_warm = game.launch_stats(reset=True)           # launches so far (reset + warm-up): a profiler sees those too
-    sample_s, sample_dev_ms = [], []
+    sample_s, sample_dev_ms, sample_stats = [], [], []
     for _ in range(max(1, args.samples)):
         ctx.barrier(); game.sync()
         game.record_event(ev0.handle)                    # HIP events on the stream the kernel is launched on
@@ -392,20 +392,23 @@ def main():
         game.sync(); ctx.barrier()   # exactly reps*K steps per table are inside
         sample_s.append(ctx.aggregate(0, time.perf_counter() - t0)[1])   # MAX over ranks
         sample_dev_ms.append(DeviceEvent.elapsed_ms(ev0, ev1))
-    stats = game.launch_stats()
+        sample_stats.append(game.launch_stats(reset=True))
+    stats = dict(launches=sum(x["launches"] for x in sample_stats), steps=sum(x["steps"] for x in sample_stats),
+                 min=min(x["min"] for x in sample_stats), max=max(x["max"] for x in sample_stats))
     c = game.rollout(0, policy, True, fused, counters=True)
     assert c["steps"] == n_local * K * reps * len(sample_s), (c, n_local, K, reps)
     assert stats["steps"] == K * reps * len(sample_s), (stats, K, reps)
-    seconds = sorted(sample_s)[len(sample_s) // 2]
+    med = sorted(range(len(sample_s)), key=lambda i: sample_s[i])[len(sample_s) // 2]   # the MEDIAN sample: value, ms_per_step and kernel_ms are all its
+    seconds = sample_s[med]
     total_steps = ctx.aggregate(n_local * K * reps, 0.0)[0]
     scale = 1.0 / (sum(sample_s))   # counters cover all samples
     hands, evals, games = ctx.sum_list([c["hands"], c["evals"], c["games"]])
 
     # roofline leg (rank 0): the timed region itself, bracketed by HIP events on the handle's stream; the dominant kernel
     # is the only kernel in it, so its average launch duration (launch gaps included) = event time / launches
-    launches = max(1, stats["launches"])
-    ms_launch = sum(sample_dev_ms) / launches
-    kern_steps = stats["steps"] / float(launches)        # mean Game.step()s per table per launch
+    launches = max(1, sample_stats[med]["launches"])
+    ms_launch = sample_dev_ms[med] / launches            # of the median sample, like `value` and `ms_per_step`
+    kern_steps = sample_stats[med]["steps"] / float(launches)        # mean Game.step()s per table per launch
     ctx.barrier()
     if ctx.rank == 0:
         alg_bytes = b_step(args.players) * n_local * kern_steps
@@ -422,8 +425,8 @@ def main():
                 "frac": None, "traffic": None,
                 "traffic_unit": "HBM bytes per launch (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE, KiB)",
                 "kernel_ms": ms_launch, "launches_timed": launches, "steps_per_launch": kern_steps,
-                "kernel_ms_source": "HIP events (pk_record_event) around every timed sample on the handle's stream / "
-                                    "launches inside them (pk_get_launch_stats)",
+                "kernel_ms_source": "HIP events (pk_record_event) around the timed samples on the handle's stream; the median "
+                                    "sample's device time / the launches inside it (pk_get_launch_stats)",
                 "hbm_algorithmic": hbm}
         if prof:
             d, src = prof
@@ -451,11 +454,11 @@ def main():
         if roof["achieved"] is None:   # no committed PMC summary for this shape: only the SURVEY 8d figure can be given
             roof.update({"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "note": "no rocprofv3 PMC summary of this workload under profiles/: algorithmic-HBM figure only (see hbm_algorithmic)"})
-        kern_desc = ("k_rollout (fused; %d launches in the timed region, mean %.1f steps per launch, min %d, max %d: "
+        kern_desc = ("k_rollout (fused; %d launches in the median sample, mean %.1f steps per launch, min %d, max %d over all samples: "
                      "asynchronous calls of %d steps %s)"
                      % (launches, kern_steps, stats["min"], stats["max"], min(args.chunk, K),
                         "merged on the host while two launches are in flight (pk_set_coalesce)" if stats["max"] > min(args.chunk, K) else "launched one by one")
-                     if fused else "k_rollout (1 step/launch)")
+                     if fused else "k_rollout_single (1 step/launch, the state round-trips HBM every step)")
         out = {
             "metric": "env-steps/sec (whole node) + showdown hand-evals/sec, 65 536 tables 6-max",
             "value": total_steps / seconds, "unit": "env-steps/s", "n_gpus": ctx.world, "steps": K,

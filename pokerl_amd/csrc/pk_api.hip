@@ -125,7 +125,8 @@ static inline int flat_grid(size_t n) { return (int)((n + 255) / 256); }
 static int launch_rollout(pk_handle *h, int k_steps, int policy, int auto_reset, int endk) {
     const int slack = endk <= 1 ? PK_WAVE : ((PK_WAVE - endk) * h->tpb) / PK_WAVE;   // lanes allowed to idle before a launch ends
 #define ROLLOUT_ARGS (const State *)h->d_S, h->hot, k_steps, auto_reset, scaled_park(h, policy == PK_POLICY_RANDOM ? 28 : 32), slack, h->pending ? 0 : 1
-    if (policy == PK_POLICY_CALL) DISPATCH_N(h, k_rollout_call, table_grid(h), ROLLOUT_ARGS);
+    if (policy == PK_POLICY_RANDOM && k_steps == 1 && endk <= 1 && !h->occ3) DISPATCH_N(h, k_rollout_single, table_grid(h), ROLLOUT_ARGS);
+    else if (policy == PK_POLICY_CALL) DISPATCH_N(h, k_rollout_call, table_grid(h), ROLLOUT_ARGS);
     else if (!h->occ3) {
         if (policy == PK_POLICY_RANDOM) DISPATCH_N(h, k_rollout, table_grid(h), ROLLOUT_ARGS);
         else DISPATCH_N(h, k_rollout_allin, table_grid(h), ROLLOUT_ARGS);
@@ -413,7 +414,7 @@ int pk_step_d(pk_handle *h, const int32_t *actions_d, uint8_t *flags_d, uint8_t 
     if (!h || !actions_d || !flags_d) return h ? h->fail(PK_E_INVALID_ARG, "pk_step_d: NULL buffer") : PK_E_INVALID_ARG;
     ON_DEVICE(h);
     FLUSH(h);
-    DISPATCH_N(h, k_step, table_grid(h), (const State *)h->d_S, h->hot, actions_d, flags_d, terr_d);
+    DISPATCH_N(h, k_step, table_grid(h), (const State *)h->d_S, h->hot, actions_d, flags_d, terr_d, scaled_park(h, 28));
     HIPCHK(h, hipGetLastError());
     return PK_OK;
 }

@@ -72,42 +72,6 @@ __global__ void k_make_fresh(Hot H, Fresh *out) {
 }
 
 template <int N>
-__global__ void __launch_bounds__(PK_TABLE_BLOCK) k_step(const State *__restrict__ Sp, Hot H, const int32_t *actions, uint8_t *flags, uint8_t *terr) {  // Game.step, game.py:621-700
-    const State &S = *Sp;
-    __shared__ Lds<N> lds;
-    const int t = blockIdx.x * H.tpb + threadIdx.x;
-    const bool live = (int)threadIdx.x < H.tpb && t < S.T;
-    const uint32_t table_id = H.table_id_base + (uint32_t)t;
-    Table<N> tb;
-    if (live) tb.load(S, t); else tb.blank();
-    double high_bet;
-    uint32_t mask = tb.valid_mask(high_bet);                                       // :648
-    const int action = live ? actions[t] : -1;
-    const bool ok = live && action >= 0 && action < PK_NUM_MOVES && ((mask >> action) & 1);
-    bool todo = ok;
-    for (;;) {  // same flat shape as k_rollout / k_env_step: one instantiation of cursor and end_block
-        if (todo) { tb.begin_step(H, action, high_bet); todo = false; }
-        tb.cursor();
-        if (!__any(tb.parked())) break;
-        tb.end_block(H, t, table_id, lds, false);
-    }
-    tb.finish_step();
-    if (!live) return;
-    tb.store_show(S.show, S.T, t, lds);
-    if (!ok) {                                                                     // :649-651: no mutation
-        flags[t] = 0;
-        S.terr[t] = PK_TERR_INVALID_ACTION;
-        if (terr) terr[t] = PK_TERR_INVALID_ACTION;
-        return;
-    }
-    tb.store(S, t);
-    flags[t] = (uint8_t)tb.flags;
-    S.valid[t] = (uint8_t)tb.valid_mask(high_bet);
-    S.terr[t] = (uint8_t)tb.terr;
-    if (terr) terr[t] = (uint8_t)tb.terr;
-}
-
-template <int N>
 __global__ void __launch_bounds__(PK_TABLE_BLOCK) k_pick(State S, Hot H, int policy, int32_t *actions) {
     int t = blockIdx.x * H.tpb + threadIdx.x;
     if ((int)threadIdx.x >= H.tpb || t >= S.T) return;
@@ -133,8 +97,13 @@ __global__ void __launch_bounds__(PK_TABLE_BLOCK) k_pick(State S, Hot H, int pol
 // POLICY (the in-kernel agents) is a template parameter: with a run-time policy the random agent's LDS lookup sat in a
 // basic block of its own and its latency could not be overlapped with the action-independent part of the step
 // (+2.4 % at 65 536 x 6).
-template <int N, bool ONE_PASS, int POLICY>
-__device__ __forceinline__ void rollout_body(const State *__restrict__ Sp, const Hot &H, int K, int auto_reset, int park, int slack, int clear_terr) {
+// POLICY == PK_POLICY_EXTERNAL is Game.step itself (k_step): ONE step per table with the caller's action, read once;
+// an invalid one leaves the table untouched (game.py:649-651).  PASSES = betting passes between two looks at the parked
+// lanes: four for the multi-step kernels, one for the single-step ones (a lane makes one step; three more passes
+// would run empty).
+template <int N, bool ONE_PASS, int POLICY, int PASSES = 0>
+__device__ __forceinline__ void rollout_body(const State *__restrict__ Sp, const Hot &H, int K, int auto_reset, int park, int slack, int clear_terr,
+                                             const int32_t *actions = nullptr, uint8_t *flags_out = nullptr, uint8_t *terr_out = nullptr) {
     // Array bases by pointer (loaded only where the table is loaded / stored), loop scalars by value: see pk::Hot.
     constexpr int policy = POLICY;
     const State &S = *Sp;
@@ -146,11 +115,21 @@ __device__ __forceinline__ void rollout_body(const State *__restrict__ Sp, const
     uint32_t owed = 0;
     Table<N>::stage_fresh(lds, H.fresh);
     stage_nth(lds);
+    constexpr bool EXTERNAL = POLICY == PK_POLICY_EXTERNAL;
     if (live) { tb.load(S, t); tb.hands_this_step = (int)S.mid[t]; owed = S.owed[t] + (uint32_t)K; } else tb.blank();
     uint32_t steps = 0;
     bool alive = live;
     ActionRing ring;
     double high_bet;
+    int ext_action = -1;
+    bool ext_ok = true;
+    if (EXTERNAL) {                                                                // game.py:648-651
+        const uint32_t vm = tb.valid_mask(high_bet);
+        ext_action = live ? actions[t] : -1;
+        ext_ok = live && ext_action >= 0 && ext_action < PK_NUM_MOVES && ((vm >> ext_action) & 1);
+        owed = ext_ok ? 1u : 0u;                                                   // (the host has flushed: nothing was owed)
+        alive = ext_ok;
+    }
     // lanes that can work at all in this launch; the launch ends once more than `slack` of them have run out of work
     // (slack >= 64: never, i.e. run to completion)
     const int cap = __popcll(__ballot(live && (owed > 0 || tb.lstate == LS_END)));
@@ -178,27 +157,30 @@ __device__ __forceinline__ void rollout_body(const State *__restrict__ Sp, const
 #define PK_BET_PASSES 4   // betting passes between two looks at the parked lanes: end_block then serves what four passes
 #endif                    // have parked (1: 23.8 G, 2: 25.1 G, 3: 24.4 G, 4: 25.6 G, 6: 24.7 G, 8: 23.2 G at 65 536 x 6)
     static_assert(((PK_TAIL_MASK) >> (PK_BET_PASSES - 1)) & 1, "the last betting pass must run cursor_tail()");
+    constexpr int NPASS = PASSES > 0 ? PASSES : PK_BET_PASSES;
+    constexpr int TAILS = PASSES > 0 ? (1 << (PASSES - 1)) | (PK_TAIL_MASK & ((1 << PASSES) - 1)) : PK_TAIL_MASK;
     for (;;) {
         // Nothing is in flight at the top of an iteration.  Without this the compiler cannot rule out that a table
         // register still waits for the global loads before the loop or for end_block's LDS reads (both sit in
         // conditionally executed blocks), and parks a full s_waitcnt right behind the first LDS read of every betting
         // pass: the action ring's latency was exposed three passes out of four.
         if (policy == PK_POLICY_RANDOM) __builtin_amdgcn_s_waitcnt(0);   // (the all-in kernel has no LDS read in its passes)
-        if (policy == PK_POLICY_RANDOM) ring.ensure(lds, H, table_id, tb.step_serial, alive && owed > 0, PK_BET_PASSES);   // wave-uniform
+        if (policy == PK_POLICY_RANDOM) ring.ensure(lds, H, table_id, tb.step_serial, alive && owed > 0, NPASS);   // wave-uniform
 #pragma unroll
-        for (int pass = 0; pass < PK_BET_PASSES; ++pass) {
+        for (int pass = 0; pass < NPASS; ++pass) {
             const bool go = alive && tb.lstate == LS_DONE && owed > 0;
             uint32_t word = 0;
             if (policy == PK_POLICY_RANDOM) word = ActionRing::peek(lds, tb.step_serial);
             if (go) {
                 uint32_t mask = tb.valid_mask(high_bet);
-                tb.begin_step(H, policy == PK_POLICY_ALLIN ? (int)MV_ALL_IN
+                tb.begin_step(H, EXTERNAL ? ext_action
+                               : policy == PK_POLICY_ALLIN ? (int)MV_ALL_IN
                                : policy == PK_POLICY_CALL ? call_action(mask)
                                                           : action_from_draw_lds(lds, ActionRing::half_of(word, tb.step_serial), mask), high_bet);
             }
             PK_PROF(tb.prof.lap(PF_ACTION);)
             tb.scan_first();      // every lane in LS_SCAN: the steps just begun and the ones end_block carried into a new hand
-            if ((PK_TAIL_MASK >> pass) & 1) tb.cursor_tail();
+            if ((TAILS >> pass) & 1) tb.cursor_tail();
             PK_PROF(tb.prof.count(PF_N_CURSOR);)
             retire();
             PK_PROF(tb.prof.lap(PF_CURSOR);)
@@ -216,6 +198,22 @@ __device__ __forceinline__ void rollout_body(const State *__restrict__ Sp, const
     // LS_END: end_hand up to there is idempotent (the pending bets are committed and zero, payoffs are re-zeroed, the
     // side pots restart from the unchanged committed bets), so the next launch redoes it together with its own arrivals.
     if (tb.lstate == LS_POT) { tb.lstate = LS_END; tb.evals -= (uint32_t)__popc((tb.st_called | tb.st_allin) & Table<N>::FULL); }
+    if (EXTERNAL) {
+        if (live) {
+            if (ext_ok) {
+                tb.store(S, t);
+                tb.store_show(S.show, S.T, t, lds);
+                S.mid[t] = 0;
+                S.valid[t] = (uint8_t)tb.valid_mask(high_bet);
+            }
+            const uint8_t te = ext_ok ? (uint8_t)tb.terr : (uint8_t)PK_TERR_INVALID_ACTION;
+            flags_out[t] = ext_ok ? (uint8_t)tb.flags : (uint8_t)0;                // :649-651: no mutation
+            S.terr[t] = te;
+            if (terr_out) terr_out[t] = te;
+        }
+        PK_PROF(tb.prof.flush(S.prof);)
+        return;                                                                    // Game.step is not counted as rollout work
+    }
     if (live) {
         tb.store(S, t);
         tb.store_show(S.show, S.T, t, lds);
@@ -236,6 +234,16 @@ __global__ void __launch_bounds__(PK_TABLE_BLOCK, 2) PK_ROLLOUT_ATTR k_rollout(c
 template <int N>
 __global__ void __launch_bounds__(PK_TABLE_BLOCK, 2) PK_ROLLOUT_ATTR k_rollout_allin(const State *__restrict__ Sp, Hot H, int K, int auto_reset, int park, int slack, int clear_terr) {
     rollout_body<N, true, PK_POLICY_ALLIN>(Sp, H, K, auto_reset, park, slack, clear_terr);
+}
+// Game.step (game.py:621-700) with the caller's actions, and the single-step form of the random-agent rollout (pk_rollout
+// with fused == 0: the state round-trips HBM every step): the same body with one betting pass per look at the parked lanes.
+template <int N>
+__global__ void __launch_bounds__(PK_TABLE_BLOCK, 2) k_step(const State *__restrict__ Sp, Hot H, const int32_t *actions, uint8_t *flags, uint8_t *terr, int park) {
+    rollout_body<N, true, PK_POLICY_EXTERNAL, 1>(Sp, H, 0, 0, park, PK_WAVE, 1, actions, flags, terr);
+}
+template <int N>
+__global__ void __launch_bounds__(PK_TABLE_BLOCK, 2) k_rollout_single(const State *__restrict__ Sp, Hot H, int K, int auto_reset, int park, int slack, int clear_terr) {
+    rollout_body<N, true, PK_POLICY_RANDOM, 1>(Sp, H, K, auto_reset, park, slack, clear_terr);
 }
 template <int N>
 __global__ void __launch_bounds__(PK_TABLE_BLOCK, 2) PK_ROLLOUT_ATTR k_rollout_call(const State *__restrict__ Sp, Hot H, int K, int auto_reset, int park, int slack, int clear_terr) {

@@ -691,7 +691,7 @@ def test_bench_json_contract():
     # self-consistent timing: HIP-event time per launch / steps per launch can never exceed the wall-clock time per step
     assert rf["kernel_ms"] / rf["steps_per_launch"] <= r["ms_per_step"] * 1.0005, (rf["kernel_ms"], rf["steps_per_launch"], r["ms_per_step"])
     st = r["config"]["launch_stats"]
-    assert st["steps"] == 256 * 1536 * 7 and abs(rf["steps_per_launch"] - st["steps"] / st["launches"]) < 1e-9 and rf["launches_timed"] == st["launches"]
+    assert st["steps"] == 256 * 1536 * 7 and abs(rf["steps_per_launch"] - 256 * 1536 / rf["launches_timed"]) < 1e-9 and rf["launches_timed"] * 6 < st["launches"] < rf["launches_timed"] * 8
     # measured HBM traffic (one read + one write of the table state per launch) and SURVEY 8d's algorithmic figure, nested
     assert rf["traffic"] and 0.5 < rf["traffic"] / (65536 * 2 * 290) < 1.5 and rf["traffic_source"].endswith("_summary.json")
     hb = rf["hbm_algorithmic"]
