@@ -235,10 +235,14 @@ def env_mode(args, ctx, device):
     D = 17 + 3 * N
     lib = L.lib()
 
-    class Batch:   # one independent environment batch: its own handle, stream and output buffers
+    # ONE environment object: a pool of B batches of T tables, each batch on its own handle and stream (global table ids:
+    # the pool's tables play what a single handle of B*T tables would)
+    pool = pokerl_amd.VecPokerGameEnvPool(0, num_tables=B * T, num_batches=B, num_players=N, device=device,
+                                          table_id_base=ctx.rank * B * T)
+
+    class Batch:   # the launches of one batch of the pool and its output buffers
         def __init__(self, b):
-            self.env = pokerl_amd.VecPokerGameEnv(0, num_tables=T, num_players=N, device=device,
-                                                  table_id_base=(ctx.rank * B + b) * T)
+            self.env = pool.envs[b]
             self.g = self.env.game
             self.act, self.rew, self.done, self.hand, self.terr, self.obs = (
                 DeviceBuffer(T * 4, device), DeviceBuffer(T * 8, device), DeviceBuffer(T, device),
@@ -310,8 +314,7 @@ def env_mode(args, ctx, device):
             "game_steps_per_s": game_steps / dt, "game_steps_per_env_step": game_steps / max(1, env_steps),
             "ready_fraction_per_launch": env_steps / (B * T * args.steps),
             "tables_with_error_bits_in_last_step": capped}))
-    for b in batches:
-        b.g.close()
+    pool.close()
 
 
 def main():
@@ -438,7 +441,7 @@ def main():
             if per_wave_step and waves:
                 waves_here = waves * (n_local / float(args.tables))
                 valu_rate = per_wave_step * waves_here * kern_steps / (ms_launch * 1e-3)
-                lanes = pmc.get("SQ_THREAD_CYCLES_VALU", 0) / (64.0 * pmc["SQ_ACTIVE_INST_VALU"]) if pmc.get("SQ_ACTIVE_INST_VALU") else None
+                lanes = d.get("lanes_active")
                 ceil_rate, ceil_cyc = mix_ceiling(waves / 1024.0)
                 roof.update({"achieved": valu_rate, "frac": valu_rate / VALU_PEAK_WAVE_INSTS_PER_S,
                              "valu_insts_per_wave_step": per_wave_step, "salu_insts_per_wave_step": d.get("salu_insts_per_wave_step"),

@@ -133,6 +133,9 @@ int pk_get_valid_actions(pk_handle *h, int player, uint8_t *out);
 
 /* State reads (Game attributes). */
 int pk_get_f64(pk_handle *h, int field, double *out /* [T][N] */);
+/* The same into a DEVICE buffer, asynchronous on the handle's stream (e.g. the send buffer of an RCCL all-gather of the
+ * payoffs: pokerl_amd/sharding.py gather_f64). */
+int pk_get_f64_d(pk_handle *h, int field, double *out_d /* [T][N] */);
 int pk_get_min_raise(pk_handle *h, double *out /* [T] minimum_raise_value */);
 int pk_get_table_f64(pk_handle *h, int field /* PK_TF_* */, double *out /* [T] */);
 int pk_get_game_over(pk_handle *h, uint8_t *out /* [T] Game.game_over, pokerl/game.py:317-320 */);

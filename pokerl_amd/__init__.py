@@ -2,13 +2,13 @@
 Game.step/reset, judger and PokerGameEnv.step over thousands of tables).  HIP kernels behind a ctypes C ABI."""
 from .enums import CardRank, CardSuit, HandRanking, PlayerState, PokerMoves, Policy
 from .game import VecGame
-from .envs import VecPokerGameEnv
+from .envs import VecPokerGameEnv, VecPokerGameEnvPool
 from .agents import AllInAgent, CallAgent, PokerAgent, RandomAgent
 from .judger import compare_hands, compare_rankings, eval_hand, eval_hands
-from .sharding import shard_tables
+from .sharding import gather_f64, shard_tables
 from .state_view import Card, StateView
 from ._lib import PokerlHipError, device_count
 
-__all__ = ['VecGame', 'VecPokerGameEnv', 'eval_hand', 'eval_hands', 'compare_rankings', 'compare_hands',
-           'shard_tables', 'Card', 'StateView', 'HandRanking', 'PokerMoves', 'PlayerState', 'CardRank', 'CardSuit', 'Policy',
+__all__ = ['VecGame', 'VecPokerGameEnv', 'VecPokerGameEnvPool', 'eval_hand', 'eval_hands', 'compare_rankings', 'compare_hands',
+           'shard_tables', 'gather_f64', 'Card', 'StateView', 'HandRanking', 'PokerMoves', 'PlayerState', 'CardRank', 'CardSuit', 'Policy',
            'PokerlHipError', 'device_count', 'PokerAgent', 'RandomAgent', 'AllInAgent', 'CallAgent']

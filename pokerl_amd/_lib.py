@@ -29,7 +29,7 @@ SYMBOLS = ["pk_abi_version", "pk_device_count", "pk_last_error", "pk_create", "p
            "pk_get_valid_actions_d", "pk_env_step_d", "pk_env_reset_d", "pk_eval7_d", "pk_make_hands_d", "pk_time_eval7_d",
            "pk_get_serials", "pk_set_serials", "pk_get_table_f64", "pk_get_game_over", "pk_eval_hands_d",
            "pk_pick_actions_d", "pk_flush", "pk_get_owed", "pk_env_step_fused_d", "pk_env_step_async_d", "pk_set_tuning", "pk_get_stream", "pk_set_stream", "pk_wait_event",
-           "pk_record_event", "pk_use_own_stream", "pk_set_coalesce", "pk_get_launch_stats", "pk_env_step_multi_d", "pk_env_end_multi_d"]
+           "pk_record_event", "pk_use_own_stream", "pk_set_coalesce", "pk_get_launch_stats", "pk_env_step_multi_d", "pk_env_end_multi_d", "pk_get_f64_d"]
 
 
 class PokerlHipError(RuntimeError):
@@ -63,6 +63,7 @@ def lib():
     L.pk_step_d.argtypes = [_vp, _vp, _vp, _vp]
     L.pk_get_valid_actions.argtypes = [_vp, C.c_int, _vp]
     L.pk_get_f64.argtypes = [_vp, C.c_int, _vp]
+    L.pk_get_f64_d.argtypes = [_vp, C.c_int, _vp]
     L.pk_get_min_raise.argtypes = [_vp, _vp]
     L.pk_get_player_states.argtypes = [_vp, _vp]
     L.pk_get_i32.argtypes = [_vp, C.c_int, _vp]

@@ -20,6 +20,8 @@ static thread_local std::string g_err;
 struct pk_handle {
     int device = 0, T = 0, N = 0, block = 64, dealer = 0;
     int tpb = 64;   // tables per wavefront (Hot::tpb)
+    int env_tpb = 64;  // ... of the PokerGameEnv kernels (hot_env): see pk_create; knob PK_ENV_TPB
+    Hot hot_env{};
     bool occ3 = false;  // k_rollout_occ3 (registers capped for 3 waves per SIMD) vs k_rollout: see pk_create; knob PK_OCC3
     // lanes parked at end_hand before a wave runs end_block (the kernels look every 4 betting passes); knob PK_PARK /
     // pk_set_tuning.  0 = the measured optimum of each kernel: 28 for k_rollout with random agents (20.9 vs 20.6 G at
@@ -114,10 +116,12 @@ static inline bool bad_policy(int policy) { return policy < 0 || policy >= PK_NU
 static inline uint64_t uniform_seats(int policy) { return 0x1111111111111111ull * (uint64_t)(policy & 15); }
 static inline int table_grid(const pk_handle *h) { return (h->T + h->tpb - 1) / h->tpb; }
 // parking threshold for waves that hold h->tpb tables instead of 64
-static inline int scaled_park(const pk_handle *h, int dflt = 32) {
-    int p = ((h->park > 0 ? h->park : dflt) * h->tpb + 63) / 64;
+static inline int scaled_park(const pk_handle *h, int dflt = 32, int tpb = 0) {
+    int p = ((h->park > 0 ? h->park : dflt) * (tpb > 0 ? tpb : h->tpb) + 63) / 64;
     return p < 1 ? 1 : p;
 }
+static inline int env_grid(const pk_handle *h) { return (h->T + h->env_tpb - 1) / h->env_tpb; }
+static inline int env_park(const pk_handle *h) { return scaled_park(h, 32, h->env_tpb); }
 static inline int flat_grid(size_t n) { return (int)((n + 255) / 256); }
 
 // One fused rollout launch: every table owes k_steps more steps; the launch ends once fewer than `endk` lanes of a
@@ -223,11 +227,20 @@ int pk_create(pk_handle **out, int device, int num_tables, int num_players, cons
         while (tpb > 1 && (long)num_tables <= 1024L * (tpb / 2)) tpb /= 2;
         if (const char *pk = getenv("PK_TPB")) { int v = atoi(pk); if (v >= 1 && v <= 64) tpb = v; }
         h->tpb = tpb;
-        // k_rollout_occ3 (registers capped at 168: three waves per SIMD) only where it was measured to pay: seven seats
-        // from 262 144 tables (+6..10 %), eight from 524 288 (+5..7 %).  Up to six seats k_rollout fits 168 registers by
-        // itself (161 at N = 6); at nine and ten seats the cap spills to scratch and loses 10..35 % at every batch size.
-        h->occ3 = (num_players == 7 && num_tables >= 262144) || (num_players == 8 && num_tables >= 524288);
+        // k_rollout_occ3 (registers capped at 168: three waves per SIMD) only where it was measured to pay: six seats
+        // (k_rollout<6> needs 171 registers since round 3, the capped build 160 without a spill) as soon as a SIMD gets a
+        // third wave, i.e. beyond 131 072 tables; seven seats from 262 144 tables (+6..10 %), eight from 524 288 (+5..7 %).
+        // Up to five seats k_rollout fits 168 registers by itself; at nine and ten seats the cap spills to scratch and
+        // loses 10..35 % at every batch size.
+        h->occ3 = (num_players == 6 && num_tables > 131072) || (num_players == 7 && num_tables >= 262144) ||
+                  (num_players == 8 && num_tables >= 524288);
         if (const char *pk = getenv("PK_OCC3")) h->occ3 = atoi(pk) != 0;
+    }
+    {   // The env kernels are bound by the tail of the slowest table of a wave (a busted seat 0 waits for the end of the game),
+        // not by issue slots: half-populated waves halve that tail and bring a second wave to each SIMD
+        // (profiles/r03_env_tpb_sweep.txt)
+        h->env_tpb = h->tpb;
+        if (const char *pk = getenv("PK_ENV_TPB")) { int v = atoi(pk); if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) h->env_tpb = v; }
     }
     if (const char *pk = getenv("PK_PARK")) { int v = atoi(pk); if (v >= 1 && v <= 64) h->park = v; }
     if (const char *pk = getenv("PK_ENDK")) { int v = atoi(pk); if (v >= 1 && v <= 64) h->endk = v; }
@@ -305,6 +318,7 @@ int pk_create(pk_handle **out, int device, int num_tables, int num_players, cons
         h->hot.key0 = S.key0; h->hot.key1 = S.key1; h->hot.table_id_base = table_id_base; h->hot.T = num_tables; h->hot.tpb = h->tpb; h->hot.prof = S.prof;
         h->hot.start_uniform = S.start_credits[0]; h->hot.start_is_uniform = 1;
         for (int i = 1; i < num_players; ++i) if (S.start_credits[i] != S.start_credits[0]) h->hot.start_is_uniform = 0;
+        h->hot_env = h->hot; h->hot_env.tpb = h->env_tpb;
         if (hipMemcpyAsync(d_start, S.start_credits, PK_MAX_PLAYERS * 8, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
             hipMemcpyAsync(h->d_S, &h->S, sizeof(State), hipMemcpyHostToDevice, h->stream) != hipSuccess ||
             hipMemcpyAsync(S.seat_states, ss.data(), T * 8, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
@@ -458,6 +472,17 @@ int pk_get_f64(pk_handle *h, int field, double *out) {
     });
 }
 
+int pk_get_f64_d(pk_handle *h, int field, double *out_d) {
+    if (!h || !out_d || field < 0 || field > 3) return h ? h->fail(PK_E_INVALID_ARG, "pk_get_f64_d: bad argument") : PK_E_INVALID_ARG;
+    ON_DEVICE(h);
+    FLUSH(h);
+    const double *src = field == PK_F_CREDITS ? h->S.credits : field == PK_F_BETS ? h->S.bets : field == PK_F_PENDING_BETS ? h->S.pending : h->S.payoffs;
+    size_t n = (size_t)h->T * h->N;
+    hipLaunchKernelGGL(k_export_f64, dim3(flat_grid(n)), dim3(256), 0, h->stream, src, h->T, h->N, out_d);
+    HIPCHK(h, hipGetLastError());
+    return PK_OK;
+}
+
 int pk_get_table_f64(pk_handle *h, int field, double *out) {
     if (!h || !out || field < 0 || field > PK_TF_MIN_RAISE) return h ? h->fail(PK_E_INVALID_ARG, "pk_get_table_f64: bad field") : PK_E_INVALID_ARG;
     return export_to_host(h, out, (size_t)h->T * 8, [&] {
@@ -565,7 +590,7 @@ int pk_env_reset_d(pk_handle *h, const uint8_t *mask_d, int opp_policy) {
     if (!h || bad_policy(opp_policy)) return h ? h->fail(PK_E_INVALID_ARG, "pk_env_reset_d: bad argument") : PK_E_INVALID_ARG;
     ON_DEVICE(h);
     FLUSH(h);
-    DISPATCH_N(h, k_env_reset, table_grid(h), (const State *)h->d_S, h->hot, mask_d, uniform_seats(opp_policy), scaled_park(h));
+    DISPATCH_N(h, k_env_reset, env_grid(h), (const State *)h->d_S, h->hot_env, mask_d, uniform_seats(opp_policy), env_park(h));
     HIPCHK(h, hipGetLastError());
     return PK_OK;
 }
@@ -576,7 +601,7 @@ int pk_env_step_d(pk_handle *h, const int32_t *actions_d, int opp_policy, double
         return h ? h->fail(PK_E_INVALID_ARG, "pk_env_step_d: bad argument") : PK_E_INVALID_ARG;
     ON_DEVICE(h);
     FLUSH(h);
-    DISPATCH_N(h, k_env_step, table_grid(h), (const State *)h->d_S, h->hot, actions_d, -1, uniform_seats(opp_policy), 0, reward_d, done_d, hand_d, terr_d, (double *)nullptr, scaled_park(h));
+    DISPATCH_N(h, k_env_step, env_grid(h), (const State *)h->d_S, h->hot_env, actions_d, -1, uniform_seats(opp_policy), 0, reward_d, done_d, hand_d, terr_d, (double *)nullptr, env_park(h));
     HIPCHK(h, hipGetLastError());
     return PK_OK;
 }
@@ -588,8 +613,8 @@ int pk_env_step_fused_d(pk_handle *h, const int32_t *actions_d, int seat0_policy
         return h ? h->fail(PK_E_INVALID_ARG, "pk_env_step_fused_d: bad argument") : PK_E_INVALID_ARG;
     ON_DEVICE(h);
     FLUSH(h);
-    DISPATCH_N(h, k_env_step, table_grid(h), (const State *)h->d_S, h->hot, actions_d, actions_d ? -1 : seat0_policy, uniform_seats(opp_policy),
-               auto_reset ? 1 : 0, reward_d, done_d, hand_d, terr_d, obs_d, scaled_park(h));
+    DISPATCH_N(h, k_env_step, env_grid(h), (const State *)h->d_S, h->hot_env, actions_d, actions_d ? -1 : seat0_policy, uniform_seats(opp_policy),
+               auto_reset ? 1 : 0, reward_d, done_d, hand_d, terr_d, obs_d, env_park(h));
     HIPCHK(h, hipGetLastError());
     return PK_OK;
 }
@@ -607,8 +632,8 @@ int pk_env_step_async_d(pk_handle *h, const int32_t *actions_d, int seat0_policy
     h->env_seat0 = s0; h->env_opp = opp_policy; h->env_auto = au;
     int rc = flush_rollout(h);
     if (rc) return rc;
-    DISPATCH_N(h, k_env_step_async, table_grid(h), (const State *)h->d_S, h->hot, actions_d, actions_d ? -1 : seat0_policy, uniform_seats(opp_policy),
-               auto_reset ? 1 : 0, reward_d, done_d, hand_d, terr_d, obs_d, scaled_park(h), ready_d, max_passes > 0 ? max_passes : 0);
+    DISPATCH_N(h, k_env_step_async, env_grid(h), (const State *)h->d_S, h->hot_env, actions_d, actions_d ? -1 : seat0_policy, uniform_seats(opp_policy),
+               auto_reset ? 1 : 0, reward_d, done_d, hand_d, terr_d, obs_d, env_park(h), ready_d, max_passes > 0 ? max_passes : 0);
     HIPCHK(h, hipGetLastError());
     h->env_pending = max_passes > 0;
     h->env_multi = false;
@@ -642,8 +667,8 @@ int pk_env_step_multi_d(pk_handle *h, const int32_t *actions_d, const uint8_t *r
     rc = flush_rollout(h);
     if (rc) return rc;
     const int pol0 = PK_SEAT_POLICY(seat_policies, 0);
-    DISPATCH_N(h, k_env_step_multi, table_grid(h), (const State *)h->d_S, h->hot, actions_d, pol0 == PK_POLICY_EXTERNAL ? -1 : pol0, seat_policies,
-               au, reward_d, done_d, hand_d, terr_d, obs_d, scaled_park(h), ready_d, max_passes > 0 ? max_passes : 0, reset_d, who_d, 0);
+    DISPATCH_N(h, k_env_step_multi, env_grid(h), (const State *)h->d_S, h->hot_env, actions_d, pol0 == PK_POLICY_EXTERNAL ? -1 : pol0, seat_policies,
+               au, reward_d, done_d, hand_d, terr_d, obs_d, env_park(h), ready_d, max_passes > 0 ? max_passes : 0, reset_d, who_d, 0);
     HIPCHK(h, hipGetLastError());
     // a table may be waiting for the caller's action for an external seat even after a drain: in flight until pk_env_end_multi_d
     h->env_pending = max_passes > 0 || ext;
@@ -659,8 +684,8 @@ int pk_env_end_multi_d(pk_handle *h) {
     const int pol0 = PK_SEAT_POLICY(h->env_seats, 0);
     // drain; what is still in flight afterwards waits for an external seat's action between two Game.steps and is abandoned.
     // Outputs of steps that return during this drain go to the handle's own staging buffers, i.e. are dropped.
-    DISPATCH_N(h, k_env_step_multi, table_grid(h), (const State *)h->d_S, h->hot, (const int32_t *)nullptr, pol0 == PK_POLICY_EXTERNAL ? -1 : pol0, h->env_seats,
-               h->env_auto, h->d_reward, h->d_done, h->d_handf, h->d_terr, (double *)nullptr, scaled_park(h), h->d_flags, 0, (const uint8_t *)nullptr, h->d_mask, 1);
+    DISPATCH_N(h, k_env_step_multi, env_grid(h), (const State *)h->d_S, h->hot_env, (const int32_t *)nullptr, pol0 == PK_POLICY_EXTERNAL ? -1 : pol0, h->env_seats,
+               h->env_auto, h->d_reward, h->d_done, h->d_handf, h->d_terr, (double *)nullptr, env_park(h), h->d_flags, 0, (const uint8_t *)nullptr, h->d_mask, 1);
     HIPCHK(h, hipGetLastError());
     h->env_pending = false; h->env_multi = false;
     return PK_OK;

@@ -121,6 +121,14 @@ __device__ __forceinline__ double np_sum(const double (&a)[N]) {
     }
 }
 
+// byte 0 of x in all four bytes (one v_perm_b32)
+__device__ __forceinline__ uint32_t rep4(uint32_t x) {
+#ifdef PK_HOST_SIM
+    return (x & 0xffu) * 0x01010101u;
+#else
+    return __builtin_amdgcn_perm(x, x, 0u);
+#endif
+}
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
@@ -752,22 +760,31 @@ struct Table {
         PK_END
         hand_serial += 1;
         // Lehmer decode ("c_i-th card not yet dealt") without arrays: packed bytes (bit 7 kept set), processed from the
-        // last draw to the first; for each earlier-processed (later-drawn) byte b: b += (b >= c_i).
+        // last draw to the first; for each earlier-processed (later-drawn) byte b: b += (b >= c_i).  A word operation costs
+        // four instructions whatever the number of live bytes in it, so a LAST word that holds a single card (K = 4k + 1:
+        // six seats, K = 17) is kept as a plain register instead: compare + add-with-carry, two instructions per step.
+        constexpr bool LONE = (K % 4) == 1 && K > 1;
+        constexpr int WP = LONE ? W - 1 : W;           // packed words
         uint32_t a[W];
         PK_FOR(w, W)
             uint32_t v = 0x80808080u;
             PK_FOR(j, 4) if constexpr (4 * w + j < K) v |= c[4 * w + j] << (8 * j); PK_END
             a[w] = v;
         PK_END
+        uint32_t lone = LONE ? c[K - 1] : 0u;
         PK_FOR(ii, K)
             constexpr int i = K - 1 - ii;
-            uint32_t bc = c[i] | (c[i] << 8); bc |= bc << 16;
-            PK_FOR(w, W)
-                if constexpr (w > i / 4) a[w] += ((a[w] - bc) & 0x80808080u) >> 7;
-                else if constexpr (w == i / 4 && (i % 4) != 3)
-                    a[w] += ((a[w] - bc) & 0x80808080u & (0x80808080u << (8 * ((i % 4) + 1)))) >> 7;
-            PK_END
+            if constexpr (!(LONE && i == K - 1)) {
+                const uint32_t bc = rep4(c[i]);                                    // the draw in all four bytes
+                if constexpr (LONE) lone += (lone >= c[i]) ? 1u : 0u;
+                PK_FOR(w, WP)
+                    if constexpr (w > i / 4) a[w] += ((a[w] - bc) & 0x80808080u) >> 7;
+                    else if constexpr (w == i / 4 && (i % 4) != 3)
+                        a[w] += ((a[w] - bc) & 0x80808080u & (0x80808080u << (8 * ((i % 4) + 1)))) >> 7;
+                PK_END
+            }
         PK_END
+        if constexpr (LONE) a[W - 1] = 0x80808080u | lone;
         PK_FOR(w, W)  // canonical index k -> Card.value ((k%4)<<4)|(k//4), cards.py:77
             uint32_t idx = a[w] & 0x3f3f3f3fu;
             cards[w] = ((idx & 0x03030303u) << 4) | ((idx >> 2) & 0x0f0f0f0fu);

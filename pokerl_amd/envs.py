@@ -207,3 +207,45 @@ class VecPokerGameEnv:
         return (b['ready'].download(np.uint8, T) != 0, b['obs'].download(np.float64, T * D).reshape(T, D),
                 b['rew'].download(np.float64, T), b['done'].download(np.uint8, T) != 0,
                 b['hand'].download(np.uint8, T) != 0, b['terr'].download(np.uint8, T))
+
+
+class VecPokerGameEnvPool:
+    """ONE environment object over `num_batches` independent batches of tables, each with its own handle and HIP stream.
+
+    Why: a bounded launch of pk_env_step_async_d ends with a tail (the last waves run alone), and launches of one handle are
+    serialised on its stream, so ONE batch of 65 536 tables delivers 0.88 G env.step/s while FOUR such batches whose
+    launches overlap deliver 2.7 G -- a learner works on the batch whose launch has finished while the
+    others run.  Tables keep their GLOBAL ids (table_id_base), so the pool's tables play exactly the trajectories of one
+    handle holding all of them (RNG spec: streams are keyed by the global table id).
+
+    `envs[b]` is an ordinary VecPokerGameEnv over tables `slices[b]`; reset() / step() below are the synchronous
+    convenience forms over the whole pool, the asynchronous device-pointer calls are made per batch (envs[b].step_async_d)."""
+
+    def __init__(self, agents=Policy.RANDOM, num_tables=1, num_batches=4, **game_config):
+        base = int(game_config.pop('table_id_base', 0))
+        num_batches = max(1, min(int(num_batches), int(num_tables)))
+        per = -(-int(num_tables) // num_batches)
+        self.slices = [slice(b * per, min(int(num_tables), (b + 1) * per)) for b in range(num_batches)]
+        self.slices = [s for s in self.slices if s.stop > s.start]
+        self.envs = [VecPokerGameEnv(agents, num_tables=s.stop - s.start, table_id_base=base + s.start, **game_config)
+                     for s in self.slices]
+        self.num_tables = int(num_tables)
+
+    def __len__(self):
+        return len(self.envs)
+
+    def reset(self):
+        return np.concatenate([e.reset() for e in self.envs])
+
+    def step(self, actions, strict=True):
+        a = np.ascontiguousarray(np.broadcast_to(np.asarray(actions), (self.num_tables,)))
+        outs = [e.step(a[s], strict=strict) for e, s in zip(self.envs, self.slices)]
+        return tuple(np.concatenate([o[i] for o in outs]) for i in range(len(outs[0])))
+
+    def sync(self):
+        for e in self.envs:
+            e.game.sync()
+
+    def close(self):
+        for e in self.envs:
+            e.close()

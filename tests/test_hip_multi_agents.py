@@ -270,3 +270,27 @@ def test_multi_agent_bounded_launches_deliver_the_synchronous_sequences(O, R):
             assert same, (T, N, k)
         env.end_multi()
         env.close()
+
+
+def test_env_pool_plays_the_single_handle_trajectories(O):
+    """VecPokerGameEnvPool: several batches (own handle + stream each) behind one object; with global table ids the pool's
+    tables play exactly what one handle holding all of them -- and the oracle -- play."""
+    import pokerl_amd
+    T, N = 3000, 5
+    pool = pokerl_amd.VecPokerGameEnvPool(pokerl_amd.Policy.RANDOM, num_tables=T, num_batches=4, num_players=N, seed=11, table_id_base=500)
+    assert len(pool) == 4 and sum(s.stop - s.start for s in pool.slices) == T
+    o = O.OracleGame(T, N, seed=11, table_id_base=500)
+    obs = pool.reset(); o.env_reset(None, 0)
+    assert obs.shape == (T, 17 + 3 * N)
+    for s in range(30):
+        a = o.pick_actions(0)
+        ro, do, ho, eo = o.env_step(a, 0)
+        obs, r, d, h, e = pool.step(a, strict=False)
+        assert GU.bits_equal(ro, r) and np.array_equal(do != 0, d) and np.array_equal(ho != 0, h) and np.array_equal(eo, e), s
+        if do.any():
+            o.env_reset(do, 0)
+            for env, sl in zip(pool.envs, pool.slices):
+                if do[sl].any():
+                    env.reset(do[sl])
+    assert GU.bits_equal(o.f64(0), np.concatenate([e.game.credits for e in pool.envs]))
+    pool.close()

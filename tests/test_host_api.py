@@ -128,6 +128,45 @@ def test_bench_aggregation_gloo_world8(tmp_path):
     assert r["seconds"] == 8.0                                  # MAX over ranks (rank 7: 1 + 7 s)
 
 
+GATHER_WORKER = r'''
+import os, sys, json
+sys.path.insert(0, %r)
+import numpy as np
+import torch.distributed as dist
+from pokerl_amd import sharding
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+n_local, base = sharding.shard_tables(1001, rank, world)          # uneven shards: 334 / 334 / 333
+
+class FakeGame:                                                   # the host side of gather_f64 needs only these
+    num_tables, num_players, device = n_local, 3, 0
+    def _f64(self, field):
+        t = np.arange(base, base + n_local, dtype=np.float64)[:, None]
+        return t * 10 + np.arange(3)[None, :] + field * 0.25
+
+out = sharding.gather_f64(FakeGame(), 3, dist)
+if rank == 0:
+    t = np.arange(1001, dtype=np.float64)[:, None]
+    print(json.dumps(dict(ok=bool(np.array_equal(out, t * 10 + np.arange(3)[None, :] + 0.75)), shape=list(out.shape))))
+dist.destroy_process_group()
+'''
+
+
+def test_optional_payoff_gather_gloo_world3(tmp_path):
+    """north_star's optional payoff gather (no collective on the step path): every rank receives the field of all tables in
+    global table order; gloo ranks exchange host arrays (RCCL ranks exchange device buffers filled by pk_get_f64_d)."""
+    script = tmp_path / "g.py"
+    script.write_text(GATHER_WORKER % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", OMP_NUM_THREADS="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3",
+                          "--master-addr", "127.0.0.1", "--master-port", "29547", str(script)],
+                         capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    import json
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert r["ok"] and r["shape"] == [1001, 3]
+
+
 def test_state_view_mirror_fields_and_pickle():
     """StateView / Card host mirrors (reference game.py:39-240, cards.py:4-72): built from a dense observation row."""
     import pickle

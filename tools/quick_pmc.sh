@@ -12,7 +12,10 @@ rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_ACTIVE_IN
 python3 - $OUT <<'PY'
 import csv, glob, sys, collections
 out = sys.argv[1]
-f = glob.glob(out + "/pmc/*/*_counter_collection.csv")[0]
+fs = glob.glob(out + "/pmc/*/*_counter_collection.csv")
+if not fs:
+    sys.exit("pmc failed: no counter_collection CSV under %s/pmc (rejected counter set? see %s/pmc.log)" % (out, out))
+f = fs[0]
 agg = collections.defaultdict(list)
 for r in csv.DictReader(open(f)):
     if "k_rollout" in r["Kernel_Name"]:

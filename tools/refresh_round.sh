@@ -1,30 +1,26 @@
 #!/bin/bash
-# Runs ON THE GPU BOX: every profile and bench line that DESIGN.md section 6 quotes, for round tag $1 (e.g. r02).
+# Runs ON THE GPU BOX: every profile and bench line that DESIGN.md section 6 quotes, for round tag $1 (e.g. r03).
 # Afterwards, locally:  tools/refresh_round_local.sh $1     (delete gpurun_out/prof_$1_* locally BEFORE the gpurun call)
 set -u
 R=$1
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 cd $ROOT
-tools/profile_gpu.sh ${R}_65536x6_k4096 4096 --steps 4096 --warmup 512
 tools/profile_gpu.sh ${R}_65536x6_k20 20 --steps 20 --warmup 5
+tools/profile_gpu.sh ${R}_65536x6_k4096 4096 --steps 4096 --warmup 512
 PK_PLAYERS=9 PK_POLICY=allin tools/profile_gpu.sh ${R}_65536x9_allin_k4096 4096 --steps 4096 --warmup 512 --players 9 --policy allin
 PK_TABLES=4096 PK_PLAYERS=2 tools/profile_gpu.sh ${R}_4096x2_k4096 4096 --steps 4096 --warmup 512 --tables 4096 --players 2
 cd $ROOT
-python -m pokerl_amd.build --prof > /dev/null 2>&1
-python tools/block_profile.py 6 0 > gpurun_out/blockprof_${R}_n6.txt 2>&1
-python tools/block_profile.py 9 1 > gpurun_out/blockprof_${R}_n9_allin.txt 2>&1
-python -m pokerl_amd.build --counts > /dev/null 2>&1
-PK_COUNTS=1 python tools/block_profile.py 6 0 2>&1 | tail -1 >> gpurun_out/blockprof_${R}_n6.txt
 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${R}_bench_driver.json 2> gpurun_out/${R}_bench_driver.err
 python bench.py > gpurun_out/${R}_bench_65536x6.json 2>/dev/null
+python bench.py --gpus 1 --steps 20 --warmup 5 --coalesce 0 --no-cpu-baseline --no-evaluator > gpurun_out/${R}_bench_driver_nocoalesce.json 2>/dev/null
 python bench.py --players 9 --policy allin --no-cpu-baseline --no-evaluator > gpurun_out/${R}_bench_65536x9_allin.json 2>/dev/null
 python bench.py --tables 4096 --players 2 --no-cpu-baseline --no-evaluator > gpurun_out/${R}_bench_4096x2.json 2>/dev/null
 python bench.py --tables 1048576 --no-cpu-baseline --no-evaluator --samples 3 --min-steps 8192 > gpurun_out/${R}_bench_1048576x6.json 2>/dev/null
 python bench.py --unfused --steps 512 --warmup 64 --no-cpu-baseline --no-evaluator --samples 3 > gpurun_out/${R}_bench_65536x6_unfused.json 2>/dev/null
 python bench.py --mode env --steps 200 --warmup 20 2>/dev/null | tail -1 > gpurun_out/${R}_bench_env.json
-python bench.py --mode env --env-unfused --steps 200 --warmup 20 2>/dev/null | tail -1 > gpurun_out/${R}_bench_env_unfused.json
 python bench.py --mode env --steps 200 --warmup 20 --env-batches 4 2>/dev/null | tail -1 > gpurun_out/${R}_bench_env_sync_batches4.json
 python bench.py --mode env --steps 2000 --warmup 200 --env-async 8 2>/dev/null | tail -1 > gpurun_out/${R}_bench_env_async8_batches1.json
 python bench.py --mode env --steps 2000 --warmup 200 --env-async 8 --env-batches 4 2>/dev/null | tail -1 > gpurun_out/${R}_bench_env_async8_batches4.json
 python tools/launch_overhead.py > gpurun_out/${R}_launch_overhead.txt 2>&1
+for c in 128 256 512 1024 2048; do echo "coalesce $c: $(python bench.py --gpus 1 --steps 20 --warmup 5 --coalesce $c --no-cpu-baseline --no-evaluator --samples 3 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('%.2f G  %s' % (r['value']/1e9, r['config']['launch_stats']))")"; done > gpurun_out/${R}_coalesce_sweep.txt 2>&1
 echo refreshed $R

@@ -7,21 +7,21 @@ for t in ${R}_65536x6_k4096 ${R}_65536x6_k20 ${R}_65536x9_allin_k4096 ${R}_4096x
   python - <<PY
 import json
 d = json.load(open('profiles/${t}_summary.json'))
-keys = ('launches_full', 'avg_full_launch_ms', 'vgpr', 'lds_bytes', 'hbm_traffic_bytes_per_launch', 'valu_insts_per_wave_step',
+keys = ('launches_total', 'avg_launch_ms', 'vgpr', 'lds_bytes', 'hbm_traffic_bytes_per_launch', 'valu_insts_per_wave_step',
         'salu_insts_per_wave_step', 'valu_issue_frac_of_peak', 'lanes_active', 'wait_any_frac_of_wave_cycles')
 print('$t', {k: (round(v, 4) if isinstance(v, float) else v) for k, v in d.items() if k in keys})
 PY
 done
-cp gpurun_out/blockprof_${R}_n6.txt gpurun_out/blockprof_${R}_n9_allin.txt profiles/
 cp gpurun_out/${R}_launch_overhead.txt profiles/${R}_launch_overhead.txt
-for f in driver 65536x6 65536x9_allin 4096x2 1048576x6 65536x6_unfused env env_unfused env_sync_batches4 env_async8_batches1 env_async8_batches4; do
+cp gpurun_out/${R}_coalesce_sweep.txt profiles/${R}_coalesce_sweep.txt
+for f in driver driver_nocoalesce 65536x6 65536x9_allin 4096x2 1048576x6 65536x6_unfused env env_sync_batches4 env_async8_batches1 env_async8_batches4; do
   tail -1 gpurun_out/${R}_bench_$f.json > profiles/${R}_bench_$f.json
   python - <<PY
 import json
 d = json.load(open('profiles/${R}_bench_$f.json'))
 r = d.get('roofline') or {}
-print('$f', 'value %.3g' % d['value'], 'ms/step %.5f' % d['ms_per_step'], 'kern_ms', r.get('kernel_ms'), 'hbm frac', r.get('frac'),
-      'valu', {k: (round(v, 4) if isinstance(v, float) else v) for k, v in (r.get('valu') or {}).items() if k in ('frac', 'lanes_active', 'valu_insts_per_wave_step')},
+print('$f', 'value %.3g' % d['value'], 'ms/step %.5f' % d['ms_per_step'], 'kern_ms', r.get('kernel_ms'), 'frac', r.get('frac'),
+      'bound', r.get('bound'), 'steps/launch', r.get('steps_per_launch'), 'valu/wave-step', r.get('valu_insts_per_wave_step'), 'lanes', r.get('lanes_active'), 'ceil', (r.get('ceiling_mix') or {}).get('frac_of_ceiling'),
       'evals/s', d.get('hand_evals_per_s'), 'cpu', (d.get('cpu_baseline') or {}).get('value'), 'game_steps/s', d.get('game_steps_per_s'))
 PY
 done

@@ -1,6 +1,12 @@
 #!/usr/bin/env python3
-"""Distils gpurun_out/prof_<tag>/ (rocprofv3 kernel trace + separate PMC passes, made by tools/profile_gpu.sh) into
-profiles/<tag>_*.  usage: tools/summarize_profile.py <tag> [kernel substring]"""
+"""Distils gpurun_out/prof_<tag>/ (rocprofv3 kernel trace + separate PMC passes of ONE bench.py command, made by
+tools/profile_gpu.sh) into profiles/<tag>_kernel_stats.csv + profiles/<tag>_summary.json.
+usage: tools/summarize_profile.py <tag> [kernel substring]
+
+Asynchronous rollout calls are merged on the host into launches of varying length (pk_set_coalesce), so nothing here
+assumes "the launch": every pass's own bench line says how many launches and steps it made (config.launch_stats, plus the
+launches before the timed region), and every figure is either a SUM over all launches of the kernel divided by those
+steps (per wave-step) or by those launches (per mean launch)."""
 import collections
 import csv
 import glob
@@ -16,63 +22,84 @@ src = os.path.join(root, "gpurun_out", "prof_" + tag)
 dst = os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
 
+
+def bench_line(log):
+    """(launches, steps) of ALL rollout launches of the run that wrote `log` (timed region + what came before it)."""
+    for line in reversed(open(log).read().splitlines()):
+        if line.startswith("{") and '"launch_stats"' in line:
+            r = json.loads(line)
+            a, b = r["config"]["launch_stats"], r["config"]["launch_stats_before_timed_region"]
+            return a["launches"] + b["launches"], a["steps"] + b["steps"], r
+    return None, None, None
+
+
 stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
 shutil.copy(stats, os.path.join(dst, tag + "_kernel_stats.csv"))
 trace = glob.glob(os.path.join(src, "trace", "*", "*_kernel_trace.csv"))[0]
 rows = [r for r in csv.DictReader(open(trace)) if kname in r["Kernel_Name"]]
 durs = sorted((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in rows)
-# the launches of the profiled length: with few long launches they are the longest ones; with hundreds of short ones
-# (--steps 20) they are the bulk, and the longest are the cold first launch / the flushes of deferred work
-med = durs[len(durs) // 2]
-big = [d for d in durs if 0.6 * med <= d <= 1.6 * med] if len(durs) >= 50 else [d for d in durs if d > 0.5 * durs[-1]]
-lo, hi = big[0], big[-1]
+n_l, n_s, line = bench_line(os.path.join(src, "trace.log"))
+waves = int(rows[0]["Grid_Size_X"]) // int(rows[0]["Workgroup_Size_X"])
 summary = {
-    "tag": tag, "kernel": rows[0]["Kernel_Name"], "launches_total": len(durs), "launches_full": len(big),
-    "avg_full_launch_ms": sum(big) / len(big) / 1e6, "min_full_launch_ms": big[0] / 1e6, "max_full_launch_ms": big[-1] / 1e6,
+    "tag": tag, "kernel": rows[0]["Kernel_Name"], "launches_total": len(durs),
+    "avg_launch_ms": sum(durs) / len(durs) / 1e6, "min_launch_ms": durs[0] / 1e6, "max_launch_ms": durs[-1] / 1e6,
+    "median_launch_ms": durs[len(durs) // 2] / 1e6,
     "vgpr": int(rows[0]["VGPR_Count"]), "agpr": int(rows[0]["Accum_VGPR_Count"]), "sgpr": int(rows[0]["SGPR_Count"]),
     "lds_bytes": int(rows[0]["LDS_Block_Size"]), "scratch_bytes": int(rows[0]["Scratch_Size"]),
-    "workgroup": int(rows[0]["Workgroup_Size_X"]), "grid": int(rows[0]["Grid_Size_X"]),
+    "workgroup": int(rows[0]["Workgroup_Size_X"]), "grid": int(rows[0]["Grid_Size_X"]), "waves_per_launch": waves,
 }
-# workload of the profiled command (tools/profile_gpu.sh passes it through PK_PROFILE_WORKLOAD)
 wl = os.path.join(src, "workload.json")
 if os.path.exists(wl):
     summary["workload"] = json.load(open(wl))
-counters = {}
-for f in sorted(glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv"))):
-    agg = collections.defaultdict(list)
-    for r in csv.DictReader(open(f)):
+if n_l:
+    assert n_l == len(durs), ("the bench line's launch count differs from the trace", n_l, len(durs))
+    summary["steps_total"] = n_s
+    summary["workload"]["steps_per_launch"] = n_s / float(n_l)          # mean over ALL launches of the traced run
+    summary["us_per_step_of_kernel_time"] = sum(durs) / 1e3 / n_s
+    summary["bench_line_of_the_traced_run"] = {k: line[k] for k in ("value", "ms_per_step", "steps", "warmup")}
+    summary["bench_line_of_the_traced_run"]["kernel"] = line["config"]["kernel"]
+counters, per_step = {}, {}
+for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
+    if not os.path.isdir(d):
+        continue
+    files = glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))
+    if not files:
+        continue
+    pl, ps, _ = bench_line(d + ".log")
+    ptr = glob.glob(os.path.join(d, "*", "*_kernel_trace.csv"))
+    pass_ns = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(ptr[0])) if kname in r["Kernel_Name"]) if ptr else 0
+    agg = collections.defaultdict(float)
+    cnt = collections.defaultdict(int)
+    for r in csv.DictReader(open(files[0])):
         if kname in r["Kernel_Name"]:
-            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+            agg[r["Counter_Name"]] += float(r["Counter_Value"])
+            cnt[r["Counter_Name"]] += 1
     for k, v in agg.items():
-        v = sorted(v)
-        if k in ("FETCH_SIZE", "WRITE_SIZE"):           # one read + one write of the table state whatever the launch
-            full = [v[len(v) // 2]]                     # length: the median (a pass now and then reports a 4x outlier)
-        elif len(v) >= 50:                                # many short launches: the bulk around the median
-            m = v[len(v) // 2]
-            full = [x for x in v if 0.5 * m <= x <= 2.0 * m] or v
-        else:
-            full = [x for x in v if x > 0.5 * v[-1]]
-        counters[k] = sum(full) / len(full)             # per launch of the profiled length
+        counters[k] = v / cnt[k]                        # per mean launch of THAT pass
+        if ps:
+            per_step[k] = v / ps                        # per step of every table (sum over the 1 024 waves)
+        if k == "GRBM_GUI_ACTIVE" and pass_ns:          # summed over the 8 XCDs (guide, DVFS): clock of that pass
+            summary["effective_clock_GHz"] = v / 8.0 / pass_ns
 summary["pmc_per_full_launch"] = counters
+summary["pmc_per_step"] = per_step
 if "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
     # guides/MI355X_MICROARCH.md, HBM: FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports 1/2 of the bytes
     # of a coalesced streaming read (calibrated there for 16 B/lane; our loads are 8 and 4 B/lane -> treat as an upper
     # estimate); WRITE_SIZE reads exactly.
     summary["hbm_traffic_bytes_per_launch"] = (2.0 * counters["FETCH_SIZE"] + counters["WRITE_SIZE"]) * 1024.0
-    summary["hbm_traffic_note"] = "(2*FETCH_SIZE + WRITE_SIZE) KiB: FETCH_SIZE doubled per the guide's gfx950 correction"
-if "SQ_INSTS_VALU" in counters and "SQ_WAVES" in counters:
-    summary["valu_insts_per_wave"] = counters["SQ_INSTS_VALU"] / counters["SQ_WAVES"]
-    summary["salu_insts_per_wave"] = counters.get("SQ_INSTS_SALU", 0) / counters["SQ_WAVES"]
-    k = summary.get("workload", {}).get("steps_per_launch")
-    if k:
-        summary["valu_insts_per_wave_step"] = summary["valu_insts_per_wave"] / k
-        summary["salu_insts_per_wave_step"] = summary["salu_insts_per_wave"] / k
-        # chip VALU issue: wave-instructions per second vs 256 CU x 4 SIMD x 2.4 GHz / 2 cycles (guides/MI355X_MICROARCH.md)
-        rate = counters["SQ_INSTS_VALU"] / (summary["avg_full_launch_ms"] * 1e-3)
-        summary["valu_issue_rate_wave_insts_per_s"] = rate
-        summary["valu_issue_frac_of_peak"] = rate / (256 * 4 * 2.4e9 / 2)
-if "SQ_THREAD_CYCLES_VALU" in counters and counters.get("SQ_ACTIVE_INST_VALU"):
-    summary["lanes_active"] = counters["SQ_THREAD_CYCLES_VALU"] / (64.0 * counters["SQ_ACTIVE_INST_VALU"])
+    summary["hbm_traffic_note"] = "(2*FETCH_SIZE + WRITE_SIZE) KiB per mean launch: FETCH_SIZE doubled per the guide's gfx950 correction"
+if "SQ_INSTS_VALU" in per_step:
+    summary["valu_insts_per_wave_step"] = per_step["SQ_INSTS_VALU"] / waves
+    summary["salu_insts_per_wave_step"] = per_step.get("SQ_INSTS_SALU", 0) / waves
+    summary["lds_insts_per_wave_step"] = per_step.get("SQ_INSTS_LDS", 0) / waves
+    # chip VALU issue: wave-instructions per second vs 256 CU x 4 SIMD x 2.4 GHz / 2 cycles (guides/MI355X_MICROARCH.md)
+    rate = per_step["SQ_INSTS_VALU"] * n_s / (sum(durs) * 1e-9)      # instructions per step x the traced run's steps per second of kernel time
+    summary["valu_issue_rate_wave_insts_per_s"] = rate
+    summary["valu_issue_frac_of_peak"] = rate / (256 * 4 * 2.4e9 / 2)
+if "SQ_WAVE_CYCLES" in per_step:
+    summary["wave_cycles_per_wave_step_x4"] = 4.0 * per_step["SQ_WAVE_CYCLES"] / waves      # the counter ticks in quad-cycles
+if "SQ_THREAD_CYCLES_VALU" in per_step and per_step.get("SQ_ACTIVE_INST_VALU"):   # two passes: compare per STEP, not per launch
+    summary["lanes_active"] = per_step["SQ_THREAD_CYCLES_VALU"] / (64.0 * per_step["SQ_ACTIVE_INST_VALU"])
 if "SQ_WAVES" in counters:
     summary["waves_per_simd"] = counters["SQ_WAVES"] / 1024.0
 if "SQ_ACTIVE_INST_VALU" in counters and "SQ_WAVE_CYCLES" in counters:
