@@ -118,13 +118,18 @@ VALU_PEAK_WAVE_INSTS_PER_S = 256 * 4 * 2.4e9 / 2.0   # 256 CUs x 4 SIMDs, one wa
 #   (guides/MI355X_MICROARCH.md: "v_fma_f32 (wave64) 2 cyc (SIMD-32); one wave alone: 4")
 
 
+# Cycles per wave-instruction measured by tools/microbench/valu_rates.hip on MI355X (profiles/r02_valu_rates.txt), by waves
+# per SIMD: (plain 32-bit ALU: v_add / v_and / v_xor, independent stream; the "half-rate" kinds: f64 add / mul / compare,
+# shifts, v_bfe, v_bcnt, 32-bit multiplies, v_cndmask on an SGPR mask).  A lone wave issues ~one instruction per 5 cycles
+# whatever its kind; three waves per SIMD are interpolated between the measured two and four.
+ISSUE_CYCLES = {1: (5.0, 5.0), 2: (2.7, 4.5), 3: (2.55, 4.4), 4: (2.45, 4.3)}
+HALF_RATE_SHARE = 0.45   # of k_rollout<6>'s VALU instructions (opcode histogram of its ISA: v_cndmask 20 %, f64 10 %, shifts / bfe / bcnt / mul 15 %)
+
+
 def mix_ceiling(waves_per_simd):
-    """Issue rate this kernel's instruction MIX can reach at its occupancy (tools/microbench/valu_rates.hip, measured on
-    MI355X: profiles/r02_valu_rates.txt): a lone wave per SIMD issues an independent instruction every ~5 cycles whatever
-    its type; from two waves per SIMD on, the half-rate kinds that make up the step machine (f64 add / mul / compare,
-    shifts, v_bcnt, 32-bit multiplies, v_cndmask on an SGPR mask) take 4.2-4.6 cycles and only plain 32-bit ALU reaches
-    2.3-2.8.  Returned as (wave-instr/s, cycles per instruction)."""
-    cyc = 5.0 if waves_per_simd < 1.5 else (4.5 if waves_per_simd < 2.5 else 4.25)
+    """Issue rate this kernel's instruction MIX can reach at its occupancy: (wave-instr/s, cycles per instruction)."""
+    full, half = ISSUE_CYCLES[max(1, min(4, int(round(waves_per_simd))))]
+    cyc = HALF_RATE_SHARE * half + (1.0 - HALF_RATE_SHARE) * full
     return 256 * 4 * 2.4e9 / cyc, cyc
 
 
@@ -135,7 +140,8 @@ def profile_summary(tables, players, policy, kern_steps=None):
     among equals; None if none."""
     import glob
     import math
-    best = None
+    import re
+    cands = []
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_summary.json"))):
         try:
             d = json.load(open(f))
@@ -143,11 +149,15 @@ def profile_summary(tables, players, policy, kern_steps=None):
             continue
         w = d.get("workload", {})
         if (w.get("tables"), w.get("players"), w.get("policy")) == (tables, players, policy) and w.get("fused", True):
+            m = re.match(r"r(\d+)_", os.path.basename(f))
             k = w.get("steps_per_launch") or 0
             dist = abs(math.log(max(k, 1e-9) / kern_steps)) if kern_steps else 0.0
-            if best is None or dist <= best[0] + 1e-9:
-                best = (dist, d, os.path.basename(f))
-    return (best[1], best[2]) if best else None
+            cands.append((int(m.group(1)) if m else -1, -dist, d, os.path.basename(f)))
+    if not cands:
+        return None
+    newest = max(c[0] for c in cands)                      # only the latest round's profiles describe the current kernels
+    best = max((c for c in cands if c[0] == newest), key=lambda c: c[1])
+    return best[2], best[3]
 
 
 def evaluator_leg(device, log2_m=None, reps=20):
@@ -442,14 +452,20 @@ def main():
                 waves_here = waves * (n_local / float(args.tables))
                 valu_rate = per_wave_step * waves_here * kern_steps / (ms_launch * 1e-3)
                 lanes = d.get("lanes_active")
-                ceil_rate, ceil_cyc = mix_ceiling(waves / 1024.0)
+                # resident waves per SIMD: the launch's waves, capped by what the kernel's registers allow (rocprofv3's VGPR_Count
+                # is half the allocation; 512 registers per lane and SIMD: guides/MI355X_MICROARCH.md, register files)
+                resident = min(waves / 1024.0, float(max(1, min(8, 512 // (2 * d["vgpr"]))))) if d.get("vgpr") else waves / 1024.0
+                ceil_rate, ceil_cyc = mix_ceiling(resident)
                 roof.update({"achieved": valu_rate, "frac": valu_rate / VALU_PEAK_WAVE_INSTS_PER_S,
                              "valu_insts_per_wave_step": per_wave_step, "salu_insts_per_wave_step": d.get("salu_insts_per_wave_step"),
-                             "lanes_active": lanes, "waves_per_simd": waves / 1024.0,
+                             "lanes_active": lanes, "waves_per_simd": resident, "waves_per_simd_launched": waves / 1024.0,
                              "wait_any_frac": d.get("wait_any_frac_of_wave_cycles"), "source": src,
                              "ceiling_mix": {"peak": ceil_rate, "frac_of_ceiling": valu_rate / ceil_rate,
                                              "cycles_per_instruction": ceil_cyc, "source": "profiles/r02_valu_rates.txt",
-                                             "note": "what this instruction mix can issue at this occupancy (see mix_ceiling in bench.py)"},
+                                             "half_rate_share": HALF_RATE_SHARE,
+                                             "note": "what this instruction mix can issue at this occupancy: measured cycles per "
+                                                     "wave-instruction of the plain and of the half-rate kinds, weighted by their "
+                                                     "share of the kernel's VALU instructions (ISSUE_CYCLES / mix_ceiling in bench.py)"},
                              "note": "achieved = wave-level VALU instructions per wave-step (SQ_INSTS_VALU of the committed "
                                      "rocprofv3 PMC pass of this workload / waves / steps) x waves x steps per launch / "
                                      "this run's HIP-event launch time; peak = 256 CU x 4 SIMD x 2.4 GHz / 2 cycles per "

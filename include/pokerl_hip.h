@@ -311,8 +311,9 @@ int pk_record_event(pk_handle *h, void *event);
 /* Completes deferred rollout steps and waits until everything requested so far has finished. */
 int pk_sync(pk_handle *h);
 /* Runs `reps` back-to-back fused rollouts of k_steps each (never coalesced) plus the flush of what they deferred and
- * returns the average device time of one launch in milliseconds (events on the handle's stream; the flush, when there is
- * one, counts as a launch).  Diagnostic (tools/); bench.py's roofline leg brackets its own timed region with events. */
+ * returns the device time of all of it divided by `reps`, in milliseconds (events on the handle's stream): the time one
+ * launch's k_steps of work take, the flush shared among the launches.  Diagnostic (tools/); bench.py's roofline leg
+ * brackets its own timed region with events instead (pk_record_event + pk_get_launch_stats). */
 int pk_time_rollout(pk_handle *h, int k_steps, int policy, int auto_reset, int fused, int reps, double *ms_per_launch,
                     uint64_t *counters);
 

@@ -802,13 +802,12 @@ int pk_time_rollout(pk_handle *h, int k_steps, int policy, int auto_reset, int f
                          : launch_rollout(h, 0, policy, auto_reset ? 1 : 0, 1);
         if (rc) return rc;
     }
-    const bool flushed = h->pending;
-    FLUSH(h);  // what the deferred launches left is part of the work that is being timed: one more launch, counted below
+    FLUSH(h);  // what the deferred launches left is part of the work that is being timed
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));
     HIPCHK(h, hipEventSynchronize(h->ev1));
     float ms = 0.f;
     HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
-    int launches = reps * (fused ? 1 : k_steps) + (flushed ? 1 : 0);
+    int launches = reps * (fused ? 1 : k_steps);   // the flush is work of these launches: its time is shared among them
     *ms_per_launch = launches ? (double)ms / launches : 0.0;
     if (counters) return fetch_counters(h, counters);
     return PK_OK;

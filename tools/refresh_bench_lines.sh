@@ -1,15 +1,8 @@
 #!/bin/bash
-# Runs ON THE GPU BOX: every profile and bench line that DESIGN.md section 6 quotes, for round tag $1 (e.g. r03).
-# Afterwards, locally:  tools/refresh_round_local.sh $1     (delete gpurun_out/prof_$1_* locally BEFORE the gpurun call)
+# Runs ON THE GPU BOX: the bench lines DESIGN.md section 6 quotes (no profiling; tools/refresh_round.sh does both).
 set -u
 R=$1
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
-cd $ROOT
-tools/profile_gpu.sh ${R}_65536x6_k20 20 --steps 20 --warmup 5
-tools/profile_gpu.sh ${R}_65536x6_k4096 4096 --steps 4096 --warmup 512
-PK_PLAYERS=9 PK_POLICY=allin tools/profile_gpu.sh ${R}_65536x9_allin_k4096 4096 --steps 4096 --warmup 512 --players 9 --policy allin
-PK_TABLES=4096 PK_PLAYERS=2 tools/profile_gpu.sh ${R}_4096x2_k4096 4096 --steps 4096 --warmup 512 --tables 4096 --players 2
-PK_TABLES=1048576 tools/profile_gpu.sh ${R}_1048576x6_k1024 1024 --steps 1024 --warmup 128 --tables 1048576 --samples 2 --min-steps 4096
 cd $ROOT
 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${R}_bench_driver.json 2> gpurun_out/${R}_bench_driver.err
 python bench.py > gpurun_out/${R}_bench_65536x6.json 2>/dev/null
@@ -23,5 +16,5 @@ python bench.py --mode env --steps 200 --warmup 20 --env-batches 4 2>/dev/null |
 python bench.py --mode env --steps 2000 --warmup 200 --env-async 8 2>/dev/null | tail -1 > gpurun_out/${R}_bench_env_async8_batches1.json
 python bench.py --mode env --steps 2000 --warmup 200 --env-async 8 --env-batches 4 2>/dev/null | tail -1 > gpurun_out/${R}_bench_env_async8_batches4.json
 python tools/launch_overhead.py > gpurun_out/${R}_launch_overhead.txt 2>&1
-for c in 128 256 512 1024 2048; do echo "coalesce $c: $(python bench.py --gpus 1 --steps 20 --warmup 5 --coalesce $c --no-cpu-baseline --no-evaluator --samples 3 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('%.2f G  %s' % (r['value']/1e9, r['config']['launch_stats']))")"; done > gpurun_out/${R}_coalesce_sweep.txt 2>&1
-echo refreshed $R
+python tools/measure_api.py > gpurun_out/${R}_measure_api.txt 2>&1
+echo refreshed bench lines $R
