@@ -435,6 +435,7 @@ __device__ __forceinline__ void env_step_body(const State *__restrict__ Sp, cons
         }
         if (draws) __builtin_amdgcn_s_waitcnt(0);   // as in k_rollout: no stray full wait behind the passes' LDS reads
         if (draws) ring.ensure(lds, H, table_id, tb.step_serial, live && phase != PH_END && !yielded, PK_ENV_PASSES);
+        int made = 0;
 #pragma unroll
         for (int pass = 0; pass < PK_ENV_PASSES; ++pass) {
             const bool open = !(ASYNC && max_passes > 0 && passes + pass >= max_passes);
@@ -454,11 +455,17 @@ __device__ __forceinline__ void env_step_body(const State *__restrict__ Sp, cons
             }
             tb.cursor();
             retire();
+            ++made;
+            // The tail of an env step is a handful of lanes (a busted seat 0 waits for the end of its game): once no lane can
+            // begin another Game.step in this round of passes -- all parked at end_hand, returned, or waiting for a reset /
+            // the caller -- the remaining passes would run empty; go and serve the parked lanes at once.
+            if (pass + 1 < PK_ENV_PASSES &&
+                !__any(phase != PH_END && phase != PH_RESET && tb.lstate == LS_DONE && !yielded)) break;
         }
         const int parked = __popcll(__ballot(tb.parked()));
         const int runnable = draining ? 0 : __popcll(__ballot(phase != PH_END && tb.lstate == LS_DONE && !yielded));
         if (parked == 0 && runnable == 0) break;                                   // draining: the rest stays in flight
-        passes += PK_ENV_PASSES;
+        passes += made;
         if (parked >= park || runnable == 0) {
             tb.end_block(H, t, table_id, lds, false);
             retire();

@@ -209,7 +209,8 @@ def test_multi_agent_bounded_launches_deliver_the_synchronous_sequences(O, R):
 
     # (calling stations as the caller's seats would need one launch per Game.step of the endless games they play once
     # seat 0 is broke -- 8 192 launches up to PK_TERR_ENV_CAP -- so the caller's opponent seats shove instead)
-    for T, N, pols, passes in [(4096, 6, [1, 0, 1, 2, 0], 6), (1000, 4, [1, 1, 0], 2), (2048, 3, [1, 0], 9)]:
+    seen_all = {0: 0, 1: 0, 2: 0}
+    for T, N, pols, passes in [(4096, 6, [1, 0, 1, 2, 0], 3), (1000, 4, [1, 1, 0], 1), (2048, 3, [1, 0], 9)]:
         K = 30
         ext_seats = [s for s, p in enumerate(pols, start=1) if p == 1]          # the all-in seats are played by the caller
         agents = [(lambda st: 6) if p == 1 else (RandomAgent() if p == 0 else CallAgent()) for p in pols]
@@ -264,12 +265,15 @@ def test_multi_agent_bounded_launches_deliver_the_synchronous_sequences(O, R):
             a = np.full(T, -1, np.int32)                  # garbage for tables in flight (ready 0): must be ignored
             a[r == 1] = call_rule(rows[r == 1])           # seat 0: the call rule on its delivered row
             a[r == 2] = 6                                 # the caller's opponent seats: all-in
-        assert seen[0] > 0 and seen[2] > 0, seen          # budget-exhausted and yielded tables both occurred
+        assert seen[2] > 0, seen                          # tables yielded to the caller's seats
+        for v in seen:
+            seen_all[v] += seen[v]
         for k in want:
             same = GU.bits_equal(want[k], got[k]) if want[k].dtype == np.float64 else np.array_equal(want[k], got[k])
             assert same, (T, N, k)
         env.end_multi()
         env.close()
+    assert seen_all[0] > 0, seen_all                      # ... and some ran out of passes with their call still in flight
 
 
 def test_env_pool_plays_the_single_handle_trajectories(O):
