@@ -353,7 +353,7 @@ def main():
     ap.add_argument("--no-evaluator", action="store_true", help="skip the stand-alone evaluator kernel leg")
     ap.add_argument("--coalesce", type=int, default=-1,
                     help="host-side merging of asynchronous rollout calls into launches of up to this many steps "
-                         "(pk_set_coalesce; -1: the library default 512, 0: one launch per call)")
+                         "(pk_set_coalesce; -1: the library default 1024, 0: one launch per call)")
     args = ap.parse_args()
 
     ctx = DistContext()

@@ -201,7 +201,7 @@ int pk_rollout(pk_handle *h, int k_steps, int policy, int auto_reset, int fused,
  * as soon as a launch slot frees up, when it reaches `max_steps`, or by the flush every observer issues -- so a stream of
  * short calls (20 steps each) runs as launches of up to max_steps steps and pays the fixed cost of a launch once per
  * launch, not per call.  Invisible like deferral: no entry point can observe fewer than the requested steps.
- * max_steps: 0 = every call launches at once; default 512 (env PK_COALESCE). */
+ * max_steps: 0 = every call launches at once; default 1024 (env PK_COALESCE). */
 int pk_set_coalesce(pk_handle *h, int max_steps);
 /* Launches of the rollout kernel since the last reset: out[4] = {launches (including the 0-step flushes of deferred
  * work), steps summed over them, min and max steps per launch over the launches with steps}.  reset != 0 clears them. */

@@ -38,7 +38,7 @@ struct pk_handle {
     // frees up, at `coalesce` accumulated steps, or by the flush every observer issues.  A stream of 20-step calls thus
     // runs as launches of up to `coalesce` steps: the fixed cost of a launch (load + store of every table, ramp and
     // tail: ~8 us of a 60 us 20-step launch) is paid once per launch, not per call.  0: every call launches.
-    int coalesce = 512;
+    int coalesce = 1024;
     int acc = 0;
     hipEvent_t ev_ring[2] = {nullptr, nullptr};
     bool ev_used[2] = {false, false};

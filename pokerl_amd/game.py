@@ -166,7 +166,7 @@ class VecGame:
 
     def set_coalesce(self, max_steps):
         """Asynchronous rollout calls that arrive while two launches are in flight are merged on the host into launches
-        of up to `max_steps` steps (0: every call launches; default 512)."""
+        of up to `max_steps` steps (0: every call launches; default 1024)."""
         L.check(self._lib.pk_set_coalesce(self._h, int(max_steps)), self._h)
 
     def launch_stats(self, reset=False):

@@ -2,7 +2,7 @@
 # Build container: distil what tools/refresh_round.sh left under gpurun_out/ into profiles/ and print the figures.
 R=$1
 cd "$(dirname "$0")/.."
-for t in ${R}_65536x6_k4096 ${R}_65536x6_k20 ${R}_65536x9_allin_k4096 ${R}_4096x2_k4096; do
+for t in ${R}_65536x6_k4096 ${R}_65536x6_k20 ${R}_65536x9_allin_k4096 ${R}_4096x2_k4096 ${R}_1048576x6_k1024; do
   python tools/summarize_profile.py $t > /tmp/sum_$t.txt 2>&1 || tail -3 /tmp/sum_$t.txt
   python - <<PY
 import json
