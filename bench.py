@@ -118,12 +118,15 @@ VALU_PEAK_WAVE_INSTS_PER_S = 256 * 4 * 2.4e9 / 2.0   # 256 CUs x 4 SIMDs, one wa
 #   (guides/MI355X_MICROARCH.md: "v_fma_f32 (wave64) 2 cyc (SIMD-32); one wave alone: 4")
 
 
-# Cycles per wave-instruction measured by tools/microbench/valu_rates.hip on MI355X (profiles/r02_valu_rates.txt), by waves
-# per SIMD: (plain 32-bit ALU: v_add / v_and / v_xor, independent stream; the "half-rate" kinds: f64 add / mul / compare,
-# shifts, v_bfe, v_bcnt, 32-bit multiplies, v_cndmask on an SGPR mask).  A lone wave issues ~one instruction per 5 cycles
-# whatever its kind; three waves per SIMD are interpolated between the measured two and four.
+# Cycles per wave-instruction measured by tools/microbench/valu_rates.hip on MI355X (profiles/r03_valu_rates.txt; round 2's
+# subset: r02_valu_rates.txt), by waves per SIMD: (the plain VOP2 ALU kinds -- v_add / v_sub / v_and / v_or / v_xor, independent
+# stream; everything else the step machine is made of -- every f64 op, shifts, v_bfe, v_bcnt, v_ffbh, multiplies, v_perm,
+# v_max, the three-operand forms v_or3 / v_lshl_or / v_max3 / v_lshl_add_u64, v_cndmask on an SGPR mask -- which all issue
+# at half rate).  A lone wave issues ~one instruction per 5 cycles whatever its kind; three waves per SIMD are interpolated.
 ISSUE_CYCLES = {1: (5.0, 5.0), 2: (2.7, 4.5), 3: (2.55, 4.4), 4: (2.45, 4.3)}
-HALF_RATE_SHARE = 0.45   # of k_rollout<6>'s VALU instructions (opcode histogram of its ISA: v_cndmask 20 %, f64 10 %, shifts / bfe / bcnt / mul 15 %)
+HALF_RATE_SHARE = 0.60   # of k_rollout<6>'s VALU instructions, by the opcode histogram of its ISA with v_mov and the 32-bit
+#                          v_cmp counted as plain (v_cndmask 20 %, f64 10 %, shifts / bfe / bcnt / ffbl / mul / perm 15 %,
+#                          three-operand and 64-bit integer forms 15 %): an estimate -- the ceiling is a model, not a measurement
 
 
 def mix_ceiling(waves_per_simd):
@@ -339,9 +342,9 @@ def main():
     ap.add_argument("--reps", type=int, default=0,
                     help="blocks of --steps per timed sample (0 = as many as make a sample >= --min-steps steps, so that a "
                          "short --steps is not one launch-latency sample)")
-    ap.add_argument("--min-steps", type=int, default=393216,
-                    help="a timed sample runs at least this many steps per table (~0.8-1.2 s of GPU work at 65 536 x 6, so "
-                         "that the GPU is busy for most of the run)")
+    ap.add_argument("--min-steps", type=int, default=524288,
+                    help="a timed sample runs at least this many steps per table (~1.1 s of GPU work at 65 536 x 6: seven "
+                         "samples keep the GPU busy for ~8 s of a ~16 s run)")
     ap.add_argument("--samples", type=int, default=7, help="timed samples; the MEDIAN is reported")
     ap.add_argument("--unfused", action="store_true", help="one launch per step (state round-trips HBM every step)")
     ap.add_argument("--mode", choices=["game", "env"], default="game")

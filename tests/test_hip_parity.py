@@ -680,7 +680,7 @@ def test_bench_json_contract():
     assert r["scaling"] == "weak" and r["vs_baseline"] is None and r["dtype"] == "f64" and r["data"] == "synthetic"
     assert "workload" in r["config"] and "model" not in r["config"] and "BASELINE configs[2]" in r["config"]["workload"]
     assert abs(r["value"] - 65536 * 256 / (r["ms_per_step"] * 256 / 1e3)) / r["value"] < 1e-6
-    assert r["reps"] == 1536 and r["samples"] == 7 and len(r["sample_seconds"]) == 7   # 1 536 blocks of 256 steps = 393 216 per sample
+    assert r["reps"] == 2048 and r["samples"] == 7 and len(r["sample_seconds"]) == 7   # 2 048 blocks of 256 steps = 524 288 per sample
     rf = r["roofline"]
     # the binding roofline leads: VALU issue, from the committed rocprofv3 PMC summary of this workload x this run's launch time
     assert rf["bound"] == "valu-issue" and rf["unit"] == "wave-instr/s" and rf["peak"] == 256 * 4 * 2.4e9 / 2
@@ -691,7 +691,7 @@ def test_bench_json_contract():
     # self-consistent timing: HIP-event time per launch / steps per launch can never exceed the wall-clock time per step
     assert rf["kernel_ms"] / rf["steps_per_launch"] <= r["ms_per_step"] * 1.0005, (rf["kernel_ms"], rf["steps_per_launch"], r["ms_per_step"])
     st = r["config"]["launch_stats"]
-    assert st["steps"] == 256 * 1536 * 7 and abs(rf["steps_per_launch"] - 256 * 1536 / rf["launches_timed"]) < 1e-9 and rf["launches_timed"] * 6 < st["launches"] < rf["launches_timed"] * 8
+    assert st["steps"] == 256 * 2048 * 7 and abs(rf["steps_per_launch"] - 256 * 2048 / rf["launches_timed"]) < 1e-9 and rf["launches_timed"] * 6 < st["launches"] < rf["launches_timed"] * 8
     # measured HBM traffic (one read + one write of the table state per launch) and SURVEY 8d's algorithmic figure, nested
     assert rf["traffic"] and 0.5 < rf["traffic"] / (65536 * 2 * 290) < 1.5 and rf["traffic_source"].endswith("_summary.json")
     hb = rf["hbm_algorithmic"]

@@ -31,6 +31,23 @@ struct CmpCndS { static constexpr const char *label = "v_cmp_lt_u32 s[] + v_cndm
     static __device__ __forceinline__ void dep(unsigned &a, unsigned b) {
         unsigned long long m;
         asm volatile("v_cmp_lt_u32_e64 %2, %0, %1\n\tv_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(a), "+v"(b), "=&s"(m)); } };
+OP32(BfeU32_, v_lshrrev_b32)
+struct Bfe { static constexpr const char *label = "v_bfe_u32";
+    static __device__ __forceinline__ void dep(unsigned &a, unsigned b) { asm volatile("v_bfe_u32 %0, %0, %1, 13" : "+v"(a) : "v"(b)); } };
+struct Perm { static constexpr const char *label = "v_perm_b32";
+    static __device__ __forceinline__ void dep(unsigned &a, unsigned b) { asm volatile("v_perm_b32 %0, %0, %1, %1" : "+v"(a) : "v"(b)); } };
+struct Or3 { static constexpr const char *label = "v_or3_b32";
+    static __device__ __forceinline__ void dep(unsigned &a, unsigned b) { asm volatile("v_or3_b32 %0, %0, %1, %1" : "+v"(a) : "v"(b)); } };
+struct Max3 { static constexpr const char *label = "v_max3_u32";
+    static __device__ __forceinline__ void dep(unsigned &a, unsigned b) { asm volatile("v_max3_u32 %0, %0, %1, %1" : "+v"(a) : "v"(b)); } };
+struct Bitop3 { static constexpr const char *label = "v_bitop3_b32";
+    static __device__ __forceinline__ void dep(unsigned &a, unsigned b) { asm volatile("v_bitop3_b32 %0, %0, %1, %1 bitop3:0x6c" : "+v"(a) : "v"(b)); } };
+struct LshlOr { static constexpr const char *label = "v_lshl_or_b32";
+    static __device__ __forceinline__ void dep(unsigned &a, unsigned b) { asm volatile("v_lshl_or_b32 %0, %0, 3, %1" : "+v"(a) : "v"(b)); } };
+struct Ffbh { static constexpr const char *label = "v_ffbh_u32";
+    static __device__ __forceinline__ void dep(unsigned &a, unsigned b) { asm volatile("v_ffbh_u32 %0, %0" : "+v"(a)); } };
+struct MaxU32 { static constexpr const char *label = "v_max_u32";
+    static __device__ __forceinline__ void dep(unsigned &a, unsigned b) { asm volatile("v_max_u32 %0, %0, %1" : "+v"(a) : "v"(b)); } };
 struct Bcnt { static constexpr const char *label = "v_bcnt_u32_b32";
     static __device__ __forceinline__ void dep(unsigned &a, unsigned b) { asm volatile("v_bcnt_u32_b32 %0, %0, %1" : "+v"(a) : "v"(b)); } };
 
@@ -56,6 +73,16 @@ struct FmaF64 { static constexpr const char *label = "v_fma_f64";
     static __device__ __forceinline__ void dep(double &a, double b) { asm volatile("v_fma_f64 %0, %0, %1, %1" : "+v"(a) : "v"(b)); } };
 struct CmpF64 { static constexpr const char *label = "v_cmp_gt_f64 (to vcc)";
     static __device__ __forceinline__ void dep(double &a, double b) { asm volatile("v_cmp_gt_f64 vcc, %0, %1" : : "v"(a), "v"(b) : "vcc"); } };
+struct Lshl64 { static constexpr const char *label = "v_lshlrev_b64";
+    static __device__ __forceinline__ void dep(double &a, double b) {
+        unsigned long long &x = reinterpret_cast<unsigned long long &>(a);
+        asm volatile("v_lshlrev_b64 %0, 1, %0" : "+v"(x)); } };
+struct LshlAdd64 { static constexpr const char *label = "v_lshl_add_u64";
+    static __device__ __forceinline__ void dep(double &a, double b) {
+        unsigned long long &x = reinterpret_cast<unsigned long long &>(a);
+        asm volatile("v_lshl_add_u64 %0, %0, 0, %0" : "+v"(x)); } };
+struct MaxF64 { static constexpr const char *label = "v_max_f64";
+    static __device__ __forceinline__ void dep(double &a, double b) { asm volatile("v_max_f64 %0, %0, %1" : "+v"(a) : "v"(b)); } };
 struct Mad64 { static constexpr const char *label = "v_mad_u64_u32";
     static __device__ __forceinline__ void dep(double &a, double b) {
         unsigned long long &x = reinterpret_cast<unsigned long long &>(a);
@@ -104,6 +131,7 @@ int main() {
 #define R32(OP) row(OP::label, k32<OP, 1>, s32, 1); row(OP::label, k32<OP, 8>, s32, 8);
 #define R64(OP) row(OP::label, k64<OP, 1>, s64, 1); row(OP::label, k64<OP, 8>, s64, 8);
     R32(AddU32) R32(XorB32) R32(AndB32) R32(Cndmask) R32(CndmaskSgpr) R32(CmpCnd) R32(CmpCndS) R32(LshlRev) R32(Bcnt) R32(MulU24) R32(MulLo) R32(MulHi)
-    R64(AddF64) R64(MulF64) R64(FmaF64) R64(CmpF64) R64(Mad64)
+    R32(Bfe) R32(Perm) R32(Or3) R32(Max3) R32(MaxU32) R32(Bitop3) R32(LshlOr) R32(Ffbh)
+    R64(AddF64) R64(MulF64) R64(FmaF64) R64(CmpF64) R64(Mad64) R64(Lshl64) R64(LshlAdd64) R64(MaxF64)
     return 0;
 }
