@@ -298,3 +298,39 @@ def test_env_pool_plays_the_single_handle_trajectories(O):
                     env.reset(do[sl])
     assert GU.bits_equal(o.f64(0), np.concatenate([e.game.credits for e in pool.envs]))
     pool.close()
+
+
+GATHER_GPU = r'''
+import os, sys
+import torch                      # first: the process must settle on torch's HIP runtime
+import torch.distributed as dist
+sys.path.insert(0, %r)
+import numpy as np
+import pokerl_amd
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29561")
+os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))      # RCCL
+g = pokerl_amd.VecGame(3000, num_players=5, seed=9)
+g.reset()
+g.rollout(200, 0)
+for field, want in ((3, g.payoffs), (0, g.credits)):
+    got = pokerl_amd.gather_f64(g, field, dist)                          # pk_get_f64_d -> all_gather on the device
+    assert got.shape == want.shape and got.tobytes() == want.tobytes(), field
+dist.destroy_process_group()
+print("GATHER-OK")
+'''
+
+
+def test_optional_payoff_gather_over_rccl(tmp_path):
+    """north_star's optional RCCL gather of payoffs: the local block is exported on the device (pk_get_f64_d) into the send
+    tensor of an RCCL all-gather -- one rank here (a one-GPU box), the collective and the device path are the real ones."""
+    import os
+    import subprocess
+    import sys
+    pytest.importorskip("torch")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "gather.py"
+    script.write_text(GATHER_GPU % root)
+    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0 and "GATHER-OK" in out.stdout, (out.stdout[-2000:], out.stderr[-3000:])
