@@ -747,7 +747,7 @@ static int enqueue_rollout(pk_handle *h, int k_steps, int policy, int auto_reset
         // the launch before the last one (the ring slot about to be reused) still running: two launches are in flight,
         // the GPU will not idle if this call just leaves its steps with the host
         hipError_t q = hipEventQuery(h->ev_ring[h->ev_idx]);
-        if (q == hipErrorNotReady) return PK_OK;
+        if (q == hipErrorNotReady) { (void)hipGetLastError(); return PK_OK; }   // "not ready" is an answer, not an error to keep
         if (q != hipSuccess) return h->fail(PK_E_HIP, "hipEventQuery", q);
     }
     return launch_coalesced(h, policy, auto_reset);

@@ -131,6 +131,18 @@ class VecPokerGameEnv:
             L.check(g._lib.pk_env_reset(g._h, L.ptr(m), self._opp_policy), g._h)
         return g.observations
 
+    def check_actions(self, actions, table_offset=0):
+        """Raises the reference's ValueError (game.py:649-651) if any table's action is not valid for its active player;
+        nothing is mutated."""
+        g = self.game
+        a = g._actions(actions)
+        valid = g.get_valid_actions()[0]
+        ok = (a >= 0) & (a < valid.shape[1])
+        ok[ok] = valid[np.nonzero(ok)[0], a[ok]] != 0
+        if not ok.all():
+            t = int(np.argmin(ok))
+            raise ValueError('Player %d invalid move: `%d` (table %d)' % (int(g.active_player[t]), int(a[t]), t + table_offset))
+
     def step(self, actions, strict=True):
         """game_env.py:31-53: returns (obs, reward f64[T], done bool[T], hand bool[T]) -- the reference's 4-tuple.
 
@@ -141,12 +153,7 @@ class VecPokerGameEnv:
         a = g._actions(actions)
         T = g.num_tables
         if strict:
-            valid = g.get_valid_actions()[0]
-            ok = (a >= 0) & (a < valid.shape[1])
-            ok[ok] = valid[np.nonzero(ok)[0], a[ok]] != 0
-            if not ok.all():
-                t = int(np.argmin(ok))
-                raise ValueError('Player %d invalid move: `%d` (table %d)' % (int(g.active_player[t]), int(a[t]), t))
+            self.check_actions(a)
         if self._opp_policy is None:
             reward, done, hand, terr = self._multi_run(actions=a)
         else:
@@ -238,9 +245,19 @@ class VecPokerGameEnvPool:
         return np.concatenate([e.reset() for e in self.envs])
 
     def step(self, actions, strict=True):
+        """PokerGameEnv.step on every table of the pool.  strict: every batch is checked BEFORE any is stepped, so that an
+        invalid action raises with no table of the pool mutated (as VecPokerGameEnv.step does for its batch)."""
         a = np.ascontiguousarray(np.broadcast_to(np.asarray(actions), (self.num_tables,)))
-        outs = [e.step(a[s], strict=strict) for e, s in zip(self.envs, self.slices)]
-        return tuple(np.concatenate([o[i] for o in outs]) for i in range(len(outs[0])))
+        if strict:
+            for e, s in zip(self.envs, self.slices):
+                e.check_actions(a[s], table_offset=s.start)
+        outs = [e.step(a[s], strict=False) for e, s in zip(self.envs, self.slices)]
+        cat = tuple(np.concatenate([o[i] for o in outs]) for i in range(5))
+        if not strict:
+            return cat
+        if cat[4].any():
+            raise L.PokerlHipError('table error bits %s' % np.unique(cat[4]))
+        return cat[:4]
 
     def sync(self):
         for e in self.envs:

@@ -297,6 +297,14 @@ def test_env_pool_plays_the_single_handle_trajectories(O):
                 if do[sl].any():
                     env.reset(do[sl])
     assert GU.bits_equal(o.f64(0), np.concatenate([e.game.credits for e in pool.envs]))
+    # strict: an invalid action anywhere raises before ANY batch of the pool is stepped
+    before = np.concatenate([e.game.step_serial for e in pool.envs])
+    bad = o.pick_actions(0); bad[T - 1] = 7
+    with pytest.raises(ValueError, match="table %d" % (T - 1)):
+        pool.step(bad)
+    assert np.array_equal(before, np.concatenate([e.game.step_serial for e in pool.envs]))
+    obs, r, d, h = pool.step(o.pick_actions(0))
+    assert obs.shape[0] == T and len(r) == T
     pool.close()
 
 
