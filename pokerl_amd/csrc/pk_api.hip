@@ -169,7 +169,8 @@ static int launch_coalesced(pk_handle *h, int policy, int auto_reset) {
 }
 static int flush(pk_handle *h) {
     if (h->env_pending)
-        return h->fail(PK_E_BUSY, "PokerGameEnv steps are in flight (pk_env_step_async_d): drain them with max_passes = 0 first");
+        return h->fail(PK_E_BUSY, "PokerGameEnv steps are in flight (pk_env_step_async_d / pk_env_step_multi_d): drain them with max_passes = 0 "
+                                  "(pk_env_end_multi_d where seats are played by the caller) first");
     return flush_rollout(h);
 }
 #define FLUSH(h)                   \
