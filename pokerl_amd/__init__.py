@@ -6,9 +6,10 @@ from .envs import VecPokerGameEnv, VecPokerGameEnvPool
 from .agents import AllInAgent, CallAgent, PokerAgent, RandomAgent
 from .judger import compare_hands, compare_rankings, eval_hand, eval_hands
 from .sharding import gather_f64, shard_tables
+from .single import Game, PokerGameEnv
 from .state_view import Card, StateView
 from ._lib import PokerlHipError, device_count
 
-__all__ = ['VecGame', 'VecPokerGameEnv', 'VecPokerGameEnvPool', 'eval_hand', 'eval_hands', 'compare_rankings', 'compare_hands',
+__all__ = ['Game', 'PokerGameEnv', 'VecGame', 'VecPokerGameEnv', 'VecPokerGameEnvPool', 'eval_hand', 'eval_hands', 'compare_rankings', 'compare_hands',
            'shard_tables', 'gather_f64', 'Card', 'StateView', 'HandRanking', 'PokerMoves', 'PlayerState', 'CardRank', 'CardSuit', 'Policy',
            'PokerlHipError', 'device_count', 'PokerAgent', 'RandomAgent', 'AllInAgent', 'CallAgent']

@@ -342,3 +342,51 @@ def test_optional_payoff_gather_over_rccl(tmp_path):
     script.write_text(GATHER_GPU % root)
     out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600, cwd=root)
     assert out.returncode == 0 and "GATHER-OK" in out.stdout, (out.stdout[-2000:], out.stderr[-3000:])
+
+
+def test_single_table_drop_in_reads_like_the_reference():
+    """pokerl_amd.Game / PokerGameEnv: the reference's own shapes (one table, scalars, Card lists, StateView objects).
+    The loop of examples/random_game.py:8-12 against the reference-generated trajectory of that very configuration
+    (tests/golden/game_n4_example_cfg: 1000 / 40 / 20, four seats), table by table, plus the env fixture with mixed agents."""
+    import pokerl_amd
+    from pokerl_amd import AllInAgent, CallAgent, Game, PokerGameEnv, PokerMoves, RandomAgent
+    z, meta = GU.load_npz("game_n4_example_cfg")
+    for t in range(2):
+        game = Game(num_players=meta["n"], seed=meta["seed"], table_id_base=meta["table_id_base"] + t, **meta["cfg"])
+        game.reset()
+        assert game.num_players == 4 and not game.game_over and game.community_cards == []
+        for s in range(meta["steps"]):
+            onehot, valid = game.get_valid_actions()
+            action = int(z["actions"][s, t])
+            assert onehot[action] == 1.0 and action in list(valid)
+            state = game.active_state
+            assert state.player == game.active_player and len(state.player_cards) == 2
+            over, hand, turn = game.step(action)
+            assert (int(over) | int(hand) << 1 | int(turn) << 2) == int(z["flags"][s, t]), (t, s)
+            assert GU.bits_equal(z["post_credits"][s, t], game.credits) and GU.bits_equal(z["post_payoffs"][s, t], game.payoffs)
+            assert GU.bits_equal(z["post_pending"][s, t], game.pending_bets) and game.turn == int(z["post_turn"][s, t])
+            assert [c.value for c in game.deck] == z["post_cards"][s, t].tolist()
+            assert len(game.community_cards) == (0 if game.turn == 0 else game.turn + 2)
+            assert game.pot == float(np.sum(game.bets)) and game.get_hand_for(1)[5:] == game.get_cards_of(1)
+            if over:
+                game.reset()
+        with pytest.raises(NotImplementedError):
+            game.step(1.5)                                                        # game.py:700
+        bad = next(a for a in range(7) if game.get_valid_actions()[0][a] == 0) if (game.get_valid_actions()[0] == 0).any() else None
+        if bad is not None:
+            with pytest.raises(ValueError, match="invalid move"):
+                game.step(bad)                                                    # game.py:649-651
+        game.close()
+    z, meta = GU.load_npz("env_n4_mixed_opponents")                               # agents = [call, random, all-in]
+    env = PokerGameEnv([CallAgent(), RandomAgent(), AllInAgent()], num_players=4, seed=meta["seed"], table_id_base=meta["table_id_base"], **meta["cfg"])
+    state = env.reset()
+    assert state.player == 0 and env.game.active_player == 0
+    for s in range(60):
+        action = int(z["actions"][s, 0])
+        state, reward, done, hand = env.step(action)
+        assert np.float64(reward).tobytes() == z["reward"][s, 0].tobytes() and done == bool(z["done"][s, 0]) and hand == bool(z["hand_over"][s, 0]), s
+        assert GU.bits_equal(z["post_credits"][s, 0], env.game.credits)
+        if done:
+            state = env.reset()
+    assert isinstance(state.valid_actions, np.ndarray) and PokerMoves.FOLD == 0
+    env.close()
