@@ -167,6 +167,29 @@ def test_optional_payoff_gather_gloo_world3(tmp_path):
     assert r["ok"] and r["shape"] == [1001, 3]
 
 
+def test_agents_module_maps_in_kernel_agents_and_applies_their_rules_on_the_host():
+    """pokerl_amd.agents (reference pokerl/agents): in-kernel markers map to policy nibbles, anything else is a host agent;
+    called on the host the markers apply the same RULE to a StateView (agents/random.py:12-18 for the random one)."""
+    from pokerl_amd import AllInAgent, CallAgent, PokerAgent, Policy, RandomAgent, StateView
+    from pokerl_amd.agents import kernel_policy
+    assert [kernel_policy(a) for a in (RandomAgent(), AllInAgent(), CallAgent(), Policy.CALL, 1, np.int64(0))] == [0, 1, 2, 2, 1, 0]
+    assert kernel_policy(lambda s: 0) is None and kernel_policy(PokerAgent()) is None and kernel_policy(True) is None
+    with pytest.raises(ValueError):
+        kernel_policy(7)                                   # not a Policy
+    with pytest.raises(NotImplementedError):
+        PokerAgent()(None)                                 # agents/agent.py:11-13
+    n = 3
+    row = np.array([1, 0, 2.0,  1, 0, 1, 1, 0, 0, 1,  0x20, 0x3c,  -1, -1, -1, -1, -1,  90, 80, 70,  0, 0, 0,  1, 2, 0], np.float64)
+    sv = StateView(row, n)                                 # valid: FOLD, CALL, RAISE_TEN, ALL_IN
+    assert CallAgent()(sv) == 2 and AllInAgent()(sv) == 6
+    np.random.seed(3)
+    assert {RandomAgent()(sv) for _ in range(200)} == {0, 2, 3, 6}
+    row[5] = 0                                             # CALL invalid, CHECK invalid -> the call agent shoves
+    assert CallAgent()(StateView(row, n)) == 6
+    row[4] = 1
+    assert CallAgent()(StateView(row, n)) == 1             # ... or checks where it can
+
+
 def test_state_view_mirror_fields_and_pickle():
     """StateView / Card host mirrors (reference game.py:39-240, cards.py:4-72): built from a dense observation row."""
     import pickle
