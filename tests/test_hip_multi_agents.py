@@ -390,3 +390,28 @@ def test_single_table_drop_in_reads_like_the_reference():
             state = env.reset()
     assert isinstance(state.valid_actions, np.ndarray) and PokerMoves.FOLD == 0
     env.close()
+
+
+def test_call_agent_rollout_and_pick_vs_oracle(O):
+    """PK_POLICY_CALL in the rollout kernels (k_rollout_call, fused and one step per launch), pk_pick_actions and the lockstep
+    path, against the oracle's call agent (rng_spec: CALL if valid, else CHECK if valid, else ALL_IN)."""
+    from hip_backend import HipBackend as HB
+    for T, N, K in [(4096, 6, 120), (1000, 3, 200), (65536, 2, 40)]:
+        o = O.OracleGame(T, N, seed=321)
+        h = HB(T, N, seed=321)
+        o.reset(); h.reset()
+        a = o.pick_actions(2)
+        assert np.array_equal(a, h.pick_actions(2)) and set(np.unique(a)) <= {1, 2, 6}
+        co, err = o.rollout(K, 2, True)
+        ch = h.rollout(K, 2, True)
+        assert ch.tolist() == co.tolist(), (T, N)
+        co2, _ = o.rollout(7, 2, True)
+        ch2 = h.rollout(7, 2, True, fused=False)
+        assert ch2.tolist() == co2.tolist()
+        for _ in range(5):                                   # asynchronous calls (deferred / merged) of the call agents
+            h.g.rollout(9, 2, True, True, counters=False)
+        o.rollout(45, 2, True)
+        so, sh = o.snapshot(), h.snapshot()
+        for k in GU.SNAP_FIELDS:
+            assert GU.bits_equal(so[k], sh[k]), (T, N, k)
+        h.g.close()
