@@ -90,13 +90,15 @@ def main():
         cfg = dict(start_credits=start, big_blind=rng.choice([b for b in BLINDS if 0 < b <= 40]),
                    small_blind=rng.choice([b for b in BLINDS if 0 < b <= 40]))
         opp = 1 if rng.random() < 0.25 else 0
+        if i % 2:   # round 3: one agent per opponent seat (random / all-in / call), as PokerGameEnv(agents=[...]) takes them
+            opp = [rng.choice([0, 0, 1, 2]) for _ in range(n - 1)]
         seed, base = rng.getrandbits(63), rng.getrandbits(32) & 0xFFFFFF00
         signal.alarm(30)
         try:
             out = MG.env_trajectory(n, 0, opp, seed, 3, 40, base, cfg)
         except Timeout:
             env_skipped += 1
-            print("skip (reference env spins): n=%d cfg=%s opp=%d" % (n, cfg, opp), flush=True)
+            print("skip (reference env spins): n=%d cfg=%s opp=%s" % (n, cfg, opp), flush=True)
             continue
         finally:
             signal.alarm(0)
@@ -104,7 +106,7 @@ def main():
         try:
             GU.replay_env(make_oracle, "envfuzz%d" % i, loaded=(out, meta))
         except AssertionError as e:
-            print("ENV MISMATCH n=%d cfg=%s opp=%d seed=%d base=%d\n%s" % (n, cfg, opp, seed, base, e))
+            print("ENV MISMATCH n=%d cfg=%s opp=%s seed=%d base=%d\n%s" % (n, cfg, opp, seed, base, e))
             return 1
         env_ok += 1
     print("fuzz oracle vs reference, PokerGameEnv: %d configurations identical, %d skipped" % (env_ok, env_skipped))
