@@ -383,42 +383,41 @@ __device__ __forceinline__ void env_step_body(const State *__restrict__ Sp, cons
     yielded = yielded && !have_ext;
     int passes = 0;
     const uint32_t caps = PK_TERR_HAND_CAP | PK_TERR_ENV_CAP;
-    auto step_finished = [&]() {   // PokerGameEnv.step has returned: its outputs are final; maybe reset the episode
-        terr_step = tb.terr;
-        phase = (auto_reset && (done || (tb.terr & caps))) ? PH_RESET : PH_END;
-    };
-    auto retire = [&]() {  // a Game.step() of this lane has returned: the reference's control flow between two steps
-        if (tb.stepped && tb.lstate == LS_DONE) {
-            tb.finish_step();
-            if (phase == PH_RESET_PLAY) {                                          // game_env.py:24-27
-                if (--budget_reset < 0) tb.terr |= PK_TERR_ENV_CAP;
-                if (tb.terr) phase = PH_END;
-                else if (tb.flags & PK_FLAG_GAME_OVER) phase = PH_RESET;           // :27
-                else if (tb.active == 0) phase = PH_END;                           // :24
-                return;
-            }
-            if (phase != PH_SEAT0 && --budget < 0) tb.terr |= PK_TERR_ENV_CAP;
-            if (tb.terr) { step_finished(); return; }
-            const bool over = (tb.flags & PK_FLAG_GAME_OVER) != 0, hand_now = (tb.flags & PK_FLAG_HAND_OVER) != 0;
-            const bool seat0 = tb.active == 0;
-            bool leave_hand_stretch = false;                                       // :41's loop is over (or never entered)
-            if (phase == PH_SEAT0) {
-                done = over; hand = hand_now;
-                if (done || (tb.st_broken & 1)) { rew = tb.payoffs[0]; done = true; hand = true; step_finished(); }  // :37-39
-                else if (!hand && !seat0) phase = PH_HAND;                         // :41
-                else leave_hand_stretch = true;
-            } else if (phase == PH_HAND) {
-                done = over; hand = hand_now;                                      // :44
-                leave_hand_stretch = hand || seat0;
-            } else {                                                               // PH_TURN: only `done` is re-read (:52)
-                done = over;
-                if (done || seat0) step_finished();
-            }
-            if (leave_hand_stretch) {
-                if (hand) rew = tb.payoffs[0];                                     // :47
-                if (!done && !seat0) phase = PH_TURN; else step_finished();        // :49
-            }
-        }
+    // A Game.step() of this lane has returned: the reference's control flow between two steps (game_env.py:24-27, :37-52),
+    // as SELECTS over the predicates of all its branches -- written as nested ifs (round 2) every pass carried ~25
+    // divergent branches (s_and_saveexec / s_cbranch / s_or each) against ~3 in k_rollout's pass -- behind ONE wave-uniform
+    // test: in the second half of a bounded launch most passes retire nothing, and unguarded selects cost the asynchronous
+    // kernel 10 % (synchronous +5 % either way; guarded: +7.6 % synchronous, +2.6 % asynchronous).
+    auto retire = [&]() {
+        const bool r = tb.stepped && tb.lstate == LS_DONE;
+        if (!__any(r)) return;                                                     // (wave-uniform: most passes of a bounded launch's second half)
+        tb.step_serial += (r && !(tb.terr & PK_TERR_NO_WINNER)) ? 1u : 0u;          // finish_step()
+        tb.stepped = r ? 0u : tb.stepped;
+        const bool rp = r && phase == PH_RESET_PLAY;                               // a step of PokerGameEnv.reset()'s loop (:24-27)
+        const bool rn = r && phase != PH_RESET_PLAY;                               // a step of PokerGameEnv.step (:35-52)
+        const bool opp = rn && phase != PH_SEAT0;                                  // ... played by an opponent
+        budget_reset -= rp ? 1 : 0; budget -= opp ? 1 : 0;
+        tb.terr |= ((rp && budget_reset < 0) || (opp && budget < 0)) ? (uint32_t)PK_TERR_ENV_CAP : 0u;
+        const bool err = tb.terr != 0;
+        const bool over = (tb.flags & PK_FLAG_GAME_OVER) != 0, hand_now = (tb.flags & PK_FLAG_HAND_OVER) != 0;
+        const bool seat0 = tb.active == 0;
+        int ph = phase;
+        ph = rp ? (err ? (int)PH_END : (over ? (int)PH_RESET : (seat0 ? (int)PH_END : (int)PH_RESET_PLAY))) : ph;   // :27 / :24
+        const bool s0 = rn && !err && phase == PH_SEAT0, sh = rn && !err && phase == PH_HAND, st = rn && !err && phase == PH_TURN;
+        done = (s0 || sh || st) ? over : done;                                     // :35 / :44 / :52
+        hand = (s0 || sh) ? hand_now : hand;
+        const bool bust = s0 && (done || (tb.st_broken & 1u));                     // :37-39
+        done = bust ? true : done; hand = bust ? true : hand;
+        const bool to_hand = s0 && !bust && !hand && !seat0;                       // :41
+        const bool leave = (s0 && !bust && !to_hand) || (sh && (hand || seat0));   // :41's loop is over (or never entered)
+        rew = (bust || (leave && hand)) ? tb.payoffs[0] : rew;                     // :39 / :47
+        const bool to_turn = leave && !done && !seat0;                             // :49
+        const bool fin = (rn && err) || bust || (leave && !to_turn) || (st && (done || seat0));
+        ph = to_hand ? (int)PH_HAND : ph; ph = to_turn ? (int)PH_TURN : ph;
+        // PokerGameEnv.step has returned: its outputs are final; maybe reset the episode
+        terr_step = fin ? tb.terr : terr_step;
+        ph = fin ? ((auto_reset && (done || (tb.terr & caps))) ? (int)PH_RESET : (int)PH_END) : ph;
+        phase = ph;
     };
 #ifndef PK_ENV_PASSES
 #define PK_ENV_PASSES 4   // betting passes between two looks at the parked lanes, as in k_rollout
@@ -453,7 +452,7 @@ __device__ __forceinline__ void env_step_body(const State *__restrict__ Sp, cons
                 if (MULTI && supplied && phase != PH_SEAT0) { yielded = !have_ext; have_ext = false; }
                 if (begin) tb.begin_step(H, a, high_bet);                          // :35 / :43-44 / :51-52 / :25-26
             }
-            tb.cursor();
+            tb.cursor();          // (k_rollout's scan_first / cursor_tail split measured 1.7 % slower here)
             retire();
             ++made;
             // The tail of an env step is a handful of lanes (a busted seat 0 waits for the end of its game): once no lane can
