@@ -445,10 +445,12 @@ __device__ __forceinline__ void env_step_body(const State *__restrict__ Sp, cons
                 const int pol = phase == PH_SEAT0 ? seat0_policy : seat_policy(seatpol, tb.active);
                 const bool supplied = (phase == PH_SEAT0 && pol < 0) || (MULTI && phase != PH_SEAT0 && pol == PK_POLICY_EXTERNAL);
                 const bool begin = !supplied || phase == PH_SEAT0 || have_ext;     // an external seat without an action: yield
-                const int a = supplied ? action
-                            : pol == PK_POLICY_ALLIN ? (int)MV_ALL_IN
-                            : pol == PK_POLICY_CALL ? call_action(vm)
-                                                    : action_from_draw_lds(lds, ActionRing::half_of(word, tb.step_serial), vm);
+                // every agent's move computed, then selected: as a chain of conditionals around the LDS lookup of the random
+                // agent's move the compiler made this four nested branches per pass
+                const int a_rand = draws ? action_from_draw_lds(lds, ActionRing::half_of(word, tb.step_serial), vm) : 0;
+                const int a_call = call_action(vm);
+                int a = pol == PK_POLICY_ALLIN ? (int)MV_ALL_IN : (pol == PK_POLICY_CALL ? a_call : a_rand);
+                a = supplied ? action : a;
                 if (MULTI && supplied && phase != PH_SEAT0) { yielded = !have_ext; have_ext = false; }
                 if (begin) tb.begin_step(H, a, high_bet);                          // :35 / :43-44 / :51-52 / :25-26
             }
