@@ -464,7 +464,7 @@ def main():
                              "lanes_active": lanes, "waves_per_simd": resident, "waves_per_simd_launched": waves / 1024.0,
                              "wait_any_frac": d.get("wait_any_frac_of_wave_cycles"), "source": src,
                              "ceiling_mix": {"peak": ceil_rate, "frac_of_ceiling": valu_rate / ceil_rate,
-                                             "cycles_per_instruction": ceil_cyc, "source": "profiles/r02_valu_rates.txt",
+                                             "cycles_per_instruction": ceil_cyc, "source": "profiles/r03_valu_rates.txt",
                                              "half_rate_share": HALF_RATE_SHARE,
                                              "note": "what this instruction mix can issue at this occupancy: measured cycles per "
                                                      "wave-instruction of the plain and of the half-rate kinds, weighted by their "
