@@ -261,15 +261,19 @@ def env_mode(args, ctx, device):
                 DeviceBuffer(T * 4, device), DeviceBuffer(T * 8, device), DeviceBuffer(T, device),
                 DeviceBuffer(T, device), DeviceBuffer(T, device), DeviceBuffer(T * D * 8, device))
             L.check(lib.pk_env_reset_d(self.g._h, None, 0), self.g._h)
+            self.inner = self.env.set_env_batches(args.env_inner_batches) if (args.env_async > 0 and args.env_inner_batches > 1) else 1
             # --env-async: one ready[T] slice per timed launch, summed after the timed region
             self.ready = DeviceBuffer(T * (args.steps + 1), device) if args.env_async > 0 else None
             self.launch = 0
+            self.delivered = []     # per timed launch: (slot, begin, end) of the delivered range (inner batches)
 
         def step(self, timed=False):
             g, h = self.g, self.g._h
             if args.env_async > 0:   # bounded launches: tables whose env.step has not returned stay in flight
                 slot = 1 + self.launch if timed else 0
                 self.launch += 1 if timed else 0
+                if self.inner > 1 and timed:    # the range this call LAUNCHES = the range the previous call delivered; its ready
+                    self.delivered.append((slot, self.env.last_range()[:2]))   # flags go to this call's slot
                 L.check(lib.pk_env_step_async_d(h, None, 0, 0, 1, args.env_async, self.rew.ptr, self.done.ptr, self.hand.ptr,
                                                 self.terr.ptr, self.obs.ptr, C.c_void_p(self.ready.ptr.value + slot * T)), h)
             elif args.env_unfused:   # five launches per env step
@@ -302,8 +306,17 @@ def env_mode(args, ctx, device):
     sync(); ctx.barrier()
     dt = time.perf_counter() - t0
     env_steps = B * T * args.steps
+    launched_tables = env_steps
+    if args.env_async > 0 and batches[0].inner > 1:     # a call steps ONE range of its handle
+        launched_tables = sum(r1 - r0 for b in batches for _, (r0, r1) in b.delivered)
     if args.env_async > 0:   # delivered env.steps = ready flags of the timed launches; then drain so that the tables can be read
-        env_steps = sum(int(b.ready.download(np.uint8, T * (args.steps + 1))[T:].sum(dtype=np.int64)) for b in batches)
+        def delivered_steps(b):
+            flags = b.ready.download(np.uint8, T * (args.steps + 1))
+            if b.inner <= 1:
+                return int(flags[T:].sum(dtype=np.int64))
+            # inner batches: every timed call wrote the flags of the ONE range it launched into its own slot
+            return sum(int(flags[slot * T + r0:slot * T + r1].sum(dtype=np.int64)) for slot, (r0, r1) in b.delivered)
+        env_steps = sum(delivered_steps(b) for b in batches)
         for b in batches:
             L.check(lib.pk_env_step_async_d(b.g._h, None, 0, 0, 1, 0, b.rew.ptr, b.done.ptr, b.hand.ptr, b.terr.ptr, b.obs.ptr,
                                             b.ready.ptr), b.g._h)
@@ -320,12 +333,14 @@ def env_mode(args, ctx, device):
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%d batch(es) x %d tables x %d seats per GPU, seat 0 + opponents random in-kernel, "
-                                   "episodes auto-reset; reference pokerl/envs/game_env.py:20-53" % (B, T, N),
-                       "env_batches": B,
+                                   "episodes auto-reset%s; reference pokerl/envs/game_env.py:20-53"
+                                   % (B, T, N, ", each handle in %d sub-batches (pk_set_env_batches): one call launches one of them"
+                                      % batches[0].inner if batches[0].inner > 1 else ""),
+                       "env_batches": B, "env_inner_batches": batches[0].inner,
                        "note": "one env.step of a batch lasts as long as its slowest table (a busted seat 0 waits for the "
                                "rest of the game, game_env.py:44-47); independent batches on their own streams fill that tail"},
             "game_steps_per_s": game_steps / dt, "game_steps_per_env_step": game_steps / max(1, env_steps),
-            "ready_fraction_per_launch": env_steps / (B * T * args.steps),
+            "ready_fraction_per_launch": env_steps / float(launched_tables), "inner_batches": batches[0].inner,
             "tables_with_error_bits_in_last_step": capped}))
     pool.close()
 
@@ -352,6 +367,9 @@ def main():
     ap.add_argument("--env-async", type=int, default=0, metavar="PASSES",
                     help="--mode env through pk_env_step_async_d with this pass budget per launch (0: synchronous)")
     ap.add_argument("--env-unfused", action="store_true", help="--mode env with separate pick / step / reset / obs launches")
+    ap.add_argument("--env-inner-batches", type=int, default=1,
+                    help="--mode env --env-async: sub-batches INSIDE each handle (pk_set_env_batches): a call launches one "
+                         "range of the handle's tables and delivers the range launched longest ago")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-evaluator", action="store_true", help="skip the stand-alone evaluator kernel leg")
     ap.add_argument("--coalesce", type=int, default=-1,

@@ -34,6 +34,7 @@ extern "C" {
 #define PK_ABI_VERSION 3
 #define PK_MIN_PLAYERS 2
 #define PK_MAX_PLAYERS 10
+#define PK_MAX_ENV_BATCHES 8 /* pk_set_env_batches */
 #define PK_MAX_DEVICES 64 /* the handle-less judger calls keep one scratch arena per device index below this */
 #define PK_NUM_MOVES 7 /* pokerl/enums.py:104-114 PokerMoves */
 
@@ -266,6 +267,25 @@ int pk_env_step_fused_d(pk_handle *h, const int32_t *actions_d, int seat0_policy
 int pk_env_step_async_d(pk_handle *h, const int32_t *actions_d, int seat0_policy, int opp_policy, int auto_reset,
                         int max_passes, double *reward_d, uint8_t *done_d, uint8_t *hand_d, uint8_t *terr_d,
                         double *obs_d, uint8_t *ready_d);
+
+/* Sub-batches of pk_env_step_async_d inside ONE handle.  A bounded launch ends with a tail (its last waves run alone) and
+ * the launches of one handle are serialised on its stream, so one handle of 524 288 tables delivers 2.37 G env.step/s where
+ * the same handle in three sub-batches delivers 2.96 G (profiles/r03_env_inner_sweep.txt).  pk_set_env_batches(h, B) splits
+ * the handle's tables into B contiguous ranges (whole waves each; fewer than B for a small batch; returns the number made),
+ * each with an internal stream.  From then on a call with max_passes > 0
+ *   - LAUNCHES one range (round robin), reading actions_d only inside it, and
+ *   - DELIVERS the range launched longest ago: the handle's stream waits for that launch, and pk_env_last_range reports
+ *     [begin, end): ready_d / reward_d / ... / obs_d are complete in stream order INSIDE that range (and untouched outside).
+ *     fresh != 0: that range has not been launched yet since pk_set_env_batches / the last drain -- nothing was written, every
+ *     table of it awaits its first action (its observation is the one pk_env_reset_d / pk_get_obs_d left).
+ * The range delivered by one call is the range the next call launches, so a learner acts on [begin, end) between two
+ * calls.  max_passes <= 0 drains every range and delivers [0, T).  Per table nothing changes: the sequence of steps, outputs
+ * and RNG draws is that of the synchronous call.  Call it while no env step is in flight (PK_E_BUSY otherwise).
+ * Use B <= 3: HIP gives a process 4 hardware queues, the caller's stream + 3 internal ones use them all, and a fourth internal
+ * stream shares a queue and serialises on the cross-stream waits (524 288 tables: 2.81 / 2.96 / 2.11 G at B = 2 / 3 / 4).
+ * Ranges of >= 131 072 tables are the ones that pay (smaller batches: several handles, each on its own stream). */
+int pk_set_env_batches(pk_handle *h, int batches);
+int pk_env_last_range(pk_handle *h, int *begin, int *end, int *fresh);
 
 /* PokerGameEnv with ONE AGENT PER SEAT, some of them played by the CALLER (self-play, league opponents, a learner's
  * earlier checkpoints): pokerl/envs/game_env.py:13-18 takes a list of agent callables and calls

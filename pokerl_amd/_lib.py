@@ -29,7 +29,7 @@ SYMBOLS = ["pk_abi_version", "pk_device_count", "pk_last_error", "pk_create", "p
            "pk_get_valid_actions_d", "pk_env_step_d", "pk_env_reset_d", "pk_eval7_d", "pk_make_hands_d", "pk_time_eval7_d",
            "pk_get_serials", "pk_set_serials", "pk_get_table_f64", "pk_get_game_over", "pk_eval_hands_d",
            "pk_pick_actions_d", "pk_flush", "pk_get_owed", "pk_env_step_fused_d", "pk_env_step_async_d", "pk_set_tuning", "pk_get_stream", "pk_set_stream", "pk_wait_event",
-           "pk_record_event", "pk_use_own_stream", "pk_set_coalesce", "pk_get_launch_stats", "pk_env_step_multi_d", "pk_env_end_multi_d", "pk_get_f64_d"]
+           "pk_record_event", "pk_use_own_stream", "pk_set_coalesce", "pk_get_launch_stats", "pk_env_step_multi_d", "pk_env_end_multi_d", "pk_get_f64_d", "pk_set_env_batches", "pk_env_last_range"]
 
 
 class PokerlHipError(RuntimeError):
@@ -96,6 +96,8 @@ def lib():
     L.pk_env_step_async_d.argtypes = [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]
     L.pk_env_step_multi_d.argtypes = [_vp, _vp, _vp, C.c_uint64, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
     L.pk_env_end_multi_d.argtypes = [_vp]
+    L.pk_set_env_batches.argtypes = [_vp, C.c_int]
+    L.pk_env_last_range.argtypes = [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.pk_get_owed.argtypes = [_vp, _vp]
     L.pk_set_tuning.argtypes = [_vp, C.c_int, C.c_int]
     L.pk_get_stream.argtypes = [_vp, C.POINTER(_vp)]

@@ -46,6 +46,16 @@ struct pk_handle {
     // launches of the fused rollout kernel since pk_get_launch_stats(reset): count, steps summed, min / max steps per launch
     uint64_t st_launches = 0, st_steps = 0, st_min = 0, st_max = 0;
     int env_seat0 = 0, env_opp = 0, env_auto = 0;   // agents / auto_reset of the PokerGameEnv.steps in flight (env_pending)
+    // Sub-batches of pk_env_step_async_d inside ONE handle (pk_set_env_batches): contiguous table ranges, each on its own
+    // internal stream, launched round robin -- a call launches one range and delivers the range launched longest ago, so that
+    // the launches of the ranges overlap like those of separate handles do (a launch ends with a tail; launches on one stream
+    // are serialised).
+    int env_batches = 1, env_range = 0;             // number of ranges, tables per range (a multiple of 64)
+    hipStream_t env_streams[PK_MAX_ENV_BATCHES] = {};
+    hipEvent_t env_done[PK_MAX_ENV_BATCHES] = {};
+    bool env_launched[PK_MAX_ENV_BATCHES] = {};
+    hipEvent_t env_in = nullptr;
+    int env_next = 0, env_last_begin = 0, env_last_end = 0, env_last_fresh = 0;
     bool env_multi = false;                         // ... they belong to pk_env_step_multi_d, with these per-seat agents:
     uint64_t env_seats = 0;
     // PokerGameEnv.steps left in flight by pk_env_step_async_d (State::env_ctx): every other entry point that touches
@@ -108,6 +118,22 @@ struct DeviceGuard {
             case 8: hipLaunchKernelGGL(KERNEL<8>, g_, b_, 0, (h)->stream, __VA_ARGS__); break;                   \
             case 9: hipLaunchKernelGGL(KERNEL<9>, g_, b_, 0, (h)->stream, __VA_ARGS__); break;                   \
             case 10: hipLaunchKernelGGL(KERNEL<10>, g_, b_, 0, (h)->stream, __VA_ARGS__); break;                 \
+        }                                                                                                        \
+    } while (0)
+
+#define DISPATCH_N_ON(h, strm, KERNEL, grid, ...)                                                                \
+    do {                                                                                                         \
+        dim3 g_((grid)), b_((h)->block);                                                                         \
+        switch ((h)->N) {                                                                                        \
+            case 2: hipLaunchKernelGGL(KERNEL<2>, g_, b_, 0, (strm), __VA_ARGS__); break;                        \
+            case 3: hipLaunchKernelGGL(KERNEL<3>, g_, b_, 0, (strm), __VA_ARGS__); break;                        \
+            case 4: hipLaunchKernelGGL(KERNEL<4>, g_, b_, 0, (strm), __VA_ARGS__); break;                        \
+            case 5: hipLaunchKernelGGL(KERNEL<5>, g_, b_, 0, (strm), __VA_ARGS__); break;                        \
+            case 6: hipLaunchKernelGGL(KERNEL<6>, g_, b_, 0, (strm), __VA_ARGS__); break;                        \
+            case 7: hipLaunchKernelGGL(KERNEL<7>, g_, b_, 0, (strm), __VA_ARGS__); break;                        \
+            case 8: hipLaunchKernelGGL(KERNEL<8>, g_, b_, 0, (strm), __VA_ARGS__); break;                        \
+            case 9: hipLaunchKernelGGL(KERNEL<9>, g_, b_, 0, (strm), __VA_ARGS__); break;                        \
+            case 10: hipLaunchKernelGGL(KERNEL<10>, g_, b_, 0, (strm), __VA_ARGS__); break;                      \
         }                                                                                                        \
     } while (0)
 
@@ -345,6 +371,11 @@ int pk_destroy(pk_handle *h) {
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     for (int i = 0; i < 2; ++i) if (h->ev_ring[i]) (void)hipEventDestroy(h->ev_ring[i]);
+    for (int b = 0; b < PK_MAX_ENV_BATCHES; ++b) {
+        if (h->env_streams[b]) { (void)hipStreamSynchronize(h->env_streams[b]); (void)hipStreamDestroy(h->env_streams[b]); }
+        if (h->env_done[b]) (void)hipEventDestroy(h->env_done[b]);
+    }
+    if (h->env_in) (void)hipEventDestroy(h->env_in);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
     return PK_OK;
@@ -633,11 +664,71 @@ int pk_env_step_async_d(pk_handle *h, const int32_t *actions_d, int seat0_policy
     h->env_seat0 = s0; h->env_opp = opp_policy; h->env_auto = au;
     int rc = flush_rollout(h);
     if (rc) return rc;
-    DISPATCH_N(h, k_env_step_async, env_grid(h), (const State *)h->d_S, h->hot_env, actions_d, actions_d ? -1 : seat0_policy, uniform_seats(opp_policy),
-               auto_reset ? 1 : 0, reward_d, done_d, hand_d, terr_d, obs_d, env_park(h), ready_d, max_passes > 0 ? max_passes : 0);
-    HIPCHK(h, hipGetLastError());
+    const int mp = max_passes > 0 ? max_passes : 0;
+    if (h->env_batches <= 1) {
+        DISPATCH_N(h, k_env_step_async, env_grid(h), (const State *)h->d_S, h->hot_env, actions_d, actions_d ? -1 : seat0_policy, uniform_seats(opp_policy),
+                   au, reward_d, done_d, hand_d, terr_d, obs_d, env_park(h), ready_d, mp, 0, h->T);
+        HIPCHK(h, hipGetLastError());
+        h->env_last_begin = 0; h->env_last_end = h->T; h->env_last_fresh = 0;
+    } else {
+        // the caller's writes so far (actions of the range about to be launched) order before the launch(es) below
+        HIPCHK(h, hipEventRecord(h->env_in, h->stream));
+        auto launch_range = [&](int b, int passes) -> int {
+            const int t0 = b * h->env_range, tend = (t0 + h->env_range < h->T) ? t0 + h->env_range : h->T;
+            HIPCHK(h, hipStreamWaitEvent(h->env_streams[b], h->env_in, 0));
+            DISPATCH_N_ON(h, h->env_streams[b], k_env_step_async, (tend - t0 + h->env_tpb - 1) / h->env_tpb, (const State *)h->d_S, h->hot_env, actions_d,
+                          actions_d ? -1 : seat0_policy, uniform_seats(opp_policy), au, reward_d, done_d, hand_d, terr_d, obs_d, env_park(h), ready_d, passes, t0, tend);
+            HIPCHK(h, hipGetLastError());
+            HIPCHK(h, hipEventRecord(h->env_done[b], h->env_streams[b]));
+            return PK_OK;
+        };
+        if (mp == 0) {   // drain: every range runs to its end; everything is delivered
+            for (int b = 0; b < h->env_batches; ++b) { rc = launch_range(b, 0); if (rc) return rc; }
+            for (int b = 0; b < h->env_batches; ++b) { HIPCHK(h, hipStreamWaitEvent(h->stream, h->env_done[b], 0)); h->env_launched[b] = false; }
+            // everything is delivered; the next bounded call starts the round again with range 0
+            h->env_last_begin = 0; h->env_last_end = h->T; h->env_last_fresh = 0; h->env_next = 0;
+        } else {         // launch one range, deliver the one launched longest ago (the next in the round)
+            const int b = h->env_next, d = (b + 1) % h->env_batches;
+            rc = launch_range(b, mp);
+            if (rc) return rc;
+            h->env_launched[b] = true;
+            h->env_last_fresh = h->env_launched[d] ? 0 : 1;
+            if (h->env_launched[d]) HIPCHK(h, hipStreamWaitEvent(h->stream, h->env_done[d], 0));
+            h->env_last_begin = d * h->env_range;
+            h->env_last_end = (h->env_last_begin + h->env_range < h->T) ? h->env_last_begin + h->env_range : h->T;
+            h->env_next = d;
+        }
+    }
     h->env_pending = max_passes > 0;
     h->env_multi = false;
+    return PK_OK;
+}
+
+int pk_set_env_batches(pk_handle *h, int batches) {
+    if (!h || batches < 1 || batches > PK_MAX_ENV_BATCHES) return h ? h->fail(PK_E_INVALID_ARG, "pk_set_env_batches: 1 <= batches <= PK_MAX_ENV_BATCHES") : PK_E_INVALID_ARG;
+    ON_DEVICE(h);
+    FLUSH(h);                                         // PK_E_BUSY while env steps are in flight: drain first
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    int range = (h->T + batches - 1) / batches;
+    range = (range + 63) / 64 * 64;                   // whole waves per range
+    const int nb = (h->T + range - 1) / range;        // (fewer ranges than asked for when the batch is small)
+    for (int b = 0; b < nb && nb > 1; ++b) {
+        if (!h->env_streams[b]) HIPCHK(h, hipStreamCreateWithFlags(&h->env_streams[b], hipStreamNonBlocking));
+        if (!h->env_done[b]) HIPCHK(h, hipEventCreateWithFlags(&h->env_done[b], hipEventDisableTiming));
+        h->env_launched[b] = false;
+    }
+    if (nb > 1 && !h->env_in) HIPCHK(h, hipEventCreateWithFlags(&h->env_in, hipEventDisableTiming));
+    h->env_batches = nb; h->env_range = range; h->env_next = 0;
+    // "the range one call delivers is the range the next call launches": before the first call that is range 0, untouched
+    h->env_last_begin = 0; h->env_last_end = nb > 1 ? (range < h->T ? range : h->T) : h->T; h->env_last_fresh = nb > 1 ? 1 : 0;
+    return PK_OK;
+}
+
+int pk_env_last_range(pk_handle *h, int *begin, int *end, int *fresh) {
+    if (!h) return PK_E_INVALID_ARG;
+    if (begin) *begin = h->env_last_begin;
+    if (end) *end = h->env_last_end;
+    if (fresh) *fresh = h->env_last_fresh;
     return PK_OK;
 }
 
@@ -863,6 +954,7 @@ int pk_sync(pk_handle *h) {
     ON_DEVICE(h);
     if (!h->env_pending) FLUSH(h);   // env steps in flight stay in flight: only wait for the launches made so far
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (int b = 0; b < h->env_batches && h->env_batches > 1; ++b) HIPCHK(h, hipStreamSynchronize(h->env_streams[b]));
     return PK_OK;
 }
 

@@ -341,12 +341,12 @@ __global__ void __launch_bounds__(PK_TABLE_BLOCK) k_env_reset(const State *__res
 // StateView), its env call stays in flight exactly like a step that ran out of passes, and the next launch takes
 // actions[t] as that seat's action.  reset_req[t] != 0 starts PokerGameEnv.reset() on that table instead of a step.
 template <int N, bool ASYNC, bool MULTI>
-__device__ __forceinline__ void env_step_body(const State *__restrict__ Sp, const Hot &H, const int32_t *actions, int seat0_policy, uint64_t seatpol, int auto_reset, double *reward, uint8_t *done_out, uint8_t *hand_out, uint8_t *terr, double *obs, int park, uint8_t *ready, int max_passes, const uint8_t *reset_req, uint8_t *who_out, int abandon) {
+__device__ __forceinline__ void env_step_body(const State *__restrict__ Sp, const Hot &H, const int32_t *actions, int seat0_policy, uint64_t seatpol, int auto_reset, double *reward, uint8_t *done_out, uint8_t *hand_out, uint8_t *terr, double *obs, int park, uint8_t *ready, int max_passes, const uint8_t *reset_req, uint8_t *who_out, int abandon, int t0 = 0, int tend = 0x7fffffff) {
     static_assert(ASYNC || !MULTI, "yielding to the caller needs the in-flight context of the asynchronous form");
     const State &S = *Sp;
     __shared__ Lds<N> lds;
-    const int t = blockIdx.x * H.tpb + threadIdx.x;
-    const bool live = (int)threadIdx.x < H.tpb && t < S.T;
+    const int t = t0 + blockIdx.x * H.tpb + threadIdx.x;        // [t0, tend): the sub-range of the handle this launch serves
+    const bool live = (int)threadIdx.x < H.tpb && t < S.T && t < tend;
     const uint32_t table_id = H.table_id_base + (uint32_t)t;
     Table<N> tb;
     if (live) tb.load(S, t); else tb.blank();
@@ -524,8 +524,8 @@ __global__ void __launch_bounds__(PK_TABLE_BLOCK) k_env_step(const State *__rest
     env_step_body<N, false, false>(Sp, H, actions, seat0_policy, seatpol, auto_reset, reward, done_out, hand_out, terr, obs, park, nullptr, 0, nullptr, nullptr, 0);
 }
 template <int N>
-__global__ void __launch_bounds__(PK_TABLE_BLOCK, (N <= 6 ? 3 : 2)) k_env_step_async(const State *__restrict__ Sp, Hot H, const int32_t *actions, int seat0_policy, uint64_t seatpol, int auto_reset, double *reward, uint8_t *done_out, uint8_t *hand_out, uint8_t *terr, double *obs, int park, uint8_t *ready, int max_passes) {
-    env_step_body<N, true, false>(Sp, H, actions, seat0_policy, seatpol, auto_reset, reward, done_out, hand_out, terr, obs, park, ready, max_passes, nullptr, nullptr, 0);
+__global__ void __launch_bounds__(PK_TABLE_BLOCK, (N <= 6 ? 3 : 2)) k_env_step_async(const State *__restrict__ Sp, Hot H, const int32_t *actions, int seat0_policy, uint64_t seatpol, int auto_reset, double *reward, uint8_t *done_out, uint8_t *hand_out, uint8_t *terr, double *obs, int park, uint8_t *ready, int max_passes, int t0, int tend) {
+    env_step_body<N, true, false>(Sp, H, actions, seat0_policy, seatpol, auto_reset, reward, done_out, hand_out, terr, obs, park, ready, max_passes, nullptr, nullptr, 0, t0, tend);
 }
 template <int N>
 __global__ void __launch_bounds__(PK_TABLE_BLOCK, 2) k_env_step_multi(const State *__restrict__ Sp, Hot H, const int32_t *actions, int seat0_policy, uint64_t seatpol, int auto_reset, double *reward, uint8_t *done_out, uint8_t *hand_out, uint8_t *terr, double *obs, int park, uint8_t *ready, int max_passes, const uint8_t *reset_req, uint8_t *who_out, int abandon) {

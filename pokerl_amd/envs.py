@@ -180,6 +180,22 @@ class VecPokerGameEnv:
     def end_multi(self):
         L.check(self.game._lib.pk_env_end_multi_d(self.game._h), self.game._h)
 
+    def set_env_batches(self, batches):
+        """pk_set_env_batches: split this env's tables into `batches` contiguous ranges with internal streams; every bounded
+        step_async_d call then launches one range and delivers the range launched longest ago (see last_range).  Returns
+        the number of ranges actually made (fewer for a small batch)."""
+        g = self.game
+        L.check(g._lib.pk_set_env_batches(g._h, int(batches)), g._h)
+        return -(-g.num_tables // max(1, self.last_range()[1]))
+
+    def last_range(self):
+        """(begin, end, fresh) of the tables the last step_async_d call delivered: outputs are complete inside [begin, end);
+        fresh: that range has not been stepped yet (nothing written, every table awaits its first action)."""
+        g = self.game
+        b, e, f = L.C.c_int(0), L.C.c_int(0), L.C.c_int(0)
+        L.check(g._lib.pk_env_last_range(g._h, L.C.byref(b), L.C.byref(e), L.C.byref(f)), g._h)
+        return b.value, e.value, bool(f.value)
+
     def step_async_d(self, actions_d, reward_d, done_d, hand_d, terr_d, obs_d, ready_d, max_passes=8, seat0_policy=Policy.RANDOM,
                      auto_reset=True):
         """pk_env_step_async_d on DEVICE pointers (ints / c_void_p; actions_d None = seat 0 played by `seat0_policy`

@@ -415,3 +415,101 @@ def test_call_agent_rollout_and_pick_vs_oracle(O):
         for k in GU.SNAP_FIELDS:
             assert GU.bits_equal(so[k], sh[k]), (T, N, k)
         h.g.close()
+
+
+def test_env_sub_batches_inside_one_handle(O):
+    """pk_set_env_batches: the handle's tables split into contiguous ranges on internal streams; a bounded
+    pk_env_step_async_d call launches ONE range (reading actions only inside it) and delivers the range launched longest ago
+    (pk_env_last_range).  Per table the delivered (reward, done, hand, obs row) sequence is the synchronous one's -- with
+    seat 0's actions supplied by the caller as a function of the delivered row -- and a drain delivers everything."""
+    import pokerl_amd
+    from pokerl_amd import _lib as L
+    from pokerl_amd.hipmem import DeviceBuffer
+    lib = L.lib()
+
+    def choose(row, k):   # seat 0's host-side policy: the (k mod #valid)-th valid action of the delivered row
+        mask = row[:, 3:10] > 0
+        nth = k % mask.sum(axis=1)
+        return ((np.cumsum(mask, axis=1) - 1 == nth[:, None]) & mask).argmax(axis=1).astype(np.int32)
+
+    for T, N, opp, K, passes, B in [(3 * 2048 + 100, 6, 0, 25, 5, 3), (4096, 3, 1, 20, 2, 4), (1000, 9, 0, 15, 7, 8)]:
+        D = 17 + 3 * N
+        rew, done, hand, terr, obs, ready, act = (DeviceBuffer(T * 8), DeviceBuffer(T), DeviceBuffer(T), DeviceBuffer(T),
+                                                  DeviceBuffer(T * D * 8), DeviceBuffer(T), DeviceBuffer(T * 4))
+        outputs = lambda: (rew.download(np.float64, T), done.download(np.uint8, T), hand.download(np.uint8, T),
+                           obs.download(np.float64, T * D).reshape(T, D))
+        # ---- the synchronous sequences (checked against the oracle)
+        env = pokerl_amd.VecPokerGameEnv(opp, num_tables=T, num_players=N, seed=4321)
+        g = env.game
+        o = O.OracleGame(T, N, seed=4321)
+        row = env.reset(); o.env_reset(None, opp)
+        want = dict(rew=np.zeros((T, K)), done=np.zeros((T, K), np.uint8), hand=np.zeros((T, K), np.uint8), obs=np.zeros((T, K, D)))
+        for k in range(K):
+            a = choose(row, np.full(T, k))
+            ro, do, ho, eo = o.env_step(a, opp)
+            m = ((do != 0) | ((eo & 12) != 0)).astype(np.uint8)
+            if m.any():
+                o.env_reset(m, opp)
+            act.upload(a)
+            L.check(lib.pk_env_step_fused_d(g._h, act.ptr, 0, opp, 1, rew.ptr, done.ptr, hand.ptr, terr.ptr, obs.ptr), g._h)
+            g.sync()
+            want["rew"][:, k], want["done"][:, k], want["hand"][:, k], want["obs"][:, k] = outputs()
+            row = want["obs"][:, k]
+            assert GU.bits_equal(ro, want["rew"][:, k]) and np.array_equal(do, want["done"][:, k]) and np.array_equal(ho, want["hand"][:, k])
+        g.close()
+        # ---- the same tables through one handle with B sub-batches
+        env = pokerl_amd.VecPokerGameEnv(opp, num_tables=T, num_players=N, seed=4321)
+        g = env.game
+        row = env.reset().copy()
+        nb = env.set_env_batches(B)
+        assert 1 < nb <= B
+        b0, e0, fresh = env.last_range()
+        assert (b0, fresh) == (0, True) and 0 < e0 < T and e0 % 64 == 0
+        got = {k: np.zeros_like(v) for k, v in want.items()}
+        count = np.zeros(T, np.int64)
+        waiting = np.ones(T, bool)                  # tables that are to be given an action (all of them after the reset)
+        ranges, launches, in_flight_seen = set(), 0, 0
+        while count.min() < K:
+            launches += 1
+            assert launches < 100 * K * nb, ("no progress", T, N, B)
+            lb, le, _ = env.last_range()            # the range this call will launch = the one delivered last
+            a = np.full(T, -1, np.int32)            # garbage outside the range and for tables in flight: must be ignored
+            idx = np.nonzero(waiting[lb:le])[0] + lb
+            a[idx] = choose(row[idx], count[idx])
+            waiting[lb:le] = False
+            act.upload(a)
+            env.step_async_d(act.ptr, rew.ptr, done.ptr, hand.ptr, terr.ptr, obs.ptr, ready.ptr, max_passes=passes)
+            g.sync()
+            db, de, fresh = env.last_range()
+            ranges.add((db, de))
+            if fresh:                               # not launched yet: untouched, every table awaits its first action
+                assert waiting[db:de].all()
+                continue
+            r = ready.download(np.uint8, T)[db:de] != 0
+            in_flight_seen += int((~r).sum())
+            assert not terr.download(np.uint8, T)[db:de][r].any()
+            out = outputs()
+            t_idx = np.nonzero(r)[0] + db
+            row[t_idx] = out[3][t_idx]
+            use = t_idx[count[t_idx] < K]
+            c = count[use]
+            got["rew"][use, c], got["done"][use, c], got["hand"][use, c], got["obs"][use, c] = (x[use] for x in out)
+            count[t_idx] += 1
+            waiting[t_idx] = True
+        assert len(ranges) == nb and in_flight_seen > 0, (ranges, in_flight_seen)
+        for k in want:
+            same = GU.bits_equal(want[k], got[k]) if want[k].dtype == np.float64 else np.array_equal(want[k], got[k])
+            assert same, (T, N, B, k)
+        with pytest.raises(L.PokerlHipError):
+            g.credits                               # steps are in flight
+        with pytest.raises(L.PokerlHipError):
+            env.set_env_batches(2)
+        # drain: every range runs to its end, everything is delivered, the handle is readable again
+        a = np.full(T, -1, np.int32)
+        a[waiting] = choose(row[waiting], count[waiting])
+        act.upload(a)
+        env.step_async_d(act.ptr, rew.ptr, done.ptr, hand.ptr, terr.ptr, obs.ptr, ready.ptr, max_passes=0)
+        g.sync()
+        assert env.last_range() == (0, T, False) and (ready.download(np.uint8, T) != 0).all()
+        assert GU.bits_equal(obs.download(np.float64, T * D).reshape(T, D), g.observations)
+        env.close()

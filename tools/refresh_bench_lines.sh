@@ -15,6 +15,7 @@ python bench.py --mode env --steps 200 --warmup 20 2>/dev/null | tail -1 > gpuru
 python bench.py --mode env --steps 200 --warmup 20 --env-batches 4 2>/dev/null | tail -1 > gpurun_out/${R}_bench_env_sync_batches4.json
 python bench.py --mode env --steps 2000 --warmup 200 --env-async 8 2>/dev/null | tail -1 > gpurun_out/${R}_bench_env_async8_batches1.json
 python bench.py --mode env --steps 2000 --warmup 200 --env-async 8 --env-batches 4 2>/dev/null | tail -1 > gpurun_out/${R}_bench_env_async8_batches4.json
+python bench.py --mode env --steps 2000 --warmup 200 --env-async 8 --tables 524288 --env-inner-batches 3 2>/dev/null | tail -1 > gpurun_out/${R}_bench_env_async8_inner3_524288.json
 python tools/launch_overhead.py > gpurun_out/${R}_launch_overhead.txt 2>&1
 python tools/measure_api.py > gpurun_out/${R}_measure_api.txt 2>&1
 echo refreshed bench lines $R

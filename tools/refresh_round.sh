@@ -22,6 +22,7 @@ python bench.py --mode env --steps 200 --warmup 20 2>/dev/null | tail -1 > gpuru
 python bench.py --mode env --steps 200 --warmup 20 --env-batches 4 2>/dev/null | tail -1 > gpurun_out/${R}_bench_env_sync_batches4.json
 python bench.py --mode env --steps 2000 --warmup 200 --env-async 8 2>/dev/null | tail -1 > gpurun_out/${R}_bench_env_async8_batches1.json
 python bench.py --mode env --steps 2000 --warmup 200 --env-async 8 --env-batches 4 2>/dev/null | tail -1 > gpurun_out/${R}_bench_env_async8_batches4.json
+python bench.py --mode env --steps 2000 --warmup 200 --env-async 8 --tables 524288 --env-inner-batches 3 2>/dev/null | tail -1 > gpurun_out/${R}_bench_env_async8_inner3_524288.json
 python tools/launch_overhead.py > gpurun_out/${R}_launch_overhead.txt 2>&1
 for c in 128 256 512 1024 2048; do echo "coalesce $c: $(python bench.py --gpus 1 --steps 20 --warmup 5 --coalesce $c --no-cpu-baseline --no-evaluator --samples 3 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('%.2f G  %s' % (r['value']/1e9, r['config']['launch_stats']))")"; done > gpurun_out/${R}_coalesce_sweep.txt 2>&1
 echo refreshed $R

@@ -14,7 +14,7 @@ PY
 done
 cp gpurun_out/${R}_launch_overhead.txt profiles/${R}_launch_overhead.txt
 cp gpurun_out/${R}_coalesce_sweep.txt profiles/${R}_coalesce_sweep.txt
-for f in driver driver_nocoalesce 65536x6 65536x9_allin 4096x2 1048576x6 65536x6_unfused env env_sync_batches4 env_async8_batches1 env_async8_batches4; do
+for f in driver driver_nocoalesce 65536x6 65536x9_allin 4096x2 1048576x6 65536x6_unfused env env_sync_batches4 env_async8_batches1 env_async8_batches4 env_async8_inner3_524288; do
   tail -1 gpurun_out/${R}_bench_$f.json > profiles/${R}_bench_$f.json
   python - <<PY
 import json
