@@ -33,7 +33,8 @@ extern "C" {
 
 #define PK_ABI_VERSION 3
 #define PK_MIN_PLAYERS 2
-#define PK_MAX_PLAYERS 10
+#define PK_MAX_PLAYERS 15 /* the reference takes any num_players (game.py:246); up to 15 every numpy routine it calls behaves as
+                             for a short array (np.sum: one 8-way block; np.argsort: insertion sort, stable): see DESIGN.md section 9 */
 #define PK_MAX_ENV_BATCHES 8 /* pk_set_env_batches */
 #define PK_MAX_DEVICES 64 /* the handle-less judger calls keep one scratch arena per device index below this */
 #define PK_NUM_MOVES 7 /* pokerl/enums.py:104-114 PokerMoves */

@@ -105,37 +105,29 @@ struct DeviceGuard {
         if (e_ != hipSuccess) return (h)->fail(PK_E_HIP, #call, e_); \
     } while (0)
 
-#define DISPATCH_N(h, KERNEL, grid, ...)                                                                         \
-    do {                                                                                                         \
-        dim3 g_((grid)), b_((h)->block);                                                                         \
-        switch ((h)->N) {                                                                                        \
-            case 2: hipLaunchKernelGGL(KERNEL<2>, g_, b_, 0, (h)->stream, __VA_ARGS__); break;                   \
-            case 3: hipLaunchKernelGGL(KERNEL<3>, g_, b_, 0, (h)->stream, __VA_ARGS__); break;                   \
-            case 4: hipLaunchKernelGGL(KERNEL<4>, g_, b_, 0, (h)->stream, __VA_ARGS__); break;                   \
-            case 5: hipLaunchKernelGGL(KERNEL<5>, g_, b_, 0, (h)->stream, __VA_ARGS__); break;                   \
-            case 6: hipLaunchKernelGGL(KERNEL<6>, g_, b_, 0, (h)->stream, __VA_ARGS__); break;                   \
-            case 7: hipLaunchKernelGGL(KERNEL<7>, g_, b_, 0, (h)->stream, __VA_ARGS__); break;                   \
-            case 8: hipLaunchKernelGGL(KERNEL<8>, g_, b_, 0, (h)->stream, __VA_ARGS__); break;                   \
-            case 9: hipLaunchKernelGGL(KERNEL<9>, g_, b_, 0, (h)->stream, __VA_ARGS__); break;                   \
-            case 10: hipLaunchKernelGGL(KERNEL<10>, g_, b_, 0, (h)->stream, __VA_ARGS__); break;                 \
-        }                                                                                                        \
+// one instantiation of every table kernel per seat count, PK_MIN_PLAYERS .. PK_MAX_PLAYERS
+static_assert(PK_MIN_PLAYERS == 2 && PK_MAX_PLAYERS == 15, "the dispatch below lists the seat counts");
+#define DISPATCH_N_ON(h, strm, KERNEL, grid, ...) \
+    do { \
+        dim3 g_((grid)), b_((h)->block); \
+        switch ((h)->N) { \
+            case 2: hipLaunchKernelGGL(KERNEL<2>, g_, b_, 0, (strm), __VA_ARGS__); break; \
+            case 3: hipLaunchKernelGGL(KERNEL<3>, g_, b_, 0, (strm), __VA_ARGS__); break; \
+            case 4: hipLaunchKernelGGL(KERNEL<4>, g_, b_, 0, (strm), __VA_ARGS__); break; \
+            case 5: hipLaunchKernelGGL(KERNEL<5>, g_, b_, 0, (strm), __VA_ARGS__); break; \
+            case 6: hipLaunchKernelGGL(KERNEL<6>, g_, b_, 0, (strm), __VA_ARGS__); break; \
+            case 7: hipLaunchKernelGGL(KERNEL<7>, g_, b_, 0, (strm), __VA_ARGS__); break; \
+            case 8: hipLaunchKernelGGL(KERNEL<8>, g_, b_, 0, (strm), __VA_ARGS__); break; \
+            case 9: hipLaunchKernelGGL(KERNEL<9>, g_, b_, 0, (strm), __VA_ARGS__); break; \
+            case 10: hipLaunchKernelGGL(KERNEL<10>, g_, b_, 0, (strm), __VA_ARGS__); break; \
+            case 11: hipLaunchKernelGGL(KERNEL<11>, g_, b_, 0, (strm), __VA_ARGS__); break; \
+            case 12: hipLaunchKernelGGL(KERNEL<12>, g_, b_, 0, (strm), __VA_ARGS__); break; \
+            case 13: hipLaunchKernelGGL(KERNEL<13>, g_, b_, 0, (strm), __VA_ARGS__); break; \
+            case 14: hipLaunchKernelGGL(KERNEL<14>, g_, b_, 0, (strm), __VA_ARGS__); break; \
+            case 15: hipLaunchKernelGGL(KERNEL<15>, g_, b_, 0, (strm), __VA_ARGS__); break; \
+        } \
     } while (0)
-
-#define DISPATCH_N_ON(h, strm, KERNEL, grid, ...)                                                                \
-    do {                                                                                                         \
-        dim3 g_((grid)), b_((h)->block);                                                                         \
-        switch ((h)->N) {                                                                                        \
-            case 2: hipLaunchKernelGGL(KERNEL<2>, g_, b_, 0, (strm), __VA_ARGS__); break;                        \
-            case 3: hipLaunchKernelGGL(KERNEL<3>, g_, b_, 0, (strm), __VA_ARGS__); break;                        \
-            case 4: hipLaunchKernelGGL(KERNEL<4>, g_, b_, 0, (strm), __VA_ARGS__); break;                        \
-            case 5: hipLaunchKernelGGL(KERNEL<5>, g_, b_, 0, (strm), __VA_ARGS__); break;                        \
-            case 6: hipLaunchKernelGGL(KERNEL<6>, g_, b_, 0, (strm), __VA_ARGS__); break;                        \
-            case 7: hipLaunchKernelGGL(KERNEL<7>, g_, b_, 0, (strm), __VA_ARGS__); break;                        \
-            case 8: hipLaunchKernelGGL(KERNEL<8>, g_, b_, 0, (strm), __VA_ARGS__); break;                        \
-            case 9: hipLaunchKernelGGL(KERNEL<9>, g_, b_, 0, (strm), __VA_ARGS__); break;                        \
-            case 10: hipLaunchKernelGGL(KERNEL<10>, g_, b_, 0, (strm), __VA_ARGS__); break;                      \
-        }                                                                                                        \
-    } while (0)
+#define DISPATCH_N(h, KERNEL, grid, ...) DISPATCH_N_ON(h, (h)->stream, KERNEL, grid, __VA_ARGS__)
 
 static inline bool bad_policy(int policy) { return policy < 0 || policy >= PK_NUM_POLICIES; }
 // every seat plays `policy`: the per-seat word of the entry points that take ONE opponent policy
@@ -235,7 +227,7 @@ int pk_create(pk_handle **out, int device, int num_tables, int num_players, cons
     if (!out) { g_err = "pk_create: out is NULL"; return PK_E_INVALID_ARG; }
     *out = nullptr;
     if (num_tables < 1 || num_players < PK_MIN_PLAYERS || num_players > PK_MAX_PLAYERS) {
-        g_err = "pk_create: need num_tables >= 1 and 2 <= num_players <= 10";
+        g_err = "pk_create: need num_tables >= 1 and 2 <= num_players <= 15";
         return PK_E_INVALID_ARG;
     }
     int ndev = 0;

@@ -3,7 +3,8 @@
 /root/reference through make_golden's injection harness; nothing is written).  A configuration on which the reference
 itself never returns (Game.step spins) is skipped after a time-out.
 
-    PYTHONDONTWRITEBYTECODE=1 python tests/golden/fuzz_oracle_vs_reference.py [rounds]
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/fuzz_oracle_vs_reference.py [rounds] [min_seats max_seats]
+(seats default 2..10: the generator sequence of the recorded runs; `200 11 15` fuzzes the wide tables)
 """
 import os
 import random
@@ -39,13 +40,31 @@ def make_oracle(meta):
                         seed=meta["seed"], table_id_base=meta["table_id_base"])
 
 
+def env_cap_hit(out, meta):
+    """True if the oracle stops one of this trajectory's env calls with ORC_ERR_ENV_CAP (8)."""
+    import numpy as np
+    b = make_oracle(meta)
+    opp = meta["opp_policy"]
+    b.env_reset(None, opp)
+    for s in range(meta["steps"]):
+        _, done, _, err = b.env_step(out["actions"][s].astype(np.int32), opp)
+        if (err & 8).any():
+            return True
+        if err.any():
+            return False
+        if done.any():
+            b.env_reset(done, opp)
+    return False
+
+
 def main():
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 120
+    lo, hi = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (2, 10)
     rng = random.Random(2026)
     signal.signal(signal.SIGALRM, _alarm)
     ok = skipped = capped = 0
     for i in range(rounds):
-        n = rng.randint(2, 10)
+        n = rng.randint(lo, hi)
         same = rng.random() < 0.5
         start = rng.choice(STACKS) if same else [rng.choice(STACKS) for _ in range(n)]
         if same and isinstance(start, float) and start != int(start):
@@ -81,9 +100,9 @@ def main():
           "%d stopped by the hand cap where the reference rolled > 4096 hands in one step" % (ok, skipped, capped))
     # ---- PokerGameEnv.reset / step (envs/game_env.py:20-53) on odd configurations: reward / done / hand and the whole
     #      table state after every env.step and after every reset of a finished episode
-    env_ok = env_skipped = 0
+    env_ok = env_skipped = env_capped = 0
     for i in range(max(10, rounds // 3)):
-        n = rng.randint(2, 10)
+        n = rng.randint(lo, hi)
         same = rng.random() < 0.5
         stacks = [x for x in STACKS if x >= 2]
         start = int(rng.choice([x for x in stacks if x == int(x)])) if same else [rng.choice(stacks) for _ in range(n)]
@@ -106,10 +125,15 @@ def main():
         try:
             GU.replay_env(make_oracle, "envfuzz%d" % i, loaded=(out, meta))
         except AssertionError as e:
+            if env_cap_hit(out, meta):      # the documented divergence: the reference plays on past ORC_ENV_STEP_CAP opponent steps
+                env_capped += 1
+                print("env cap (reference auto-plays more than 8 192 opponent steps in one call): n=%d cfg=%s opp=%s" % (n, cfg, opp), flush=True)
+                continue
             print("ENV MISMATCH n=%d cfg=%s opp=%s seed=%d base=%d\n%s" % (n, cfg, opp, seed, base, e))
             return 1
         env_ok += 1
-    print("fuzz oracle vs reference, PokerGameEnv: %d configurations identical, %d skipped" % (env_ok, env_skipped))
+    print("fuzz oracle vs reference, PokerGameEnv: %d configurations identical, %d skipped, %d stopped by the env step cap"
+          % (env_ok, env_skipped, env_capped))
     return 0
 
 

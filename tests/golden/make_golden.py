@@ -493,6 +493,9 @@ GAME_SETS = {
     "game_n3_percredits": (3, R.POLICY_RANDOM, 7, 6, 200, 77,
                            dict(start_credits=[30, 100, 5], big_blind=4, small_blind=2)),
     "game_n10_random": (10, R.POLICY_RANDOM, 99, 4, 150, 5, None),
+    # round 3: more than ten seats (PK_MAX_PLAYERS 15: np.sum's unrolled block once, np.argsort's insertion sort)
+    "game_n12_random": (12, R.POLICY_RANDOM, 1212, 4, 160, 3, None),
+    "game_n15_random": (15, R.POLICY_RANDOM, 1515, 4, 160, 0, dict(start_credits=50, big_blind=4, small_blind=2)),
 }
 # odd configurations found worth pinning by tests/golden/fuzz_oracle_vs_reference.py: (n, policy, seed, tables, steps, base, cfg, dealer)
 # resumed RNG streams: hand_serial crosses 2^32 and the action block index (step_serial >> 3) crosses 2^32 mid-run
@@ -503,12 +506,15 @@ SERIAL_SETS = {
 VIEW_SETS = {
     "views_n6_random": (6, R.POLICY_RANDOM, SEED ^ 0x77, 4, 60, 0, None),
     "views_n3_percredits": (3, R.POLICY_RANDOM, 7, 4, 60, 77, dict(start_credits=[30, 100, 5], big_blind=4, small_blind=2)),
+    "views_n13_random": (13, R.POLICY_RANDOM, 1313, 2, 24, 0, None),
 }
 ODD_SETS = {
     "game_n5_zero_blinds": (5, R.POLICY_RANDOM, 21, 6, 150, 9, dict(start_credits=10, big_blind=0, small_blind=0), 3),
     "game_n4_sb_gt_bb_fractional": (4, R.POLICY_RANDOM, 22, 6, 150, 0, dict(start_credits=[37.5, 3, 1000, 0.5], big_blind=0.25, small_blind=7.5), 1),
     "game_n7_blinds_gt_stacks": (7, R.POLICY_RANDOM, 23, 6, 150, 4000000000, dict(start_credits=5, big_blind=40, small_blind=250), 6),
     "game_n8_mixed_allin": (8, R.POLICY_ALLIN, 24, 6, 100, 0, dict(start_credits=[1, 2, 3, 5, 10, 100, 1000, 0.5], big_blind=3, small_blind=1), 0),
+    "game_n14_mixed_allin": (14, R.POLICY_ALLIN, 1414, 4, 100, 77,
+                             dict(start_credits=[1, 2, 3, 5, 10, 100, 1000, 0.5, 37.5, 3, 2, 10, 5, 100], big_blind=3, small_blind=1), 11),
 }
 # Configurations whose payoffs DEPEND on the order in which np.argsort(bets) (game.py:495) returns seats with EQUAL bets
 # (found with the fuzz generator): the reference with its pinned numpy (stable), which the fixtures pin, differs from the
@@ -538,6 +544,7 @@ DIGEST_SETS = {
     "digest_n9_allin": (9, R.POLICY_ALLIN, SEED, 32, 1000, 0, None),
     "digest_n6_shard1": (6, R.POLICY_RANDOM, SEED, 32, 1000, 65536, None),  # table_id_base of rank 1 at C4
     "digest_n6_shard7": (6, R.POLICY_RANDOM, SEED, 32, 1000, 7 * 65536, None),  # ... of rank 7 (last shard of 524 288)
+    "digest_n15_random": (15, R.POLICY_RANDOM, SEED, 16, 800, 0, None),
 }
 ENV_SETS = {
     "env_n4_random": (4, R.POLICY_RANDOM, R.POLICY_RANDOM, SEED, 8, 200, 0, None),
@@ -557,6 +564,11 @@ ENV_SETS = {
     "env_n6_mixed_percredits": (6, R.POLICY_RANDOM, [R.POLICY_CALL, R.POLICY_CALL, R.POLICY_ALLIN, R.POLICY_RANDOM, R.POLICY_CALL],
                                 424242, 6, 150, 123456, dict(start_credits=[50, 100, 20, 200, 100, 75], big_blind=4, small_blind=2)),
     "env_n2_call_vs_call": (2, R.POLICY_CALL, R.POLICY_CALL, 5, 4, 120, 0, dict(start_credits=6, big_blind=2, small_blind=1)),
+    # more than ten seats: random opponents, and one agent per seat with seats 8..10 (policy nibbles above bit 31) differing
+    "env_n11_random": (11, R.POLICY_RANDOM, R.POLICY_RANDOM, 1111, 4, 100, 0, None),
+    "env_n12_mixed_opponents": (12, R.POLICY_RANDOM, [R.POLICY_RANDOM, R.POLICY_ALLIN, R.POLICY_RANDOM, R.POLICY_CALL, R.POLICY_RANDOM, R.POLICY_RANDOM,
+                                                     R.POLICY_ALLIN, R.POLICY_CALL, R.POLICY_ALLIN, R.POLICY_RANDOM, R.POLICY_CALL],
+                                1212, 4, 100, 9, dict(start_credits=40, big_blind=4, small_blind=2)),
 }
 
 

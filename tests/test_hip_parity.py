@@ -364,8 +364,8 @@ def test_observation_and_cards(HB, O):
 
 
 def test_all_player_counts_fused_vs_oracle(HB, O):
-    """Every template instantiation (N = 2..10), ragged table count, both policies."""
-    for N in range(2, 11):
+    """Every template instantiation (N = 2..15), ragged table count, both policies."""
+    for N in range(2, 16):
         for policy in (0, 1):
             T, K = 1000 + N, 150
             o = O.OracleGame(T, N, seed=N * 17 + policy)
@@ -450,7 +450,7 @@ def test_bad_arguments_are_reported_not_fatal(HB):
     from pokerl_amd import _lib as L
     lib = L.lib()
     h = C.c_void_p()
-    assert lib.pk_create(C.byref(h), 0, 16, 11, None, 100.0, 2.0, 1.0, 0, 1, 0) == L.PK_E_INVALID_ARG   # N > 10
+    assert lib.pk_create(C.byref(h), 0, 16, 16, None, 100.0, 2.0, 1.0, 0, 1, 0) == L.PK_E_INVALID_ARG   # N > 15
     assert lib.pk_create(C.byref(h), 0, 0, 4, None, 100.0, 2.0, 1.0, 0, 1, 0) == L.PK_E_INVALID_ARG     # T < 1
     assert lib.pk_create(C.byref(h), 99, 16, 4, None, 100.0, 2.0, 1.0, 0, 1, 0) == L.PK_E_INVALID_ARG   # no such device
     assert b"device" in lib.pk_last_error(None)
@@ -583,8 +583,8 @@ def test_random_configurations_vs_oracle(HB, O):
     rng = random.Random(99)
     stacks = [0.5, 1, 2, 3, 5, 10, 37.5, 100, 1000, 1e6]
     blinds = [0, 0.25, 0.5, 1, 2, 3, 7.5, 40]
-    for i in range(36):
-        N = 2 + i % 9
+    for i in range(42):
+        N = 2 + i % 14
         start = [rng.choice(stacks) for _ in range(N)] if rng.random() < 0.5 else rng.choice(stacks)
         bb, sb = rng.choice(blinds), rng.choice(blinds)
         policy = 1 if rng.random() < 0.25 else 0
