@@ -122,8 +122,9 @@ VALU_PEAK_WAVE_INSTS_PER_S = 256 * 4 * 2.4e9 / 2.0   # 256 CUs x 4 SIMDs, one wa
 # subset: r02_valu_rates.txt), by waves per SIMD: (the plain VOP2 ALU kinds -- v_add / v_sub / v_and / v_or / v_xor, independent
 # stream; everything else the step machine is made of -- every f64 op, shifts, v_bfe, v_bcnt, v_ffbh, multiplies, v_perm,
 # v_max, the three-operand forms v_or3 / v_lshl_or / v_max3 / v_lshl_add_u64, v_cndmask on an SGPR mask -- which all issue
-# at half rate).  A lone wave issues ~one instruction per 5 cycles whatever its kind; three waves per SIMD are interpolated.
-ISSUE_CYCLES = {1: (5.0, 5.0), 2: (2.7, 4.5), 3: (2.55, 4.4), 4: (2.45, 4.3)}
+# at half rate).  A lone wave issues ~one instruction per 5 cycles whatever its kind; three waves per SIMD are interpolated
+# (towards the four-wave figures: with the two-wave ones the 1 M-table run exceeded its own ceiling by 1 %).
+ISSUE_CYCLES = {1: (5.0, 5.0), 2: (2.7, 4.5), 3: (2.5, 4.3), 4: (2.45, 4.3)}
 HALF_RATE_SHARE = 0.60   # of k_rollout<6>'s VALU instructions, by the opcode histogram of its ISA with v_mov and the 32-bit
 #                          v_cmp counted as plain (v_cndmask 20 %, f64 10 %, shifts / bfe / bcnt / ffbl / mul / perm 15 %,
 #                          three-operand and 64-bit integer forms 15 %): an estimate -- the ceiling is a model, not a measurement

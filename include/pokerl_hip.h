@@ -272,7 +272,7 @@ int pk_env_step_async_d(pk_handle *h, const int32_t *actions_d, int seat0_policy
 /* Sub-batches of pk_env_step_async_d inside ONE handle.  A bounded launch ends with a tail (its last waves run alone) and
  * the launches of one handle are serialised on its stream, so one handle of 524 288 tables delivers 2.37 G env.step/s where
  * the same handle in three sub-batches delivers 2.96 G (profiles/r03_env_inner_sweep.txt).  pk_set_env_batches(h, B) splits
- * the handle's tables into B contiguous ranges (whole waves each; fewer than B for a small batch; returns the number made),
+ * the handle's tables into B contiguous ranges (whole waves each; fewer than B for a small batch: right after the call pk_env_last_range reports range 0, [0, tables per range)),
  * each with an internal stream.  From then on a call with max_passes > 0
  *   - LAUNCHES one range (round robin), reading actions_d only inside it, and
  *   - DELIVERS the range launched longest ago: the handle's stream waits for that launch, and pk_env_last_range reports

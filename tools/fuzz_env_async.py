@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """One-off confidence run (GPU box): pk_env_step_async_d against pk_env_step_fused_d and the CPU oracle over seeded odd
-configurations (every N, odd blinds / stacks, both opponent policies, pass budgets 1..9): per table the delivered
-(reward, done, hand, obs row) sequence must equal the synchronous one bit for bit.
+configurations (every N, odd blinds / stacks, both opponent policies, pass budgets 1..9, half of them with the handle split
+into 2..8 sub-batches by pk_set_env_batches): per table the delivered (reward, done, hand, obs row) sequence must equal the
+synchronous one bit for bit.
 usage: python tools/fuzz_env_async.py [configs] [seed]"""
 import os
 import random
@@ -22,7 +23,7 @@ rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
 stacks = [1, 2, 5, 10, 37.5, 100, 1000]
 blinds = [0.5, 1, 2, 3, 7.5, 40]
 lib = L.lib()
-delivered = 0
+delivered = sub = 0
 for i in range(n_cfg):
     N = 2 + i % 14
     start = [rng.choice(stacks) for _ in range(N)] if rng.random() < 0.5 else rng.choice(stacks)
@@ -30,8 +31,9 @@ for i in range(n_cfg):
     opp = 1 if rng.random() < 0.25 else 0
     seed, base = rng.getrandbits(63), rng.getrandbits(32) & 0xFFFFF000
     T, K, passes = rng.choice([65, 300, 1000]), rng.choice([8, 15, 25]), rng.randrange(1, 10)
+    B = rng.choice([1, 1, 1, 2, 3, 4, 8])
     cfg = dict(num_tables=T, num_players=N, start_credits=start, big_blind=bb, small_blind=sb, seed=seed, table_id_base=base)
-    where = "cfg %d: %s opp=%d K=%d passes=%d" % (i, cfg, opp, K, passes)
+    where = "cfg %d: %s opp=%d K=%d passes=%d sub-batches=%d" % (i, cfg, opp, K, passes, B)
     D = 17 + 3 * N
     rew, done, hand, terr, obs, ready = (DeviceBuffer(T * 8), DeviceBuffer(T), DeviceBuffer(T), DeviceBuffer(T),
                                          DeviceBuffer(T * D * 8), DeviceBuffer(T))
@@ -58,14 +60,23 @@ for i in range(n_cfg):
     env = pokerl_amd.VecPokerGameEnv(opp, **cfg)
     g = env.game
     env.reset()
+    nb = env.set_env_batches(B) if B > 1 else 1
+    sub += int(nb > 1)
     count = np.zeros(T, np.int64)
     launches = 0
     while count.min() < K:
         launches += 1
-        assert launches < 200 * K, where
+        assert launches < 200 * K * nb, where
         env.step_async_d(None, rew.ptr, done.ptr, hand.ptr, terr.ptr, obs.ptr, ready.ptr, max_passes=passes)
         g.sync()
         r = ready.download(np.uint8, T) != 0
+        if nb > 1:                                   # one range was launched; outputs are complete inside the DELIVERED range only
+            db, de, fresh = env.last_range()
+            if fresh:
+                continue
+            inside = np.zeros(T, bool)
+            inside[db:de] = True
+            r &= inside
         w = out()
         for t in np.nonzero(r & (count < K))[0]:
             k = count[t]
@@ -78,4 +89,5 @@ for i in range(n_cfg):
     g.close()
     if i % 20 == 19:
         print("%d configurations bit-exact so far" % (i + 1), flush=True)
-print("fuzz: %d configurations, %d env.steps delivered asynchronously, all equal to the synchronous sequences" % (n_cfg, delivered))
+print("fuzz: %d configurations (%d with sub-batches inside the handle), %d env.steps delivered asynchronously, all equal to the synchronous sequences"
+      % (n_cfg, sub, delivered))
