@@ -128,6 +128,22 @@ static_assert(PK_MIN_PLAYERS == 2 && PK_MAX_PLAYERS == 15, "the dispatch below l
         } \
     } while (0)
 #define DISPATCH_N(h, KERNEL, grid, ...) DISPATCH_N_ON(h, (h)->stream, KERNEL, grid, __VA_ARGS__)
+// ... for the kernels that exist for up to ten seats only (the 168-register variants: beyond ten seats they would spill)
+#define DISPATCH_N_LE10(h, KERNEL, grid, ...) \
+    do { \
+        dim3 g_((grid)), b_((h)->block); \
+        switch ((h)->N) { \
+            case 2: hipLaunchKernelGGL(KERNEL<2>, g_, b_, 0, (h)->stream, __VA_ARGS__); break; \
+            case 3: hipLaunchKernelGGL(KERNEL<3>, g_, b_, 0, (h)->stream, __VA_ARGS__); break; \
+            case 4: hipLaunchKernelGGL(KERNEL<4>, g_, b_, 0, (h)->stream, __VA_ARGS__); break; \
+            case 5: hipLaunchKernelGGL(KERNEL<5>, g_, b_, 0, (h)->stream, __VA_ARGS__); break; \
+            case 6: hipLaunchKernelGGL(KERNEL<6>, g_, b_, 0, (h)->stream, __VA_ARGS__); break; \
+            case 7: hipLaunchKernelGGL(KERNEL<7>, g_, b_, 0, (h)->stream, __VA_ARGS__); break; \
+            case 8: hipLaunchKernelGGL(KERNEL<8>, g_, b_, 0, (h)->stream, __VA_ARGS__); break; \
+            case 9: hipLaunchKernelGGL(KERNEL<9>, g_, b_, 0, (h)->stream, __VA_ARGS__); break; \
+            case 10: hipLaunchKernelGGL(KERNEL<10>, g_, b_, 0, (h)->stream, __VA_ARGS__); break; \
+        } \
+    } while (0)
 
 static inline bool bad_policy(int policy) { return policy < 0 || policy >= PK_NUM_POLICIES; }
 // every seat plays `policy`: the per-seat word of the entry points that take ONE opponent policy
@@ -153,8 +169,8 @@ static int launch_rollout(pk_handle *h, int k_steps, int policy, int auto_reset,
         if (policy == PK_POLICY_RANDOM) DISPATCH_N(h, k_rollout, table_grid(h), ROLLOUT_ARGS);
         else DISPATCH_N(h, k_rollout_allin, table_grid(h), ROLLOUT_ARGS);
     } else {
-        if (policy == PK_POLICY_RANDOM) DISPATCH_N(h, k_rollout_occ3, table_grid(h), ROLLOUT_ARGS);
-        else DISPATCH_N(h, k_rollout_occ3_allin, table_grid(h), ROLLOUT_ARGS);
+        if (policy == PK_POLICY_RANDOM) DISPATCH_N_LE10(h, k_rollout_occ3, table_grid(h), ROLLOUT_ARGS);
+        else DISPATCH_N_LE10(h, k_rollout_occ3_allin, table_grid(h), ROLLOUT_ARGS);
     }
 #undef ROLLOUT_ARGS
     HIPCHK(h, hipGetLastError());
@@ -253,7 +269,7 @@ int pk_create(pk_handle **out, int device, int num_tables, int num_players, cons
         // loses 10..35 % at every batch size.
         h->occ3 = (num_players == 6 && num_tables > 131072) || (num_players == 7 && num_tables >= 262144) ||
                   (num_players == 8 && num_tables >= 524288);
-        if (const char *pk = getenv("PK_OCC3")) h->occ3 = atoi(pk) != 0;
+        if (const char *pk = getenv("PK_OCC3")) h->occ3 = atoi(pk) != 0 && num_players <= 10;
     }
     {   // The env kernels are bound by the tail of the slowest table of a wave (a busted seat 0 waits for the end of the game),
         // not by issue slots: half-populated waves halve that tail and bring a second wave to each SIMD
