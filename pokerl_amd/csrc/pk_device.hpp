@@ -942,8 +942,10 @@ struct Table {
     // end_hand + setup_hand for every lane parked at LS_END (game.py:453-539), executed by the WHOLE wave.
     // auto_reset: a finished game (or a table that hit PK_HAND_CAP, which the reference would never leave) is
     // Game.reset() on the spot, as the rollout/bench loop does on the host side of the reference.
-    // ONE_PASS == false: the side-pot loop runs to its end inside the call (no LS_POT): kept for A/B measurements, it is
-    // slower at every batch size (21.9 vs 23.4 G at 65 536 x 6, 34.5 vs 37.0 G at 1 M x 6).
+    // ONE_PASS == false: the side-pot loop runs to its end inside the call (no LS_POT).  Slower for the multi-step rollout at
+    // every batch size (21.9 vs 23.4 G at 65 536 x 6, 34.5 vs 37.0 G at 1 M x 6), faster where a launch ends with a few lanes
+    // per wave anyway, so that every further end_block call serves one or two tables: the single-step kernels (k_step,
+    // k_rollout_single: +3.9 %), the synchronous PokerGameEnv.step (+3.1 %) and k_env_reset.
     template <bool ONE_PASS = true>
     __device__ __forceinline__ void end_block(const Hot &S, int t, uint32_t table_id, Lds<N> &lds, bool auto_reset) {
         const bool e = lstate == LS_END;

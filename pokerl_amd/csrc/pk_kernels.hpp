@@ -239,11 +239,11 @@ __global__ void __launch_bounds__(PK_TABLE_BLOCK, 2) PK_ROLLOUT_ATTR k_rollout_a
 // with fused == 0: the state round-trips HBM every step): the same body with one betting pass per look at the parked lanes.
 template <int N>
 __global__ void __launch_bounds__(PK_TABLE_BLOCK, 2) k_step(const State *__restrict__ Sp, Hot H, const int32_t *actions, uint8_t *flags, uint8_t *terr, int park) {
-    rollout_body<N, true, PK_POLICY_EXTERNAL, 1>(Sp, H, 0, 0, park, PK_WAVE, 1, actions, flags, terr);
+    rollout_body<N, false, PK_POLICY_EXTERNAL, 1>(Sp, H, 0, 0, park, PK_WAVE, 1, actions, flags, terr);
 }
 template <int N>
 __global__ void __launch_bounds__(PK_TABLE_BLOCK, 2) k_rollout_single(const State *__restrict__ Sp, Hot H, int K, int auto_reset, int park, int slack, int clear_terr) {
-    rollout_body<N, true, PK_POLICY_RANDOM, 1>(Sp, H, K, auto_reset, park, slack, clear_terr);
+    rollout_body<N, false, PK_POLICY_RANDOM, 1>(Sp, H, K, auto_reset, park, slack, clear_terr);
 }
 template <int N>
 __global__ void __launch_bounds__(PK_TABLE_BLOCK, 2) PK_ROLLOUT_ATTR k_rollout_call(const State *__restrict__ Sp, Hot H, int K, int auto_reset, int park, int slack, int clear_terr) {
@@ -308,7 +308,7 @@ __global__ void __launch_bounds__(PK_TABLE_BLOCK) k_env_reset(const State *__res
         const int runnable = __popcll(__ballot(more && tb.lstate == LS_DONE));
         if (parked == 0 && runnable == 0) break;
         if (parked >= park || runnable == 0) {
-            tb.end_block(H, t, table_id, lds, false);
+            tb.template end_block<false>(H, t, table_id, lds, false);   // (the whole side-pot loop per call: a reset's tail is a few lanes)
             retire();
         }
     }
@@ -468,7 +468,7 @@ __device__ __forceinline__ void env_step_body(const State *__restrict__ Sp, cons
         if (parked == 0 && runnable == 0) break;                                   // draining: the rest stays in flight
         passes += made;
         if (parked >= park || runnable == 0) {
-            tb.end_block(H, t, table_id, lds, false);
+            tb.template end_block<ASYNC>(H, t, table_id, lds, false);   // synchronous: the side-pot loop runs to its end inside the call (the step's tail is a few lanes)
             retire();
         }
     }
