@@ -949,7 +949,7 @@ int pk_env_step(pk_handle *h, const int32_t *actions, int opp_policy, double *re
 int pk_prof_read(pk_handle *h, unsigned long long *out) {
     if (!h || !out) return PK_E_INVALID_ARG;
     ON_DEVICE(h);
-    FLUSH(h);
+    if (!h->env_pending) FLUSH(h);   // (the counters themselves can be read while env steps are in flight)
     HIPCHK(h, hipMemcpyAsync(out, h->S.prof, PF_SLOTS * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemsetAsync(h->S.prof, 0, PF_SLOTS * 8, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));

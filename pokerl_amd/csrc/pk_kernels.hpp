@@ -349,6 +349,7 @@ __device__ __forceinline__ void env_step_body(const State *__restrict__ Sp, cons
     const bool live = (int)threadIdx.x < H.tpb && t < S.T && t < tend;
     const uint32_t table_id = H.table_id_base + (uint32_t)t;
     Table<N> tb;
+    PK_PROF(tb.prof.start();)
     if (live) tb.load(S, t); else tb.blank();
     uint64_t ctx = 0;                                          // != 0: a PokerGameEnv.step of this table is in flight
     if (ASYNC && live) ctx = S.env_ctx[t];
@@ -428,12 +429,15 @@ __device__ __forceinline__ void env_step_body(const State *__restrict__ Sp, cons
         // ASYNC, pass budget used up: no lane begins another Game.step; the hands that are ending are still brought to
         // their end (a lane parked at end_hand would otherwise wait for 'park' neighbours launch after launch)
         const bool draining = ASYNC && max_passes > 0 && passes >= max_passes;
+        PK_PROF(tb.prof.lap(PF_CURSOR);)
         if (!draining && phase == PH_RESET && tb.lstate == LS_DONE) {              // game_env.py:23 / :27
             tb.reset_state(H, 0); tb.deal(H, table_id);
             phase = tb.active != 0 ? PH_RESET_PLAY : PH_END;                       // :24
         }
+        PK_PROF(tb.prof.lap(14);)                   // (diagnostic build: slot 14 = the episode-reset branch, 15 = the action draws,
         if (draws) __builtin_amdgcn_s_waitcnt(0);   // as in k_rollout: no stray full wait behind the passes' LDS reads
         if (draws) ring.ensure(lds, H, table_id, tb.step_serial, live && phase != PH_END && !yielded, PK_ENV_PASSES);
+        PK_PROF(tb.prof.lap(15);)                   //  PF_CURSOR = load + census between the rounds)
         int made = 0;
 #pragma unroll
         for (int pass = 0; pass < PK_ENV_PASSES; ++pass) {
@@ -462,16 +466,22 @@ __device__ __forceinline__ void env_step_body(const State *__restrict__ Sp, cons
             // the caller -- the remaining passes would run empty; go and serve the parked lanes at once.
             if (pass + 1 < PK_ENV_PASSES &&
                 !__any(phase != PH_END && phase != PH_RESET && tb.lstate == LS_DONE && !yielded)) break;
+            // ... and so would they once the pass budget of a bounded launch is used up (no lane may begin a step): while the
+            // ending hands are brought to their end, ONE seat walk per end_block is all that is left to do (the profile showed
+            // 21.8 passes per 8-pass launch: four empty ones in front of each of the 3.5 end_blocks of the drain)
+            if (ASYNC && max_passes > 0 && passes + pass + 1 >= max_passes) break;
         }
+        PK_PROF(tb.prof.lap(PF_ACTION); tb.prof.count(PF_N_CURSOR, (unsigned)made);)
         const int parked = __popcll(__ballot(tb.parked()));
         const int runnable = draining ? 0 : __popcll(__ballot(phase != PH_END && tb.lstate == LS_DONE && !yielded));
         if (parked == 0 && runnable == 0) break;                                   // draining: the rest stays in flight
         passes += made;
         if (parked >= park || runnable == 0) {
-            tb.template end_block<ASYNC>(H, t, table_id, lds, false);   // synchronous: the side-pot loop runs to its end inside the call (the step's tail is a few lanes)
+            tb.template end_block<false>(H, t, table_id, lds, false);   // synchronous: the side-pot loop runs to its end inside the call (the step's tail is a few lanes)
             retire();
         }
     }
+    PK_PROF(tb.prof.lap(PF_OTHER); tb.prof.flush(S.prof);)
     if (!live) return;
     if (MULTI && skip) {                                       // nothing ran, nothing is written but the two status bytes
         if (ready) ready[t] = 3;
