@@ -320,6 +320,44 @@ __global__ void __launch_bounds__(PK_TABLE_BLOCK) k_env_reset(const State *__res
     }
 }
 
+// What PokerGameEnv does between two Game.steps (game_env.py:24-27, :35-52) as a TABLE: index = phase | over << 3 |
+// hand_over << 4 | err << 5 | (seat 0 is to act) << 6 | (seat 0 is BROKEN) << 7, entry = next phase (bits 0..2, before the
+// "step has returned" rule), done / hand updates (bit 3 set + bit 4 value, bit 5 set + bit 6 value), reward = payoffs[0]
+// (bit 7), PokerGameEnv.step has returned (bit 8).  The control flow itself, as the reference writes it, is env_transition()
+// below -- evaluated at compile time for all 256 inputs; the kernels stage the table in LDS and look a returned lane's
+// entry up (as ~45 lane-mask operations and a dozen selects per betting pass this logic was 13 % of the asynchronous
+// kernel: profiles/r03_blockprof_env_async.txt).
+enum : int { PH_SEAT0 = 0, PH_HAND = 1, PH_TURN = 2, PH_RESET = 3, PH_RESET_PLAY = 4, PH_END = 5 };
+constexpr uint16_t env_transition(int idx) {
+    const int phase = idx & 7;
+    const bool over = (idx >> 3) & 1, hand_now = (idx >> 4) & 1, err = (idx >> 5) & 1, seat0 = (idx >> 6) & 1, broken0 = (idx >> 7) & 1;
+    const bool rp = phase == PH_RESET_PLAY;                                    // a step of PokerGameEnv.reset()'s loop (:24-27)
+    const bool rn = !rp;                                                       // a step of PokerGameEnv.step (:35-52)
+    int ph = phase;
+    if (rp) ph = err ? (int)PH_END : (over ? (int)PH_RESET : (seat0 ? (int)PH_END : (int)PH_RESET_PLAY));   // :27 / :24
+    const bool s0 = rn && !err && phase == PH_SEAT0, sh = rn && !err && phase == PH_HAND, st = rn && !err && phase == PH_TURN;
+    bool done_set = s0 || sh || st, done_val = over;                           // :35 / :44 / :52
+    bool hand_set = s0 || sh, hand_val = hand_now;
+    const bool bust = s0 && (over || broken0);                                 // :37-39
+    if (bust) { done_set = true; done_val = true; hand_set = true; hand_val = true; }
+    const bool hand = hand_val;                                                // (only read where hand_set holds)
+    const bool to_hand = s0 && !bust && !hand && !seat0;                       // :41
+    const bool leave = (s0 && !bust && !to_hand) || (sh && (hand || seat0));   // :41's loop is over (or never entered)
+    const bool take_rew = bust || (leave && hand);                             // :39 / :47
+    const bool to_turn = leave && !over && !seat0;                             // :49 (done == over wherever `leave` can hold)
+    const bool fin = (rn && err) || bust || (leave && !to_turn) || (st && (over || seat0));
+    if (to_hand) ph = PH_HAND;
+    if (to_turn) ph = PH_TURN;
+    const bool live_phase = phase == PH_SEAT0 || phase == PH_HAND || phase == PH_TURN || phase == PH_RESET_PLAY;
+    if (!live_phase) return (uint16_t)phase;                                   // (no Game.step can return in PH_RESET / PH_END)
+    return (uint16_t)(ph | (done_set << 3) | (done_val << 4) | (hand_set << 5) | (hand_val << 6) | (take_rew << 7) | (fin << 8));
+}
+struct EnvTransitions {
+    uint16_t e[256];
+    constexpr EnvTransitions() : e{} { for (int i = 0; i < 256; ++i) e[i] = env_transition(i); }
+};
+__device__ __constant__ const EnvTransitions g_env_transitions{};
+
 // PokerGameEnv.step: seat 0's own step (:35), the opponents until the hand ends or seat 0 is to act (:41-44), the
 // opponents until seat 0 is to act or the game is over (:49-52) -- three phases of one lane-level machine.
 // Fused extras for a learner's loop (all optional, each removes a launch per env step): seat 0 can be played by an
@@ -358,7 +396,10 @@ __device__ __forceinline__ void env_step_body(const State *__restrict__ Sp, cons
     const bool carried = ctx != 0;
     bool yielded = MULTI && carried && ((ctx >> 6) & 1);       // waiting for the caller's action for seat tb.active
     ActionRing ring;
-    stage_nth(lds);
+    __shared__ uint16_t trans[256];                            // env_transition() of every input (see above)
+    for (int i = threadIdx.x & (PK_WAVE - 1); i < 128; i += PK_WAVE)
+        reinterpret_cast<uint32_t *>(trans)[i] = reinterpret_cast<const uint32_t *>(g_env_transitions.e)[i];
+    stage_nth(lds);                                            // (its barrier covers the table above)
     double high_bet;
     const uint32_t vm0 = tb.valid_mask(high_bet);
     // the action this call supplies: seat 0's for a new PokerGameEnv.step (checked here, game.py:648-651), or the
@@ -367,10 +408,9 @@ __device__ __forceinline__ void env_step_body(const State *__restrict__ Sp, cons
     const bool action_ok = action >= 0 && action < PK_NUM_MOVES && ((vm0 >> action) & 1);
     const bool skip = MULTI && live && !carried && !want_reset && action == PK_ACTION_SKIP;   // an idle table the caller leaves alone
     const bool ok = carried || want_reset || (live && !skip && (seat0_policy >= 0 || action_ok));
-    enum { PH_SEAT0 = 0, PH_HAND = 1, PH_TURN = 2, PH_RESET = 3, PH_RESET_PLAY = 4, PH_END = 5 };
     int phase = ok ? (want_reset ? PH_RESET : PH_SEAT0) : PH_END;
     double rew = 0.0;                                                              // :34
-    bool done = false, hand = false;
+    uint32_t done = 0, hand = 0;
     uint32_t terr_step = 0;
     int budget = PK_ENV_STEP_CAP, budget_reset = PK_ENV_STEP_CAP;
     if (ASYNC && carried) {
@@ -395,30 +435,19 @@ __device__ __forceinline__ void env_step_body(const State *__restrict__ Sp, cons
         tb.step_serial += (r && !(tb.terr & PK_TERR_NO_WINNER)) ? 1u : 0u;          // finish_step()
         tb.stepped = r ? 0u : tb.stepped;
         const bool rp = r && phase == PH_RESET_PLAY;                               // a step of PokerGameEnv.reset()'s loop (:24-27)
-        const bool rn = r && phase != PH_RESET_PLAY;                               // a step of PokerGameEnv.step (:35-52)
-        const bool opp = rn && phase != PH_SEAT0;                                  // ... played by an opponent
+        const bool opp = r && (phase == PH_HAND || phase == PH_TURN);              // a step of PokerGameEnv.step played by an opponent
         budget_reset -= rp ? 1 : 0; budget -= opp ? 1 : 0;
         tb.terr |= ((rp && budget_reset < 0) || (opp && budget < 0)) ? (uint32_t)PK_TERR_ENV_CAP : 0u;
-        const bool err = tb.terr != 0;
-        const bool over = (tb.flags & PK_FLAG_GAME_OVER) != 0, hand_now = (tb.flags & PK_FLAG_HAND_OVER) != 0;
-        const bool seat0 = tb.active == 0;
-        int ph = phase;
-        ph = rp ? (err ? (int)PH_END : (over ? (int)PH_RESET : (seat0 ? (int)PH_END : (int)PH_RESET_PLAY))) : ph;   // :27 / :24
-        const bool s0 = rn && !err && phase == PH_SEAT0, sh = rn && !err && phase == PH_HAND, st = rn && !err && phase == PH_TURN;
-        done = (s0 || sh || st) ? over : done;                                     // :35 / :44 / :52
-        hand = (s0 || sh) ? hand_now : hand;
-        const bool bust = s0 && (done || (tb.st_broken & 1u));                     // :37-39
-        done = bust ? true : done; hand = bust ? true : hand;
-        const bool to_hand = s0 && !bust && !hand && !seat0;                       // :41
-        const bool leave = (s0 && !bust && !to_hand) || (sh && (hand || seat0));   // :41's loop is over (or never entered)
-        rew = (bust || (leave && hand)) ? tb.payoffs[0] : rew;                     // :39 / :47
-        const bool to_turn = leave && !done && !seat0;                             // :49
-        const bool fin = (rn && err) || bust || (leave && !to_turn) || (st && (done || seat0));
-        ph = to_hand ? (int)PH_HAND : ph; ph = to_turn ? (int)PH_TURN : ph;
+        const uint32_t idx = (uint32_t)phase | ((tb.flags & 3u) << 3) | (tb.terr != 0 ? 32u : 0u) | (tb.active == 0 ? 64u : 0u) | ((tb.st_broken & 1u) << 7);
+        static_assert(PK_FLAG_GAME_OVER == 1 && PK_FLAG_HAND_OVER == 2, "env_transition()'s index takes the two flags as they are");
+        const uint32_t w = r ? (uint32_t)trans[idx] : (uint32_t)phase;             // (a lane that did not return: no bit set, its own phase)
+        done = (w & 8u) ? (w >> 4) & 1u : done;                                    // :35 / :44 / :52, :38
+        hand = (w & 32u) ? (w >> 6) & 1u : hand;
+        rew = (w & 128u) ? tb.payoffs[0] : rew;                                    // :39 / :47
+        const bool fin = (w & 256u) != 0;
         // PokerGameEnv.step has returned: its outputs are final; maybe reset the episode
         terr_step = fin ? tb.terr : terr_step;
-        ph = fin ? ((auto_reset && (done || (tb.terr & caps))) ? (int)PH_RESET : (int)PH_END) : ph;
-        phase = ph;
+        phase = fin ? ((auto_reset && (done || (tb.terr & caps))) ? (int)PH_RESET : (int)PH_END) : (int)(w & 7u);
     };
 #ifndef PK_ENV_PASSES
 #define PK_ENV_PASSES 4   // betting passes between two looks at the parked lanes, as in k_rollout
