@@ -507,7 +507,7 @@ struct Lds {  // per workgroup (= one wavefront); ~10 KB at N = 10
     uint32_t show[N][64];      // rankings of each lane's last showdown; written back by Table::store_show at kernel end
                                // (keeps global stores, and the vmcnt waits they drag along, out of the step loop)
     Fresh fresh;               // workgroup copy of *Hot::fresh (Table::stage_fresh), read with broadcast ds_reads
-    uint8_t nth[128][8];       // nth[mask][k] = k-th (0-based) set bit of a 7-bit valid-action mask (stage_nth)
+    alignas(16) uint8_t nth[128][8];   // nth[mask][k] = k-th (0-based) set bit of a 7-bit valid-action mask (stage_nth)
 };
 
 struct ActionRng {  // one Philox block serves EIGHT consecutive steps of a table: 16-bit draws (RNG spec)
@@ -597,12 +597,25 @@ struct ActionRing {
     }
 };
 // The same through the workgroup's LDS table (k_rollout): one byte read instead of a six-step select chain.
-template <typename LDS>
-__device__ __forceinline__ void stage_nth(LDS &lds) {  // call once from wave-uniform control flow
-    for (uint32_t m = threadIdx.x & (PK_WAVE - 1); m < 128; m += PK_WAVE) {
-        uint32_t rest = m;
-        for (int k = 0; k < 8; ++k) { lds.nth[m][k] = rest ? (uint8_t)(__ffs(rest) - 1) : 0; rest &= rest - 1; }
+struct NthTable {   // nth[mask][k] = k-th (0-based) set bit of a 7-bit valid-action mask, for every mask: a compile-time constant
+    uint8_t e[128][8];
+    constexpr NthTable() : e{} {
+        for (int m = 0; m < 128; ++m) {
+            int rest = m;
+            for (int k = 0; k < 8; ++k) {
+                int low = 0;
+                while (rest && !((rest >> low) & 1)) ++low;
+                e[m][k] = rest ? (uint8_t)low : (uint8_t)0;
+                rest &= rest - 1;
+            }
+        }
     }
+};
+__device__ __constant__ const NthTable g_nth{};
+template <typename LDS>
+__device__ __forceinline__ void stage_nth(LDS &lds) {  // call once from wave-uniform control flow: 16 bytes per lane
+    for (int i = threadIdx.x & (PK_WAVE - 1); i < 64; i += PK_WAVE)
+        reinterpret_cast<uint4 *>(&lds.nth[0][0])[i] = reinterpret_cast<const uint4 *>(&g_nth.e[0][0])[i];
     __syncthreads();
 }
 template <typename LDS>

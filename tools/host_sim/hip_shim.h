@@ -6,6 +6,8 @@
 #include <cstring>
 #define PK_WAVE 1
 #define __device__
+#define __constant__
+struct uint4 { unsigned x, y, z, w; };
 #define __global__
 #define __forceinline__ inline __attribute__((always_inline))
 #define __shared__ static
