@@ -450,8 +450,12 @@ __device__ __forceinline__ void env_step_body(const State *__restrict__ Sp, cons
         phase = fin ? ((auto_reset && (done || (tb.terr & caps))) ? (int)PH_RESET : (int)PH_END) : (int)(w & 7u);
     };
 #ifndef PK_ENV_PASSES
-#define PK_ENV_PASSES 4   // betting passes between two looks at the parked lanes, as in k_rollout
+#define PK_ENV_PASSES 4   // betting passes between two looks at the parked lanes, as in k_rollout (asynchronous: 2 -> 2.97 G, 4 -> 3.20 G, 8 -> 2.71 G)
 #endif
+#ifndef PK_ENV_PASSES_SYNC
+#define PK_ENV_PASSES_SYNC 8   // ... of the synchronous kernel, whose tail is a few lanes per wave (0.226 / 0.228 / 0.233 G at 2 / 4 / 8; the
+#endif                         // action ring holds draws for eight passes at most)
+    constexpr int EP = ASYNC ? PK_ENV_PASSES : PK_ENV_PASSES_SYNC;
     bool draws = seat0_policy == PK_POLICY_RANDOM;                                 // wave-uniform: some agent draws from the ring
     PK_FOR(p, N) if (p > 0) draws = draws || seat_policy(seatpol, p) == PK_POLICY_RANDOM; PK_END
     for (;;) {
@@ -465,11 +469,11 @@ __device__ __forceinline__ void env_step_body(const State *__restrict__ Sp, cons
         }
         PK_PROF(tb.prof.lap(14);)                   // (diagnostic build: slot 14 = the episode-reset branch, 15 = the action draws,
         if (draws) __builtin_amdgcn_s_waitcnt(0);   // as in k_rollout: no stray full wait behind the passes' LDS reads
-        if (draws) ring.ensure(lds, H, table_id, tb.step_serial, live && phase != PH_END && !yielded, PK_ENV_PASSES);
+        if (draws) ring.ensure(lds, H, table_id, tb.step_serial, live && phase != PH_END && !yielded, EP);
         PK_PROF(tb.prof.lap(15);)                   //  PF_CURSOR = load + census between the rounds)
         int made = 0;
 #pragma unroll
-        for (int pass = 0; pass < PK_ENV_PASSES; ++pass) {
+        for (int pass = 0; pass < EP; ++pass) {
             const bool open = !(ASYNC && max_passes > 0 && passes + pass >= max_passes);
             const uint32_t word = draws ? ActionRing::peek(lds, tb.step_serial) : 0u;
             if (open && phase != PH_END && phase != PH_RESET && tb.lstate == LS_DONE && !yielded) {   // begin this lane's next Game.step()
@@ -493,7 +497,7 @@ __device__ __forceinline__ void env_step_body(const State *__restrict__ Sp, cons
             // The tail of an env step is a handful of lanes (a busted seat 0 waits for the end of its game): once no lane can
             // begin another Game.step in this round of passes -- all parked at end_hand, returned, or waiting for a reset /
             // the caller -- the remaining passes would run empty; go and serve the parked lanes at once.
-            if (pass + 1 < PK_ENV_PASSES &&
+            if (pass + 1 < EP &&
                 !__any(phase != PH_END && phase != PH_RESET && tb.lstate == LS_DONE && !yielded)) break;
             // ... and so would they once the pass budget of a bounded launch is used up (no lane may begin a step): while the
             // ending hands are brought to their end, ONE seat walk per end_block is all that is left to do (the profile showed
