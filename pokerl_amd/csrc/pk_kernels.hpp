@@ -459,17 +459,23 @@ __device__ __forceinline__ void env_step_body(const State *__restrict__ Sp, cons
     bool draws = seat0_policy == PK_POLICY_RANDOM;                                 // wave-uniform: some agent draws from the ring
     PK_FOR(p, N) if (p > 0) draws = draws || seat_policy(seatpol, p) == PK_POLICY_RANDOM; PK_END
     for (;;) {
-        // ASYNC, pass budget used up: no lane begins another Game.step; the hands that are ending are still brought to
-        // their end (a lane parked at end_hand would otherwise wait for 'park' neighbours launch after launch)
-        const bool draining = ASYNC && max_passes > 0 && passes >= max_passes;
+        // ASYNC, pass budget used up: the launch ends.  Whatever has not returned stays IN FLIGHT as it is -- also a hand parked
+        // at end_hand, which the next launch's first end_block serves together with that launch's own arrivals.  (Rounds 2 and
+        // 3 brought those hands to their end first, "or a parked lane would wait for `park` neighbours launch after launch": it
+        // cannot -- end_block also runs whenever no lane of the wave can begin a step -- and the drain's end_blocks, each for a
+        // handful of lanes, cost a bounded launch a third of its time: 1.00 -> 1.46 G env.step/s with one batch, 3.19 -> 3.59 G
+        // with four.)  One more round, in which no lane may begin a step: a seat walk, so that no lane is left between a deal and
+        // its first seat (LS_SCAN).  (As code of its own in front of the loop's exit it cost the kernel its third wave: 87
+        // spilled VGPRs.)
+        const bool last = ASYNC && max_passes > 0 && passes >= max_passes;
         PK_PROF(tb.prof.lap(PF_CURSOR);)
-        if (!draining && phase == PH_RESET && tb.lstate == LS_DONE) {              // game_env.py:23 / :27
+        if (!last && phase == PH_RESET && tb.lstate == LS_DONE) {                  // game_env.py:23 / :27
             tb.reset_state(H, 0); tb.deal(H, table_id);
             phase = tb.active != 0 ? PH_RESET_PLAY : PH_END;                       // :24
         }
         PK_PROF(tb.prof.lap(14);)                   // (diagnostic build: slot 14 = the episode-reset branch, 15 = the action draws,
         if (draws) __builtin_amdgcn_s_waitcnt(0);   // as in k_rollout: no stray full wait behind the passes' LDS reads
-        if (draws) ring.ensure(lds, H, table_id, tb.step_serial, live && phase != PH_END && !yielded, EP);
+        if (draws && !last) ring.ensure(lds, H, table_id, tb.step_serial, live && phase != PH_END && !yielded, EP);
         PK_PROF(tb.prof.lap(15);)                   //  PF_CURSOR = load + census between the rounds)
         int made = 0;
 #pragma unroll
@@ -499,15 +505,13 @@ __device__ __forceinline__ void env_step_body(const State *__restrict__ Sp, cons
             // the caller -- the remaining passes would run empty; go and serve the parked lanes at once.
             if (pass + 1 < EP &&
                 !__any(phase != PH_END && phase != PH_RESET && tb.lstate == LS_DONE && !yielded)) break;
-            // ... and so would they once the pass budget of a bounded launch is used up (no lane may begin a step): while the
-            // ending hands are brought to their end, ONE seat walk per end_block is all that is left to do (the profile showed
-            // 21.8 passes per 8-pass launch: four empty ones in front of each of the 3.5 end_blocks of the drain)
+            // ... and so would they once the pass budget of a bounded launch is used up
             if (ASYNC && max_passes > 0 && passes + pass + 1 >= max_passes) break;
         }
         PK_PROF(tb.prof.lap(PF_ACTION); tb.prof.count(PF_N_CURSOR, (unsigned)made);)
         const int parked = __popcll(__ballot(tb.parked()));
-        const int runnable = draining ? 0 : __popcll(__ballot(phase != PH_END && tb.lstate == LS_DONE && !yielded));
-        if (parked == 0 && runnable == 0) break;                                   // draining: the rest stays in flight
+        const int runnable = __popcll(__ballot(phase != PH_END && tb.lstate == LS_DONE && !yielded));
+        if (last || (parked == 0 && runnable == 0)) break;
         passes += made;
         if (parked >= park || runnable == 0) {
             tb.template end_block<false>(H, t, table_id, lds, false);   // synchronous: the side-pot loop runs to its end inside the call (the step's tail is a few lanes)
