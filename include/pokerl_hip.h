@@ -270,8 +270,8 @@ int pk_env_step_async_d(pk_handle *h, const int32_t *actions_d, int seat0_policy
                         double *obs_d, uint8_t *ready_d);
 
 /* Sub-batches of pk_env_step_async_d inside ONE handle.  A bounded launch ends with a tail (its last waves run alone) and
- * the launches of one handle are serialised on its stream, so one handle of 524 288 tables delivers 2.64 G env.step/s where
- * the same handle in three sub-batches delivers 3.28 G (profiles/r03_env_inner_sweep.txt).  pk_set_env_batches(h, B) splits
+ * the launches of one handle are serialised on its stream, so one handle of 524 288 tables delivers 2.99 G env.step/s where
+ * the same handle in three sub-batches delivers 3.56 G (profiles/r03_env_inner_sweep.txt).  pk_set_env_batches(h, B) splits
  * the handle's tables into B contiguous ranges (whole waves each; fewer than B for a small batch: right after the call pk_env_last_range reports range 0, [0, tables per range)),
  * each with an internal stream.  From then on a call with max_passes > 0
  *   - LAUNCHES one range (round robin), reading actions_d only inside it, and
@@ -283,7 +283,7 @@ int pk_env_step_async_d(pk_handle *h, const int32_t *actions_d, int seat0_policy
  * calls.  max_passes <= 0 drains every range and delivers [0, T).  Per table nothing changes: the sequence of steps, outputs
  * and RNG draws is that of the synchronous call.  Call it while no env step is in flight (PK_E_BUSY otherwise).
  * Use B <= 3: HIP gives a process 4 hardware queues, the caller's stream + 3 internal ones use them all, and a fourth internal
- * stream shares a queue and serialises on the cross-stream waits (524 288 tables: 3.01 / 3.28 / 2.28 G at B = 2 / 3 / 4).
+ * stream shares a queue and serialises on the cross-stream waits (524 288 tables: 3.31 / 3.56 / 2.56 G at B = 2 / 3 / 4).
  * Ranges of >= 131 072 tables are the ones that pay (smaller batches: several handles, each on its own stream). */
 int pk_set_env_batches(pk_handle *h, int batches);
 int pk_env_last_range(pk_handle *h, int *begin, int *end, int *fresh);
