@@ -245,7 +245,8 @@ int pk_env_reset_d(pk_handle *h, const uint8_t *mask_d /* NULL = all */, int opp
 /* PokerGameEnv.step with the rest of a learner's loop fused into the same launch (each option removes a launch per env
  * step): actions_d == NULL lets the in-kernel agent `seat0_policy` play seat 0; auto_reset != 0 applies
  * PokerGameEnv.reset() (pokerl/envs/game_env.py:20-29) on the spot to every table whose step returned done (or ran into
- * PK_TERR_HAND_CAP / PK_TERR_ENV_CAP) -- reward / done / hand / terr still describe the step that ended the episode;
+ * PK_TERR_HAND_CAP / PK_TERR_ENV_CAP) -- reward / done / hand / terr still describe the step that ended the episode, and
+ * terr also carries the error bits of that reset, should its loop (game_env.py:24-27) run into one;
  * obs_d != NULL receives the dense StateView row of the player to act (PK_OBS_DIM(N) doubles per table). */
 int pk_env_step_fused_d(pk_handle *h, const int32_t *actions_d, int seat0_policy, int opp_policy, int auto_reset,
                         double *reward_d, uint8_t *done_d, uint8_t *hand_d, uint8_t *terr_d, double *obs_d);

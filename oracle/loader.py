@@ -59,6 +59,7 @@ def lib():
     L.orc_get_states.argtypes = [C.c_void_p, _u8p]
     L.orc_get_cursors.argtypes = [C.c_void_p, _i32p]
     L.orc_get_serials.argtypes = [C.c_void_p, _u64p, _u64p]
+    L.orc_get_errs.argtypes = [C.c_void_p, _u8p]
     L.orc_set_serials.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.orc_get_cards.argtypes = [C.c_void_p, _u8p]
     L.orc_get_showdown.argtypes = [C.c_void_p, _u8p, _u32p]
@@ -110,6 +111,12 @@ class OracleGame:
         err = np.zeros(self.T, np.uint8)
         self.L.orc_step(self.h, a, flags, err)
         return flags, err
+
+    def errs(self):
+        """Error bits each table's last Game.step left (how an error raised inside env_reset's loop becomes visible)."""
+        e = np.zeros(self.T, np.uint8)
+        self.L.orc_get_errs(self.h, e)
+        return e
 
     def valid_actions(self):
         m = np.zeros(self.T, np.uint8)

@@ -611,6 +611,11 @@ void orc_get_cursors(const orc_game *g, int32_t *out) {
 void orc_get_serials(const orc_game *g, uint64_t *hand_serial, uint64_t *step_serial) {
     for (int i = 0; i < g->T; ++i) { if (hand_serial) hand_serial[i] = g->t[i].hand_serial; if (step_serial) step_serial[i] = g->t[i].step_serial; }
 }
+/* error bits the last Game.step of each table left (ORC_ERR_*): how a harness sees an error raised INSIDE orc_env_reset's loop
+ * (game_env.py:24-27), which returns nothing */
+void orc_get_errs(const orc_game *g, uint8_t *out) {
+    for (int i = 0; i < g->T; ++i) out[i] = (uint8_t)g->t[i].err;
+}
 void orc_set_serials(orc_game *g, const uint64_t *hand_serial, const uint64_t *step_serial) {
     for (int i = 0; i < g->T; ++i) { if (hand_serial) g->t[i].hand_serial = hand_serial[i]; if (step_serial) g->t[i].step_serial = step_serial[i]; }
 }

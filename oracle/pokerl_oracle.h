@@ -71,6 +71,7 @@ void orc_get_states(const orc_game *g, uint8_t *out);
 /* [T][6] int32: active, turn, dealer, sb, bb, hand */
 void orc_get_cursors(const orc_game *g, int32_t *out);
 void orc_get_serials(const orc_game *g, uint64_t *hand_serial, uint64_t *step_serial);
+void orc_get_errs(const orc_game *g, uint8_t *out);   /* error bits of each table's last Game.step (incl. one made by orc_env_reset) */
 /* resume a table's RNG streams at given serials (rng_spec; either pointer may be NULL) */
 void orc_set_serials(orc_game *g, const uint64_t *hand_serial, const uint64_t *step_serial);
 void orc_get_cards(const orc_game *g, uint8_t *out /* [T][5+2N] Card.value */);

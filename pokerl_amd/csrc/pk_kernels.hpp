@@ -452,6 +452,9 @@ __device__ __forceinline__ void env_step_body(const State *__restrict__ Sp, cons
 #ifndef PK_ENV_PASSES
 #define PK_ENV_PASSES 4   // betting passes between two looks at the parked lanes, as in k_rollout (asynchronous: 2 -> 2.97 G, 4 -> 3.20 G, 8 -> 2.71 G)
 #endif
+#ifndef PK_ENV_ROLLING
+#define PK_ENV_ROLLING 16   // hands rolled inside one Game.step from which a bounded launch carries that step to its end
+#endif
 #ifndef PK_ENV_PASSES_SYNC
 #define PK_ENV_PASSES_SYNC 8   // ... of the synchronous kernel, whose tail is a few lanes per wave (0.226 / 0.228 / 0.233 G at 2 / 4 / 8; the
 #endif                         // action ring holds draws for eight passes at most)
@@ -467,15 +470,20 @@ __device__ __forceinline__ void env_step_body(const State *__restrict__ Sp, cons
         // with four.)  One more round, in which no lane may begin a step: a seat walk, so that no lane is left between a deal and
         // its first seat (LS_SCAN).  (As code of its own in front of the loop's exit it cost the kernel its third wave: 87
         // spilled VGPRs.)
-        const bool last = ASYNC && max_passes > 0 && passes >= max_passes;
+        // Exception: a Game.step that is rolling hand after hand (blinds far above the stacks: every new hand ends before
+        // anybody can act -- 1 300 hands inside one step seen) is carried on to its end as before; at two or three end_blocks
+        // per launch such a step would take hundreds of launches.  The threshold: short stacks posting all-in blinds roll a few
+        // hands per step in ordinary late games too (3: 1.44 -> 1.20 G env.step/s with one batch; 16: no cost).
+        const bool closing = ASYNC && max_passes > 0 && passes >= max_passes;    // no lane may begin a Game.step any more
+        const bool last = closing && !__any(tb.stepped && tb.hands_this_step >= PK_ENV_ROLLING);   // (parked, or between a deal and its first seat)
         PK_PROF(tb.prof.lap(PF_CURSOR);)
-        if (!last && phase == PH_RESET && tb.lstate == LS_DONE) {                  // game_env.py:23 / :27
+        if (!closing && phase == PH_RESET && tb.lstate == LS_DONE) {               // game_env.py:23 / :27
             tb.reset_state(H, 0); tb.deal(H, table_id);
             phase = tb.active != 0 ? PH_RESET_PLAY : PH_END;                       // :24
         }
         PK_PROF(tb.prof.lap(14);)                   // (diagnostic build: slot 14 = the episode-reset branch, 15 = the action draws,
         if (draws) __builtin_amdgcn_s_waitcnt(0);   // as in k_rollout: no stray full wait behind the passes' LDS reads
-        if (draws && !last) ring.ensure(lds, H, table_id, tb.step_serial, live && phase != PH_END && !yielded, EP);
+        if (draws && !closing) ring.ensure(lds, H, table_id, tb.step_serial, live && phase != PH_END && !yielded, EP);
         PK_PROF(tb.prof.lap(15);)                   //  PF_CURSOR = load + census between the rounds)
         int made = 0;
 #pragma unroll
@@ -510,7 +518,7 @@ __device__ __forceinline__ void env_step_body(const State *__restrict__ Sp, cons
         }
         PK_PROF(tb.prof.lap(PF_ACTION); tb.prof.count(PF_N_CURSOR, (unsigned)made);)
         const int parked = __popcll(__ballot(tb.parked()));
-        const int runnable = __popcll(__ballot(phase != PH_END && tb.lstate == LS_DONE && !yielded));
+        const int runnable = closing ? 0 : __popcll(__ballot(phase != PH_END && tb.lstate == LS_DONE && !yielded));
         if (last || (parked == 0 && runnable == 0)) break;
         passes += made;
         if (parked >= park || runnable == 0) {

@@ -398,6 +398,61 @@ def test_async_env_step_delivers_the_synchronous_sequences(HB, O, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_async_env_step_with_hands_rolling_inside_a_step(O):
+    """Blinds far above the stacks: every hand ends before anybody can act, a single Game.step rolls hundreds of hands (and a
+    reset's own loop runs into PK_TERR_HAND_CAP on dead tables, which the fused call reports with the step's terr).  Bounded
+    launches end without bringing ending hands to their end -- EXCEPT such a rolling step, which would otherwise need hundreds
+    of launches: the delivered sequences equal the synchronous ones within the usual number of launches."""
+    import pokerl_amd
+    from pokerl_amd import _lib as L
+    from pokerl_amd.hipmem import DeviceBuffer
+    lib = L.lib()
+    T, N, opp, K, passes = 300, 3, 0, 12, 8
+    cfg = dict(num_tables=T, num_players=N, start_credits=10, big_blind=0.5, small_blind=40, seed=4280805962779073359, table_id_base=2833911808)
+    D = 17 + 3 * N
+    rew, done, hand, terr, obs, ready = (DeviceBuffer(T * 8), DeviceBuffer(T), DeviceBuffer(T), DeviceBuffer(T), DeviceBuffer(T * D * 8), DeviceBuffer(T))
+    out = lambda: (rew.download(np.float64, T), done.download(np.uint8, T), hand.download(np.uint8, T), terr.download(np.uint8, T))
+    env = pokerl_amd.VecPokerGameEnv(opp, **cfg)
+    g = env.game
+    o = O.OracleGame(T, N, 10, 0.5, 40, seed=cfg["seed"], table_id_base=cfg["table_id_base"])
+    env.reset(); o.env_reset(None, opp)
+    want, reset_errors = [], 0
+    for k in range(K):
+        ro, do, ho, eo = o.env_step(o.pick_actions(0), opp)
+        m = ((do != 0) | ((eo & 12) != 0)).astype(np.uint8)
+        if m.any():
+            o.env_reset(m, opp)
+            reset_errors += int((o.errs() * m != 0).sum())
+            eo = eo | (o.errs() * m)                      # an error of the reset that followed is reported with the step's
+        L.check(lib.pk_env_step_fused_d(g._h, None, 0, opp, 1, rew.ptr, done.ptr, hand.ptr, terr.ptr, obs.ptr), g._h)
+        g.sync()
+        w = out()
+        assert GU.bits_equal(ro, w[0]) and np.array_equal(do, w[1]) and np.array_equal(ho, w[2]) and np.array_equal(eo, w[3]), k
+        want.append(w)
+    assert reset_errors > 0, "no reset ran into an error: the terr rule was not exercised"
+    g.close()
+    env = pokerl_amd.VecPokerGameEnv(opp, **cfg)
+    g = env.game
+    env.reset()
+    count = np.zeros(T, np.int64)
+    launches = 0
+    while count.min() < K:
+        launches += 1
+        assert launches < 60 * K, "a Game.step that rolls hand after hand is not carried to its end"
+        env.step_async_d(None, rew.ptr, done.ptr, hand.ptr, terr.ptr, obs.ptr, ready.ptr, max_passes=passes)
+        g.sync()
+        r = ready.download(np.uint8, T) != 0
+        w = out()
+        for t in np.nonzero(r & (count < K))[0]:
+            for x, y in zip(w, want[count[t]]):
+                assert GU.bits_equal(np.ascontiguousarray(x[t:t + 1]), np.ascontiguousarray(y[t:t + 1])), (t, count[t])
+        count[r] += 1
+    env.step_async_d(None, rew.ptr, done.ptr, hand.ptr, terr.ptr, obs.ptr, ready.ptr, max_passes=0)
+    g.sync()
+    g.close()
+
+
+@pytest.mark.gpu
 def test_async_env_step_host_arrays(HB, O):
     """VecPokerGameEnv.step_async (host arrays over pk_env_step_async_d): the delivered rows equal the synchronous
     env.step's for each table's k-th step; a drain delivers every table."""

@@ -51,6 +51,7 @@ for i in range(n_cfg):
         m = ((do != 0) | caps).astype(np.uint8)
         if m.any():
             o.env_reset(m, opp)
+            eo = eo | (o.errs() * m)                             # the fused call also reports an error raised by the reset that followed
         L.check(lib.pk_env_step_fused_d(g._h, None, 0, opp, 1, rew.ptr, done.ptr, hand.ptr, terr.ptr, obs.ptr), g._h)
         g.sync()
         w = out()

@@ -3,7 +3,7 @@
 the CPU oracle over seeded odd configurations (every N, odd blinds / stacks, random per-seat policies random / all-in /
 call, a random subset of the opponent seats external and played on the host by the policy's own rule, bounded launches of
 1..9 passes with auto-reset): per table the delivered (reward, done, hand, terr) sequence must equal the oracle's.
-usage: python tools/fuzz_env_multi.py [configs] [seed]"""
+usage: python tools/fuzz_env_multi.py [configs] [seed] [only this configuration index]"""
 import os
 import random
 import sys
@@ -21,6 +21,8 @@ from oracle import rng_spec as R  # noqa: E402
 
 n_cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 11)
+only = int(sys.argv[3]) if len(sys.argv) > 3 else None
+cap = int(os.environ.get("PK_FUZZ_LAUNCH_CAP", "6000"))   # (calling stations at one pass per launch: 3 300 launches per env.step seen)
 stacks = [2, 5, 10, 37.5, 100, 1000]
 blinds = [0.5, 1, 2, 3, 7.5, 40]
 delivered = yields = 0
@@ -35,6 +37,8 @@ for i in range(n_cfg):
     T, K, passes = rng.choice([65, 300, 700]), rng.choice([8, 15, 25]), rng.randrange(1, 10)
     cfg = dict(num_tables=T, num_players=N, start_credits=start, big_blind=bb, small_blind=sb, seed=seed, table_id_base=base)
     where = "cfg %d: %s pols=%s external=%s K=%d passes=%d" % (i, cfg, pols, external, K, passes)
+    if only is not None and i != only:
+        continue
     o = O.OracleGame(T, N, start, bb, sb, seed=seed, table_id_base=base)
     o.env_reset(None, pols)
     want = []
@@ -44,6 +48,7 @@ for i in range(n_cfg):
         m = ((do != 0) | ((eo & 12) != 0)).astype(np.uint8)      # done, or PK_TERR_HAND_CAP / _ENV_CAP: auto-reset
         if m.any():
             o.env_reset(m, pols)
+            eo = eo | (o.errs() * m)                                 # ... whose own error bits the fused call reports with the step's
         want.append((ro, do, ho, eo))
     agents = [(lambda st: 0) if s in external else [pokerl_amd.RandomAgent(), pokerl_amd.AllInAgent(), pokerl_amd.CallAgent()][pols[s - 1]]
               for s in range(1, N)]
@@ -58,7 +63,7 @@ for i in range(n_cfg):
     launches, first = 0, True
     while count.min() < K:
         launches += 1
-        assert launches < 2000 * K, where
+        assert launches < cap * K, where
         act.upload(a)
         env.step_multi_d(act.ptr, rst.ptr if first else None, rew.ptr, done.ptr, hand.ptr, terr.ptr, obs.ptr, who.ptr, ready.ptr,
                          max_passes=passes, auto_reset=True)
@@ -89,6 +94,8 @@ for i in range(n_cfg):
             a[t] = R.pick_action(seed, base + int(t), int(serial[t]), int(bits[t]), pol)
     env.end_multi()
     env.close()
+    if only is not None:
+        print("%s: %d launches" % (where, launches))
     if i % 10 == 9:
         print("%d configurations bit-exact so far" % (i + 1), flush=True)
 print("fuzz: %d configurations, %d env.steps delivered, %d yields to caller-played seats, all equal to the oracle's sequences"
