@@ -20,7 +20,9 @@
  *     (pk_wait_event before the call, pk_record_event after it).  pk_sync() waits for everything requested so far.
  *
  * All money arithmetic is IEEE binary64 in the reference's operation order (no FMA contraction), so
- * valid_actions / payoffs / credits / flags / hand ranks are bit-identical to the CPU reference.
+ * valid_actions / payoffs / credits / flags / hand ranks are bit-identical to the CPU reference.  Money must be FINITE: the
+ * library is built with -fno-honor-nans (np.max / np.minimum as v_max_f64 / v_min_f64), and pk_create refuses inf / NaN stacks
+ * and blinds (PK_E_INVALID_ARG) -- an infinite stack would turn into NaN at the first all-in (inf - inf).
  */
 #ifndef POKERL_HIP_H
 #define POKERL_HIP_H
@@ -31,7 +33,7 @@
 extern "C" {
 #endif
 
-#define PK_ABI_VERSION 3
+#define PK_ABI_VERSION 4
 #define PK_MIN_PLAYERS 2
 #define PK_MAX_PLAYERS 15 /* the reference takes any num_players (game.py:246); up to 15 every numpy routine it calls behaves as
                              for a short array (np.sum: one 8-way block; np.argsort: insertion sort, stable): see DESIGN.md section 9 */
@@ -235,6 +237,25 @@ int pk_env_step(pk_handle *h, const int32_t *actions, int opp_policy, double *re
  * reference. */
 int pk_get_obs(pk_handle *h, int player, double *out /* [T][PK_OBS_DIM(N)] */);
 
+/* The same row, compact, for callers that move observations over PCIe or keep millions of them: PK_OBS_PACKED_BYTES(N) bytes
+ * per table, 8-byte aligned --
+ *   byte 0 player (seat), 1 turn, 2 valid_actions as bits (bit a = PokerMoves a), 3-4 player_cards, 5-9 community_cards
+ *   (Card.value bytes; 0xFF where the f64 row has -1), 10-15 zero;
+ *   then (3N+1) f64: minimum_raise_value, credits[N], bets[N], pending_bets[N] -- the money stays binary64, bit for bit.
+ * 168 bytes against 280 at six seats.  pokerl_amd.state_view.PACKED_DTYPE(N) is the numpy structured dtype of a row. */
+#define PK_OBS_PACKED_BYTES(n) (16 + 8 * (3 * (n) + 1))
+int pk_get_obs_packed(pk_handle *h, int player, uint8_t *out /* [T][PK_OBS_PACKED_BYTES(N)] */);
+
+/* Pinned host memory for the host-pointer entry points: a getter / pk_step / pk_env_step* whose buffers were allocated here
+ * copies at PCIe line rate and (pk_env_step_begin) without blocking; any other host memory works too, through the HIP
+ * runtime's staged copies (about half the rate).  Wraps hipHostMalloc / hipHostFree. */
+int pk_host_alloc(void **out, size_t bytes);
+int pk_host_free(void *p);
+
+/* Game.step's precondition for a whole batch, nothing mutated (pokerl/game.py:648-651: `if action not in valid_actions:
+ * raise ValueError`): *first_bad = the lowest table index whose action is not valid for its active player, or -1. */
+int pk_check_actions(pk_handle *h, const int32_t *actions, int32_t *first_bad);
+
 /* Device-resident variants for a learner that lives on the same GPU (no host round trip; asynchronous on the handle's
  * stream -- see "Stream control" below for ordering against your own stream): out_d / actions_d / ... are DEVICE pointers. */
 int pk_get_obs_d(pk_handle *h, int player, double *out_d /* [T][PK_OBS_DIM(N)] */);
@@ -250,6 +271,23 @@ int pk_env_reset_d(pk_handle *h, const uint8_t *mask_d /* NULL = all */, int opp
  * obs_d != NULL receives the dense StateView row of the player to act (PK_OBS_DIM(N) doubles per table). */
 int pk_env_step_fused_d(pk_handle *h, const int32_t *actions_d, int seat0_policy, int opp_policy, int auto_reset,
                         double *reward_d, uint8_t *done_d, uint8_t *hand_d, uint8_t *terr_d, double *obs_d);
+
+/* The compact row (PK_OBS_PACKED_BYTES) from the PokerGameEnv kernels: once a device buffer is set here, every
+ * pk_env_step_fused_d / _async_d / _multi_d call writes the packed row of each table it delivers into it (beside the f64 row
+ * if obs_d is given too), from registers.  NULL switches it off.  8-byte aligned, [T][PK_OBS_PACKED_BYTES(N)]. */
+int pk_set_env_obs_packed(pk_handle *h, uint8_t *obs_packed_d);
+int pk_get_obs_packed_d(pk_handle *h, int player, uint8_t *out_d);
+
+/* pk_env_step through host buffers in two halves, for callers that want the copies off their critical path:
+ * pk_env_step_begin uploads actions[T], launches PokerGameEnv.step (auto_reset != 0: finished episodes are reset on the spot,
+ * as in pk_env_step_fused_d) and queues the device-to-host copies of reward / done / hand / terr and, where not NULL, of the
+ * f64 observation rows (obs) and / or the packed ones (obs_packed); pk_env_step_end waits for them.  With buffers from
+ * pk_host_alloc nothing in `begin` blocks and the copies run at PCIe line rate, so the caller's own work -- or the step of
+ * ANOTHER handle -- overlaps with them.  Per-table errors are in terr[] after `end` (which does not scan them).  The handle
+ * must not be used between the two calls. */
+int pk_env_step_begin(pk_handle *h, const int32_t *actions, int opp_policy, int auto_reset, double *reward, uint8_t *done,
+                      uint8_t *hand, uint8_t *terr, double *obs, uint8_t *obs_packed);
+int pk_env_step_end(pk_handle *h);
 
 /* The same as a BOUNDED launch for learners that act on whichever tables are ready (asynchronous vector environment).
  * One PokerGameEnv.step of a whole batch lasts as long as its slowest table: a seat 0 that goes broke during an

@@ -7,9 +7,10 @@ from .agents import AllInAgent, CallAgent, PokerAgent, RandomAgent
 from .judger import compare_hands, compare_rankings, eval_hand, eval_hands
 from .sharding import gather_f64, shard_tables
 from .single import Game, PokerGameEnv
-from .state_view import Card, StateView
+from .state_view import Card, StateView, packed_dtype, unpack_obs
+from .hipmem import pinned_empty
 from ._lib import PokerlHipError, device_count
 
 __all__ = ['Game', 'PokerGameEnv', 'VecGame', 'VecPokerGameEnv', 'VecPokerGameEnvPool', 'eval_hand', 'eval_hands', 'compare_rankings', 'compare_hands',
            'shard_tables', 'gather_f64', 'Card', 'StateView', 'HandRanking', 'PokerMoves', 'PlayerState', 'CardRank', 'CardSuit', 'Policy',
-           'PokerlHipError', 'device_count', 'PokerAgent', 'RandomAgent', 'AllInAgent', 'CallAgent']
+           'PokerlHipError', 'device_count', 'packed_dtype', 'unpack_obs', 'pinned_empty', 'PokerAgent', 'RandomAgent', 'AllInAgent', 'CallAgent']

@@ -16,7 +16,7 @@ I_ACTIVE_PLAYER, I_TURN, I_DEALER_IDX, I_SMALL_BLIND_IDX, I_BIG_BLIND_IDX, I_HAN
 TF_POT, TF_HIGH_BET, TF_MIN_RAISE = 0, 1, 2
 ACTION_SKIP = -2   # pk_env_step_multi_d: leave an idle table alone (PK_ACTION_SKIP)
 POLICY_EXTERNAL = 15
-ABI_VERSION = 3
+ABI_VERSION = 4
 NUM_COUNTERS = 4
 MIN_PLAYERS, MAX_PLAYERS = 2, 15
 
@@ -29,7 +29,9 @@ SYMBOLS = ["pk_abi_version", "pk_device_count", "pk_last_error", "pk_create", "p
            "pk_get_valid_actions_d", "pk_env_step_d", "pk_env_reset_d", "pk_eval7_d", "pk_make_hands_d", "pk_time_eval7_d",
            "pk_get_serials", "pk_set_serials", "pk_get_table_f64", "pk_get_game_over", "pk_eval_hands_d",
            "pk_pick_actions_d", "pk_flush", "pk_get_owed", "pk_env_step_fused_d", "pk_env_step_async_d", "pk_set_tuning", "pk_get_stream", "pk_set_stream", "pk_wait_event",
-           "pk_record_event", "pk_use_own_stream", "pk_set_coalesce", "pk_get_launch_stats", "pk_env_step_multi_d", "pk_env_end_multi_d", "pk_get_f64_d", "pk_set_env_batches", "pk_env_last_range"]
+           "pk_record_event", "pk_use_own_stream", "pk_set_coalesce", "pk_get_launch_stats", "pk_env_step_multi_d", "pk_env_end_multi_d", "pk_get_f64_d", "pk_set_env_batches", "pk_env_last_range",
+           "pk_get_obs_packed", "pk_get_obs_packed_d", "pk_set_env_obs_packed", "pk_host_alloc", "pk_host_free", "pk_check_actions",
+           "pk_env_step_begin", "pk_env_step_end"]
 
 
 class PokerlHipError(RuntimeError):
@@ -98,6 +100,14 @@ def lib():
     L.pk_env_end_multi_d.argtypes = [_vp]
     L.pk_set_env_batches.argtypes = [_vp, C.c_int]
     L.pk_env_last_range.argtypes = [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.pk_get_obs_packed.argtypes = [_vp, C.c_int, _vp]
+    L.pk_get_obs_packed_d.argtypes = [_vp, C.c_int, _vp]
+    L.pk_set_env_obs_packed.argtypes = [_vp, _vp]
+    L.pk_host_alloc.argtypes = [C.POINTER(_vp), C.c_size_t]
+    L.pk_host_free.argtypes = [_vp]
+    L.pk_check_actions.argtypes = [_vp, _vp, C.POINTER(C.c_int32)]
+    L.pk_env_step_begin.argtypes = [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]
+    L.pk_env_step_end.argtypes = [_vp]
     L.pk_get_owed.argtypes = [_vp, _vp]
     L.pk_set_tuning.argtypes = [_vp, C.c_int, C.c_int]
     L.pk_get_stream.argtypes = [_vp, C.POINTER(_vp)]

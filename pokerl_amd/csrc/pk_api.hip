@@ -2,6 +2,7 @@
 // no torch types.  Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -shared -fPIC (see pokerl_amd/build.py).
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -75,6 +76,8 @@ struct pk_handle {
     void *d_export = nullptr;
     size_t export_bytes = 0;
     uint8_t *h_pinned = nullptr;  // [T] pinned: per-table error bytes of pk_step / pk_env_step
+    uint8_t *d_obs_packed = nullptr;     // [T][PK_OBS_PACKED_BYTES(N)]: device staging of pk_env_step_begin (allocated on first use)
+    uint8_t *env_obs_packed = nullptr;   // pk_set_env_obs_packed: device buffer [T][PK_OBS_PACKED_BYTES(N)] or NULL
     std::string err;
     int fail(int code, const char *what, hipError_t e = hipSuccess) {
         err = what;
@@ -105,26 +108,48 @@ struct DeviceGuard {
         if (e_ != hipSuccess) return (h)->fail(PK_E_HIP, #call, e_); \
     } while (0)
 
-// one instantiation of every table kernel per seat count, PK_MIN_PLAYERS .. PK_MAX_PLAYERS
-static_assert(PK_MIN_PLAYERS == 2 && PK_MAX_PLAYERS == 15, "the dispatch below lists the seat counts");
+// One instantiation of every table kernel per seat count, PK_MIN_PLAYERS .. PK_MAX_PLAYERS, each seat count compiled in a
+// translation unit of its own (pk_tables.hip).  A development build may hold ONE seat count (-DPK_ONLY_SEATS=N: seconds
+// instead of minutes); pk_create refuses the others there.
+#ifdef PK_ONLY_SEATS
+#define PK_SEAT_ENABLED(N) ((N) == (PK_ONLY_SEATS))
+#else
+#define PK_SEAT_ENABLED(N) 1
+#endif
+#define PK_FOR_SEATS_LE10(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10)
+#define PK_FOR_SEATS_GT10(X) X(11) X(12) X(13) X(14) X(15)
+static_assert(PK_MIN_PLAYERS == 2 && PK_MAX_PLAYERS == 15, "the lists above name the seat counts");
+#define PK_DECLARE_ALL(N) PK_TABLE_KERNELS(PK_DECLARE_KERNEL, N)
+#define PK_DECLARE_ALL_LE10(N) PK_TABLE_KERNELS_LE10(PK_DECLARE_KERNEL, N)
+PK_FOR_SEATS_LE10(PK_DECLARE_ALL)
+PK_FOR_SEATS_GT10(PK_DECLARE_ALL)
+PK_FOR_SEATS_LE10(PK_DECLARE_ALL_LE10)
+static inline bool seat_count_built(int n) {
+#define PK_SEAT_CASE(N) if (n == N) return PK_SEAT_ENABLED(N);
+    PK_FOR_SEATS_LE10(PK_SEAT_CASE)
+    PK_FOR_SEATS_GT10(PK_SEAT_CASE)
+#undef PK_SEAT_CASE
+    return false;
+}
 #define DISPATCH_N_ON(h, strm, KERNEL, grid, ...) \
     do { \
         dim3 g_((grid)), b_((h)->block); \
+        hipStream_t strm_ = (strm); \
         switch ((h)->N) { \
-            case 2: hipLaunchKernelGGL(KERNEL<2>, g_, b_, 0, (strm), __VA_ARGS__); break; \
-            case 3: hipLaunchKernelGGL(KERNEL<3>, g_, b_, 0, (strm), __VA_ARGS__); break; \
-            case 4: hipLaunchKernelGGL(KERNEL<4>, g_, b_, 0, (strm), __VA_ARGS__); break; \
-            case 5: hipLaunchKernelGGL(KERNEL<5>, g_, b_, 0, (strm), __VA_ARGS__); break; \
-            case 6: hipLaunchKernelGGL(KERNEL<6>, g_, b_, 0, (strm), __VA_ARGS__); break; \
-            case 7: hipLaunchKernelGGL(KERNEL<7>, g_, b_, 0, (strm), __VA_ARGS__); break; \
-            case 8: hipLaunchKernelGGL(KERNEL<8>, g_, b_, 0, (strm), __VA_ARGS__); break; \
-            case 9: hipLaunchKernelGGL(KERNEL<9>, g_, b_, 0, (strm), __VA_ARGS__); break; \
-            case 10: hipLaunchKernelGGL(KERNEL<10>, g_, b_, 0, (strm), __VA_ARGS__); break; \
-            case 11: hipLaunchKernelGGL(KERNEL<11>, g_, b_, 0, (strm), __VA_ARGS__); break; \
-            case 12: hipLaunchKernelGGL(KERNEL<12>, g_, b_, 0, (strm), __VA_ARGS__); break; \
-            case 13: hipLaunchKernelGGL(KERNEL<13>, g_, b_, 0, (strm), __VA_ARGS__); break; \
-            case 14: hipLaunchKernelGGL(KERNEL<14>, g_, b_, 0, (strm), __VA_ARGS__); break; \
-            case 15: hipLaunchKernelGGL(KERNEL<15>, g_, b_, 0, (strm), __VA_ARGS__); break; \
+            case 2: if constexpr (PK_SEAT_ENABLED(2)) hipLaunchKernelGGL(KERNEL<2>, g_, b_, 0, strm_, __VA_ARGS__); break; \
+            case 3: if constexpr (PK_SEAT_ENABLED(3)) hipLaunchKernelGGL(KERNEL<3>, g_, b_, 0, strm_, __VA_ARGS__); break; \
+            case 4: if constexpr (PK_SEAT_ENABLED(4)) hipLaunchKernelGGL(KERNEL<4>, g_, b_, 0, strm_, __VA_ARGS__); break; \
+            case 5: if constexpr (PK_SEAT_ENABLED(5)) hipLaunchKernelGGL(KERNEL<5>, g_, b_, 0, strm_, __VA_ARGS__); break; \
+            case 6: if constexpr (PK_SEAT_ENABLED(6)) hipLaunchKernelGGL(KERNEL<6>, g_, b_, 0, strm_, __VA_ARGS__); break; \
+            case 7: if constexpr (PK_SEAT_ENABLED(7)) hipLaunchKernelGGL(KERNEL<7>, g_, b_, 0, strm_, __VA_ARGS__); break; \
+            case 8: if constexpr (PK_SEAT_ENABLED(8)) hipLaunchKernelGGL(KERNEL<8>, g_, b_, 0, strm_, __VA_ARGS__); break; \
+            case 9: if constexpr (PK_SEAT_ENABLED(9)) hipLaunchKernelGGL(KERNEL<9>, g_, b_, 0, strm_, __VA_ARGS__); break; \
+            case 10: if constexpr (PK_SEAT_ENABLED(10)) hipLaunchKernelGGL(KERNEL<10>, g_, b_, 0, strm_, __VA_ARGS__); break; \
+            case 11: if constexpr (PK_SEAT_ENABLED(11)) hipLaunchKernelGGL(KERNEL<11>, g_, b_, 0, strm_, __VA_ARGS__); break; \
+            case 12: if constexpr (PK_SEAT_ENABLED(12)) hipLaunchKernelGGL(KERNEL<12>, g_, b_, 0, strm_, __VA_ARGS__); break; \
+            case 13: if constexpr (PK_SEAT_ENABLED(13)) hipLaunchKernelGGL(KERNEL<13>, g_, b_, 0, strm_, __VA_ARGS__); break; \
+            case 14: if constexpr (PK_SEAT_ENABLED(14)) hipLaunchKernelGGL(KERNEL<14>, g_, b_, 0, strm_, __VA_ARGS__); break; \
+            case 15: if constexpr (PK_SEAT_ENABLED(15)) hipLaunchKernelGGL(KERNEL<15>, g_, b_, 0, strm_, __VA_ARGS__); break; \
         } \
     } while (0)
 #define DISPATCH_N(h, KERNEL, grid, ...) DISPATCH_N_ON(h, (h)->stream, KERNEL, grid, __VA_ARGS__)
@@ -133,18 +158,20 @@ static_assert(PK_MIN_PLAYERS == 2 && PK_MAX_PLAYERS == 15, "the dispatch below l
     do { \
         dim3 g_((grid)), b_((h)->block); \
         switch ((h)->N) { \
-            case 2: hipLaunchKernelGGL(KERNEL<2>, g_, b_, 0, (h)->stream, __VA_ARGS__); break; \
-            case 3: hipLaunchKernelGGL(KERNEL<3>, g_, b_, 0, (h)->stream, __VA_ARGS__); break; \
-            case 4: hipLaunchKernelGGL(KERNEL<4>, g_, b_, 0, (h)->stream, __VA_ARGS__); break; \
-            case 5: hipLaunchKernelGGL(KERNEL<5>, g_, b_, 0, (h)->stream, __VA_ARGS__); break; \
-            case 6: hipLaunchKernelGGL(KERNEL<6>, g_, b_, 0, (h)->stream, __VA_ARGS__); break; \
-            case 7: hipLaunchKernelGGL(KERNEL<7>, g_, b_, 0, (h)->stream, __VA_ARGS__); break; \
-            case 8: hipLaunchKernelGGL(KERNEL<8>, g_, b_, 0, (h)->stream, __VA_ARGS__); break; \
-            case 9: hipLaunchKernelGGL(KERNEL<9>, g_, b_, 0, (h)->stream, __VA_ARGS__); break; \
-            case 10: hipLaunchKernelGGL(KERNEL<10>, g_, b_, 0, (h)->stream, __VA_ARGS__); break; \
+            case 2: if constexpr (PK_SEAT_ENABLED(2)) hipLaunchKernelGGL(KERNEL<2>, g_, b_, 0, (h)->stream, __VA_ARGS__); break; \
+            case 3: if constexpr (PK_SEAT_ENABLED(3)) hipLaunchKernelGGL(KERNEL<3>, g_, b_, 0, (h)->stream, __VA_ARGS__); break; \
+            case 4: if constexpr (PK_SEAT_ENABLED(4)) hipLaunchKernelGGL(KERNEL<4>, g_, b_, 0, (h)->stream, __VA_ARGS__); break; \
+            case 5: if constexpr (PK_SEAT_ENABLED(5)) hipLaunchKernelGGL(KERNEL<5>, g_, b_, 0, (h)->stream, __VA_ARGS__); break; \
+            case 6: if constexpr (PK_SEAT_ENABLED(6)) hipLaunchKernelGGL(KERNEL<6>, g_, b_, 0, (h)->stream, __VA_ARGS__); break; \
+            case 7: if constexpr (PK_SEAT_ENABLED(7)) hipLaunchKernelGGL(KERNEL<7>, g_, b_, 0, (h)->stream, __VA_ARGS__); break; \
+            case 8: if constexpr (PK_SEAT_ENABLED(8)) hipLaunchKernelGGL(KERNEL<8>, g_, b_, 0, (h)->stream, __VA_ARGS__); break; \
+            case 9: if constexpr (PK_SEAT_ENABLED(9)) hipLaunchKernelGGL(KERNEL<9>, g_, b_, 0, (h)->stream, __VA_ARGS__); break; \
+            case 10: if constexpr (PK_SEAT_ENABLED(10)) hipLaunchKernelGGL(KERNEL<10>, g_, b_, 0, (h)->stream, __VA_ARGS__); break; \
         } \
     } while (0)
 
+#define PK_STR_(x) #x
+#define PK_STR(x) PK_STR_(x)
 static inline bool bad_policy(int policy) { return policy < 0 || policy >= PK_NUM_POLICIES; }
 // every seat plays `policy`: the per-seat word of the entry points that take ONE opponent policy
 static inline uint64_t uniform_seats(int policy) { return 0x1111111111111111ull * (uint64_t)(policy & 15); }
@@ -226,6 +253,25 @@ static int export_to_host(pk_handle *h, void *out, size_t bytes, F launch) {
     return PK_OK;
 }
 
+static int check_device_any() {
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) { g_err = "no HIP device available; this library has no CPU fallback"; return PK_E_NO_DEVICE; }
+    return PK_OK;
+}
+
+// The argument block of the PokerGameEnv.step kernels (pk_kernels.hpp EnvKernArgs): common fields; callers set the rest.
+static EnvKernArgs env_args(const pk_handle *h, const int32_t *actions_d, int seat0_policy, uint64_t seatpol, int auto_reset,
+                            double *reward_d, uint8_t *done_d, uint8_t *hand_d, uint8_t *terr_d, double *obs_d) {
+    EnvKernArgs ka{};
+    ka.Sp = (const State *)h->d_S; ka.H = h->hot_env;
+    ka.A.actions = actions_d; ka.A.seat0_policy = seat0_policy; ka.A.seatpol = seatpol; ka.A.auto_reset = auto_reset;
+    ka.A.reward = reward_d; ka.A.done = done_d; ka.A.hand = hand_d; ka.A.terr = terr_d; ka.A.obs = obs_d;
+    ka.A.obs_packed = h->env_obs_packed;   // pk_set_env_obs_packed: the compact row beside (or instead of) the f64 one
+    ka.A.park = env_park(h); ka.A.t0 = 0; ka.A.tend = h->T;
+    return ka;
+}
+
 extern "C" {
 
 int pk_abi_version(void) { return PK_ABI_VERSION; }
@@ -244,8 +290,18 @@ int pk_create(pk_handle **out, int device, int num_tables, int num_players, cons
     if (!out) { g_err = "pk_create: out is NULL"; return PK_E_INVALID_ARG; }
     *out = nullptr;
     if (num_tables < 1 || num_players < PK_MIN_PLAYERS || num_players > PK_MAX_PLAYERS) {
-        g_err = "pk_create: need num_tables >= 1 and 2 <= num_players <= 15";
+        g_err = "pk_create: need num_tables >= 1 and " PK_STR(PK_MIN_PLAYERS) " <= num_players <= " PK_STR(PK_MAX_PLAYERS)
+                " (the reference takes any num_players, game.py:246; beyond " PK_STR(PK_MAX_PLAYERS) " seats numpy's argsort of the bets, "
+                "game.py:495, is no longer a stable insertion sort, so the side-pot order among equal bets is not a rule the reference pins: DESIGN.md section 9)";
         return PK_E_INVALID_ARG;
+    }
+    if (!seat_count_built(num_players)) { g_err = "pk_create: this development build of the library holds one seat count only (PK_ONLY_SEATS)"; return PK_E_INVALID_ARG; }
+    {   // Money must be finite: the library is built with -fno-honor-nans (v_max_f64 / v_min_f64 for np.max / np.minimum), and an
+        // infinite stack turns into NaN at the first all-in (inf - inf), where numpy and the device would disagree silently.
+        bool finite = std::isfinite(big_blind) && std::isfinite(small_blind);
+        if (start_credits) { for (int i = 0; i < num_players; ++i) finite = finite && std::isfinite(start_credits[i]); }
+        else finite = finite && std::isfinite(start_credit_scalar);
+        if (!finite) { g_err = "pk_create: start_credits, big_blind and small_blind must be finite (no inf / NaN)"; return PK_E_INVALID_ARG; }
     }
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -376,6 +432,7 @@ int pk_destroy(pk_handle *h) {
     DeviceGuard guard(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->arena) (void)hipFree(h->arena);
+    if (h->d_obs_packed) (void)hipFree(h->d_obs_packed);
     if (h->h_pinned) (void)hipHostFree(h->h_pinned);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -469,7 +526,8 @@ int pk_step_d(pk_handle *h, const int32_t *actions_d, uint8_t *flags_d, uint8_t 
     if (!h || !actions_d || !flags_d) return h ? h->fail(PK_E_INVALID_ARG, "pk_step_d: NULL buffer") : PK_E_INVALID_ARG;
     ON_DEVICE(h);
     FLUSH(h);
-    DISPATCH_N(h, k_step, table_grid(h), (const State *)h->d_S, h->hot, actions_d, flags_d, terr_d, scaled_park(h, 28));
+    const StepKernArgs ka{(const State *)h->d_S, h->hot, actions_d, flags_d, terr_d, scaled_park(h, 28)};
+    DISPATCH_N(h, k_step, table_grid(h), ka);
     HIPCHK(h, hipGetLastError());
     return PK_OK;
 }
@@ -617,6 +675,65 @@ int pk_get_obs_d(pk_handle *h, int player, double *out_d) {
     return PK_OK;
 }
 
+int pk_get_obs_packed(pk_handle *h, int player, uint8_t *out) {
+    if (!h || !out || bad_player(h, player)) return h ? h->fail(PK_E_INVALID_ARG, "pk_get_obs_packed: bad argument") : PK_E_INVALID_ARG;
+    size_t bytes = (size_t)h->T * PK_OBS_PACKED_BYTES(h->N);
+    return export_to_host(h, out, bytes, [&] {
+        hipLaunchKernelGGL(k_obs_packed, dim3(flat_grid(h->T)), dim3(256), 0, h->stream, h->S, h->N, player, (uint8_t *)h->d_export);
+    });
+}
+
+int pk_get_obs_packed_d(pk_handle *h, int player, uint8_t *out_d) {
+    if (!h || !out_d || bad_player(h, player) || ((uintptr_t)out_d & 7)) return h ? h->fail(PK_E_INVALID_ARG, "pk_get_obs_packed_d: bad argument (out_d must be 8-byte aligned)") : PK_E_INVALID_ARG;
+    ON_DEVICE(h);
+    FLUSH(h);
+    hipLaunchKernelGGL(k_obs_packed, dim3(flat_grid(h->T)), dim3(256), 0, h->stream, h->S, h->N, player, out_d);
+    HIPCHK(h, hipGetLastError());
+    return PK_OK;
+}
+
+int pk_set_env_obs_packed(pk_handle *h, uint8_t *obs_packed_d) {
+    if (!h || ((uintptr_t)obs_packed_d & 7)) return h ? h->fail(PK_E_INVALID_ARG, "pk_set_env_obs_packed: the buffer must be 8-byte aligned") : PK_E_INVALID_ARG;
+    if (h->env_pending) return h->fail(PK_E_BUSY, "pk_set_env_obs_packed: PokerGameEnv steps are in flight");
+    h->env_obs_packed = obs_packed_d;
+    return PK_OK;
+}
+
+int pk_host_alloc(void **out, size_t bytes) {
+    if (!out || bytes == 0) { g_err = "pk_host_alloc: bad argument"; return PK_E_INVALID_ARG; }
+    *out = nullptr;
+    int rc = check_device_any();
+    if (rc) return rc;
+    hipError_t e = hipHostMalloc(out, bytes, hipHostMallocPortable);
+    if (e != hipSuccess) { g_err = std::string("pk_host_alloc: ") + hipGetErrorString(e); *out = nullptr; return PK_E_OOM; }
+    return PK_OK;
+}
+
+int pk_host_free(void *p) {
+    if (!p) return PK_OK;
+    return hipHostFree(p) == hipSuccess ? PK_OK : PK_E_HIP;
+}
+
+// Game.step's precondition (game.py:648-651) for a whole batch WITHOUT touching a table: index of the first table whose
+// action is not valid for its active player, or -1.
+int pk_check_actions(pk_handle *h, const int32_t *actions, int32_t *first_bad) {
+    if (!h || !actions || !first_bad) return h ? h->fail(PK_E_INVALID_ARG, "pk_check_actions: NULL buffer") : PK_E_INVALID_ARG;
+    ON_DEVICE(h);
+    FLUSH(h);
+    const size_t T = (size_t)h->T;
+    int32_t *slot = (int32_t *)h->d_totals;                         // (8-byte slot 0 of the counters' output: free between calls)
+    const int32_t init = 0x7fffffff;
+    HIPCHK(h, hipMemcpyAsync(h->d_actions, actions, T * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(slot, &init, 4, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_check_actions, dim3(flat_grid(T)), dim3(256), 0, h->stream, h->S.valid, h->d_actions, h->T, slot);
+    HIPCHK(h, hipGetLastError());
+    int32_t got = 0;
+    HIPCHK(h, hipMemcpyAsync(&got, slot, 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    *first_bad = got == init ? -1 : got;
+    return PK_OK;
+}
+
 int pk_get_valid_actions_d(pk_handle *h, int player, uint8_t *out_d) {
     if (!h || !out_d || bad_player(h, player)) return h ? h->fail(PK_E_INVALID_ARG, "pk_get_valid_actions_d: bad argument") : PK_E_INVALID_ARG;
     ON_DEVICE(h);
@@ -631,7 +748,8 @@ int pk_env_reset_d(pk_handle *h, const uint8_t *mask_d, int opp_policy) {
     if (!h || bad_policy(opp_policy)) return h ? h->fail(PK_E_INVALID_ARG, "pk_env_reset_d: bad argument") : PK_E_INVALID_ARG;
     ON_DEVICE(h);
     FLUSH(h);
-    DISPATCH_N(h, k_env_reset, env_grid(h), (const State *)h->d_S, h->hot_env, mask_d, uniform_seats(opp_policy), env_park(h));
+    const EnvResetKernArgs ka{(const State *)h->d_S, h->hot_env, mask_d, uniform_seats(opp_policy), env_park(h)};
+    DISPATCH_N(h, k_env_reset, env_grid(h), ka);
     HIPCHK(h, hipGetLastError());
     return PK_OK;
 }
@@ -642,7 +760,8 @@ int pk_env_step_d(pk_handle *h, const int32_t *actions_d, int opp_policy, double
         return h ? h->fail(PK_E_INVALID_ARG, "pk_env_step_d: bad argument") : PK_E_INVALID_ARG;
     ON_DEVICE(h);
     FLUSH(h);
-    DISPATCH_N(h, k_env_step, env_grid(h), (const State *)h->d_S, h->hot_env, actions_d, -1, uniform_seats(opp_policy), 0, reward_d, done_d, hand_d, terr_d, (double *)nullptr, env_park(h));
+    const EnvKernArgs ka = env_args(h, actions_d, -1, uniform_seats(opp_policy), 0, reward_d, done_d, hand_d, terr_d, nullptr);
+    DISPATCH_N(h, k_env_step, env_grid(h), ka);
     HIPCHK(h, hipGetLastError());
     return PK_OK;
 }
@@ -654,8 +773,8 @@ int pk_env_step_fused_d(pk_handle *h, const int32_t *actions_d, int seat0_policy
         return h ? h->fail(PK_E_INVALID_ARG, "pk_env_step_fused_d: bad argument") : PK_E_INVALID_ARG;
     ON_DEVICE(h);
     FLUSH(h);
-    DISPATCH_N(h, k_env_step, env_grid(h), (const State *)h->d_S, h->hot_env, actions_d, actions_d ? -1 : seat0_policy, uniform_seats(opp_policy),
-               auto_reset ? 1 : 0, reward_d, done_d, hand_d, terr_d, obs_d, env_park(h));
+    const EnvKernArgs ka = env_args(h, actions_d, actions_d ? -1 : seat0_policy, uniform_seats(opp_policy), auto_reset ? 1 : 0, reward_d, done_d, hand_d, terr_d, obs_d);
+    DISPATCH_N(h, k_env_step, env_grid(h), ka);
     HIPCHK(h, hipGetLastError());
     return PK_OK;
 }
@@ -675,8 +794,9 @@ int pk_env_step_async_d(pk_handle *h, const int32_t *actions_d, int seat0_policy
     if (rc) return rc;
     const int mp = max_passes > 0 ? max_passes : 0;
     if (h->env_batches <= 1) {
-        DISPATCH_N(h, k_env_step_async, env_grid(h), (const State *)h->d_S, h->hot_env, actions_d, actions_d ? -1 : seat0_policy, uniform_seats(opp_policy),
-                   au, reward_d, done_d, hand_d, terr_d, obs_d, env_park(h), ready_d, mp, 0, h->T);
+        EnvKernArgs ka = env_args(h, actions_d, actions_d ? -1 : seat0_policy, uniform_seats(opp_policy), au, reward_d, done_d, hand_d, terr_d, obs_d);
+        ka.A.ready = ready_d; ka.A.max_passes = mp;
+        DISPATCH_N(h, k_env_step_async, env_grid(h), ka);
         HIPCHK(h, hipGetLastError());
         h->env_last_begin = 0; h->env_last_end = h->T; h->env_last_fresh = 0;
     } else {
@@ -685,8 +805,9 @@ int pk_env_step_async_d(pk_handle *h, const int32_t *actions_d, int seat0_policy
         auto launch_range = [&](int b, int passes) -> int {
             const int t0 = b * h->env_range, tend = (t0 + h->env_range < h->T) ? t0 + h->env_range : h->T;
             HIPCHK(h, hipStreamWaitEvent(h->env_streams[b], h->env_in, 0));
-            DISPATCH_N_ON(h, h->env_streams[b], k_env_step_async, (tend - t0 + h->env_tpb - 1) / h->env_tpb, (const State *)h->d_S, h->hot_env, actions_d,
-                          actions_d ? -1 : seat0_policy, uniform_seats(opp_policy), au, reward_d, done_d, hand_d, terr_d, obs_d, env_park(h), ready_d, passes, t0, tend);
+            EnvKernArgs ka = env_args(h, actions_d, actions_d ? -1 : seat0_policy, uniform_seats(opp_policy), au, reward_d, done_d, hand_d, terr_d, obs_d);
+            ka.A.ready = ready_d; ka.A.max_passes = passes; ka.A.t0 = t0; ka.A.tend = tend;
+            DISPATCH_N_ON(h, h->env_streams[b], k_env_step_async, (tend - t0 + h->env_tpb - 1) / h->env_tpb, ka);
             HIPCHK(h, hipGetLastError());
             HIPCHK(h, hipEventRecord(h->env_done[b], h->env_streams[b]));
             return PK_OK;
@@ -768,8 +889,9 @@ int pk_env_step_multi_d(pk_handle *h, const int32_t *actions_d, const uint8_t *r
     rc = flush_rollout(h);
     if (rc) return rc;
     const int pol0 = PK_SEAT_POLICY(seat_policies, 0);
-    DISPATCH_N(h, k_env_step_multi, env_grid(h), (const State *)h->d_S, h->hot_env, actions_d, pol0 == PK_POLICY_EXTERNAL ? -1 : pol0, seat_policies,
-               au, reward_d, done_d, hand_d, terr_d, obs_d, env_park(h), ready_d, max_passes > 0 ? max_passes : 0, reset_d, who_d, 0);
+    EnvKernArgs ka = env_args(h, actions_d, pol0 == PK_POLICY_EXTERNAL ? -1 : pol0, seat_policies, au, reward_d, done_d, hand_d, terr_d, obs_d);
+    ka.A.ready = ready_d; ka.A.max_passes = max_passes > 0 ? max_passes : 0; ka.A.reset_req = reset_d; ka.A.who = who_d;
+    DISPATCH_N(h, k_env_step_multi, env_grid(h), ka);
     HIPCHK(h, hipGetLastError());
     // a table may be waiting for the caller's action for an external seat even after a drain: in flight until pk_env_end_multi_d
     h->env_pending = max_passes > 0 || ext;
@@ -785,8 +907,9 @@ int pk_env_end_multi_d(pk_handle *h) {
     const int pol0 = PK_SEAT_POLICY(h->env_seats, 0);
     // drain; what is still in flight afterwards waits for an external seat's action between two Game.steps and is abandoned.
     // Outputs of steps that return during this drain go to the handle's own staging buffers, i.e. are dropped.
-    DISPATCH_N(h, k_env_step_multi, env_grid(h), (const State *)h->d_S, h->hot_env, (const int32_t *)nullptr, pol0 == PK_POLICY_EXTERNAL ? -1 : pol0, h->env_seats,
-               h->env_auto, h->d_reward, h->d_done, h->d_handf, h->d_terr, (double *)nullptr, env_park(h), h->d_flags, 0, (const uint8_t *)nullptr, h->d_mask, 1);
+    EnvKernArgs ka = env_args(h, nullptr, pol0 == PK_POLICY_EXTERNAL ? -1 : pol0, h->env_seats, h->env_auto, h->d_reward, h->d_done, h->d_handf, h->d_terr, nullptr);
+    ka.A.ready = h->d_flags; ka.A.who = h->d_mask; ka.A.abandon = 1; ka.A.obs_packed = nullptr;
+    DISPATCH_N(h, k_env_step_multi, env_grid(h), ka);
     HIPCHK(h, hipGetLastError());
     h->env_pending = false; h->env_multi = false;
     return PK_OK;
@@ -942,6 +1065,44 @@ int pk_env_step(pk_handle *h, const int32_t *actions, int opp_policy, double *re
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (terr) memcpy(terr, h->h_pinned, T);
     if (any_terr(h->h_pinned, h->T)) return h->fail(PK_E_TABLE, "pk_env_step: per-table error(s), see terr");
+    return PK_OK;
+}
+
+// PokerGameEnv.step through HOST buffers, in two halves: pk_env_step_begin uploads the actions, launches the step (seat 0 =
+// the caller's actions; finished episodes reset on the spot when auto_reset != 0) and queues the copies of every output into
+// the caller's buffers; pk_env_step_end waits for them.  With PINNED buffers (pk_host_alloc) nothing in `begin` blocks, the
+// copies run at PCIe line rate, and the caller -- or another handle's step -- overlaps with them.  obs / obs_packed may be
+// NULL (no row of that kind).  Between begin and end the handle may not be used otherwise.
+int pk_env_step_begin(pk_handle *h, const int32_t *actions, int opp_policy, int auto_reset, double *reward, uint8_t *done,
+                      uint8_t *hand, uint8_t *terr, double *obs, uint8_t *obs_packed) {
+    if (!h || !actions || !reward || !done || !hand || !terr || bad_policy(opp_policy))
+        return h ? h->fail(PK_E_INVALID_ARG, "pk_env_step_begin: bad argument") : PK_E_INVALID_ARG;
+    ON_DEVICE(h);
+    FLUSH(h);
+    const size_t T = (size_t)h->T, D = (size_t)PK_OBS_DIM(h->N), PB = (size_t)PK_OBS_PACKED_BYTES(h->N);
+    if (obs && T * D * 8 > h->export_bytes) return h->fail(PK_E_INVALID_ARG, "export buffer too small");
+    if (obs_packed && !h->d_obs_packed) {
+        HIPCHK(h, hipMalloc((void **)&h->d_obs_packed, T * PB));
+    }
+    HIPCHK(h, hipMemcpyAsync(h->d_actions, actions, T * 4, hipMemcpyHostToDevice, h->stream));
+    EnvKernArgs ka = env_args(h, h->d_actions, -1, uniform_seats(opp_policy), auto_reset ? 1 : 0, h->d_reward, h->d_done, h->d_handf, h->d_terr,
+                              obs ? (double *)h->d_export : nullptr);
+    ka.A.obs_packed = obs_packed ? h->d_obs_packed : nullptr;
+    DISPATCH_N(h, k_env_step, env_grid(h), ka);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(reward, h->d_reward, T * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(done, h->d_done, T, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(hand, h->d_handf, T, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(terr, h->d_terr, T, hipMemcpyDeviceToHost, h->stream));
+    if (obs) HIPCHK(h, hipMemcpyAsync(obs, h->d_export, T * D * 8, hipMemcpyDeviceToHost, h->stream));
+    if (obs_packed) HIPCHK(h, hipMemcpyAsync(obs_packed, h->d_obs_packed, T * PB, hipMemcpyDeviceToHost, h->stream));
+    return PK_OK;
+}
+
+int pk_env_step_end(pk_handle *h) {
+    if (!h) return PK_E_INVALID_ARG;
+    ON_DEVICE(h);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
     return PK_OK;
 }
 

@@ -129,6 +129,18 @@ __device__ __forceinline__ uint32_t rep4(uint32_t x) {
     return __builtin_amdgcn_perm(x, x, 0u);
 #endif
 }
+// A pointer that was LOADED from memory (the array bases behind `const State *Sp`) is a flat pointer to the compiler: every
+// access through it becomes flat_load / flat_store (aperture check, counts on vmcnt AND lgkmcnt).  All table state lives in
+// hipMalloc'ed memory, so say so: the round trip through address space 1 makes the accesses global_load /
+// global_store.  (Pointers that arrive as kernel arguments, also inside by-value structs, are global already.)
+#ifdef PK_HOST_SIM
+#define PK_GLOBAL
+#else
+#define PK_GLOBAL __attribute__((address_space(1)))
+#endif
+template <typename T>
+__device__ __forceinline__ PK_GLOBAL T *as_global(T *p) { return (PK_GLOBAL T *)p; }   // (keep the result's TYPE: `auto g = as_global(p)`;
+                                                                                       //  cast back to a flat pointer and the optimiser folds the pair away)
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
@@ -597,7 +609,7 @@ struct ActionRing {
     }
 };
 // The same through the workgroup's LDS table (k_rollout): one byte read instead of a six-step select chain.
-struct NthTable {   // nth[mask][k] = k-th (0-based) set bit of a 7-bit valid-action mask, for every mask: a compile-time constant
+struct alignas(16) NthTable {   // (16-byte aligned: stage_nth copies it with uint4 loads) nth[mask][k] = k-th (0-based) set bit of a 7-bit valid-action mask, for every mask: a compile-time constant
     uint8_t e[128][8];
     constexpr NthTable() : e{} {
         for (int m = 0; m < 128; ++m) {
@@ -614,6 +626,7 @@ struct NthTable {   // nth[mask][k] = k-th (0-based) set bit of a 7-bit valid-ac
 __device__ __constant__ const NthTable g_nth{};
 template <typename LDS>
 __device__ __forceinline__ void stage_nth(LDS &lds) {  // call once from wave-uniform control flow: 16 bytes per lane
+    static_assert(alignof(NthTable) >= 16 && sizeof(NthTable) == 64 * sizeof(uint4), "stage_nth copies the table as 64 uint4");
     for (int i = threadIdx.x & (PK_WAVE - 1); i < 64; i += PK_WAVE)
         reinterpret_cast<uint4 *>(&lds.nth[0][0])[i] = reinterpret_cast<const uint4 *>(&g_nth.e[0][0])[i];
     __syncthreads();
@@ -669,20 +682,24 @@ struct Table {
     bool showed;  // lds.show holds a showdown of this launch
     PK_PROF(Prof prof;)
 
-    __device__ __forceinline__ void load(const State &S, int t) {
+    template <typename ST>   // State, or a State in address space 1 (`*as_global(Sp)`)
+    __device__ __forceinline__ void load(const ST &S, int t) {
+        const auto g_credits = as_global(S.credits), g_bets = as_global(S.bets), g_pending = as_global(S.pending), g_payoffs = as_global(S.payoffs);
+        const size_t T = (size_t)S.T;
         PK_FOR(p, N)
-            credits[p] = S.credits[(size_t)p * S.T + t]; bets[p] = S.bets[(size_t)p * S.T + t];
-            pending[p] = S.pending[(size_t)p * S.T + t]; payoffs[p] = S.payoffs[(size_t)p * S.T + t];
+            credits[p] = g_credits[(size_t)p * T + t]; bets[p] = g_bets[(size_t)p * T + t];
+            pending[p] = g_pending[(size_t)p * T + t]; payoffs[p] = g_payoffs[(size_t)p * T + t];
          PK_END
-        min_raise = S.min_raise[t];
-        uint64_t ss = S.seat_states[t];
+        min_raise = as_global(S.min_raise)[t];
+        uint64_t ss = as_global(S.seat_states)[t];
         st_active = (uint32_t)ss & 0xffff; st_called = (uint32_t)(ss >> 16) & 0xffff;
         st_allin = (uint32_t)(ss >> 32) & 0xffff; st_broken = (uint32_t)(ss >> 48) & 0xffff;
-        uint32_t cur = S.cursors[t];
+        uint32_t cur = as_global(S.cursors)[t];
         active = cur & 0xf; dealer = (cur >> 4) & 0xf; sb = (cur >> 8) & 0xf; bb = (cur >> 12) & 0xf; turn = (cur >> 16) & 0xf;
-        hand = S.hand[t];
-        hand_serial = S.hand_serial[t]; step_serial = S.step_serial[t];
-        PK_FOR(w, W) cards[w] = S.cards[(size_t)w * S.T + t]; PK_END
+        hand = as_global(S.hand)[t];
+        hand_serial = as_global(S.hand_serial)[t]; step_serial = as_global(S.step_serial)[t];
+        const auto g_cards = as_global(S.cards);
+        PK_FOR(w, W) cards[w] = g_cards[(size_t)w * T + t]; PK_END
         // A step left in flight by a deferred rollout launch (all-zero bits = idle table; only k_rollout ever finds
         // anything else: the host flushes deferred work before every other kernel).
         current = (cur >> 20) & 0xf; lstate = (cur >> 24) & 3; foldout = (cur >> 26) & 1; stepped = (cur >> 27) & 1;
@@ -703,19 +720,23 @@ struct Table {
         evals = 0; games = 0; hands = 0; seen = 0; showed = false;
     }
     __device__ __forceinline__ void idle() { lstate = LS_DONE; current = 0; hands_this_step = 0; flags = 0; terr = 0; stepped = 0; foldout = false; }
-    __device__ __forceinline__ void store(const State &S, int t) const {
+    template <typename ST>
+    __device__ __forceinline__ void store(const ST &S, int t) const {
+        const auto g_credits = as_global(S.credits), g_bets = as_global(S.bets), g_pending = as_global(S.pending), g_payoffs = as_global(S.payoffs);
+        const size_t T = (size_t)S.T;
         PK_FOR(p, N)
-            S.credits[(size_t)p * S.T + t] = credits[p]; S.bets[(size_t)p * S.T + t] = bets[p];
-            S.pending[(size_t)p * S.T + t] = pending[p]; S.payoffs[(size_t)p * S.T + t] = payoffs[p];
+            g_credits[(size_t)p * T + t] = credits[p]; g_bets[(size_t)p * T + t] = bets[p];
+            g_pending[(size_t)p * T + t] = pending[p]; g_payoffs[(size_t)p * T + t] = payoffs[p];
          PK_END
-        S.min_raise[t] = min_raise;
-        S.seat_states[t] = (uint64_t)st_active | ((uint64_t)st_called << 16) | ((uint64_t)st_allin << 32) | ((uint64_t)st_broken << 48);
+        as_global(S.min_raise)[t] = min_raise;
+        as_global(S.seat_states)[t] = (uint64_t)st_active | ((uint64_t)st_called << 16) | ((uint64_t)st_allin << 32) | ((uint64_t)st_broken << 48);
         const uint32_t inflight = ((uint32_t)current << 20) | ((uint32_t)lstate << 24) | ((uint32_t)foldout << 26) | (stepped << 27) | (flags << 28);
-        S.cursors[t] = (uint32_t)active | ((uint32_t)dealer << 4) | ((uint32_t)sb << 8) | ((uint32_t)bb << 12) | ((uint32_t)turn << 16) |
-                       (lstate == LS_DONE ? 0u : inflight);
-        S.hand[t] = hand;
-        S.hand_serial[t] = hand_serial; S.step_serial[t] = step_serial;
-        PK_FOR(w, W) S.cards[(size_t)w * S.T + t] = cards[w]; PK_END
+        as_global(S.cursors)[t] = (uint32_t)active | ((uint32_t)dealer << 4) | ((uint32_t)sb << 8) | ((uint32_t)bb << 12) | ((uint32_t)turn << 16) |
+                                  (lstate == LS_DONE ? 0u : inflight);
+        as_global(S.hand)[t] = hand;
+        as_global(S.hand_serial)[t] = hand_serial; as_global(S.step_serial)[t] = step_serial;
+        const auto g_cards = as_global(S.cards);
+        PK_FOR(w, W) g_cards[(size_t)w * T + t] = cards[w]; PK_END
     }
 
     __device__ __forceinline__ void set_state(int p, int st) {  // player_states[p] = st
@@ -844,14 +865,15 @@ struct Table {
     __device__ __forceinline__ void store_show(uint32_t *show, int T, int t, const Lds<N> &lds) const {
         if (showed) {
             const int lane = threadIdx.x & (PK_WAVE - 1);
-            PK_FOR(p, N) show[(size_t)p * T + t] = lds.show[p][lane]; PK_END
+            const auto g_show = as_global(show);
+            PK_FOR(p, N) g_show[(size_t)p * T + t] = lds.show[p][lane]; PK_END
         }
     }
     // Workgroup copy of the fresh-table constants; call once, from wave-uniform control flow, before the first end_block.
     __device__ __forceinline__ static void stage_fresh(Lds<N> &lds, const Fresh *src) {
         const int lane = threadIdx.x & (PK_WAVE - 1);
         constexpr int words = (int)(sizeof(Fresh) / 4);
-        const uint32_t *s32 = reinterpret_cast<const uint32_t *>(src);
+        const auto s32 = as_global(reinterpret_cast<const uint32_t *>(src));
         uint32_t *d32 = reinterpret_cast<uint32_t *>(&lds.fresh);
         for (int i = lane; i < words; i += PK_WAVE) d32[i] = s32[i];
         __syncthreads();

@@ -13,7 +13,8 @@ using namespace pk;
 // __launch_bounds__(64) lets the compiler keep a table's full state in VGPRs instead of spilling to scratch.
 #define PK_TABLE_BLOCK 64
 
-__device__ __forceinline__ void wave_add_counters(const State &S, uint32_t steps, uint32_t hands, uint32_t evals, uint32_t games) {
+template <typename ST>
+__device__ __forceinline__ void wave_add_counters(const ST &S, uint32_t steps, uint32_t hands, uint32_t evals, uint32_t games) {
     // 64-wide butterfly reduction in registers, then lane 0 adds to the slot this wavefront owns (plain RMW, no atomics).
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -21,11 +22,12 @@ __device__ __forceinline__ void wave_add_counters(const State &S, uint32_t steps
         evals += __shfl_down(evals, off, 64); games += __shfl_down(games, off, 64);
     }
     if ((threadIdx.x & 63) == 0) {
-        unsigned long long *slot = S.counters + (size_t)blockIdx.x * PK_NUM_COUNTERS;
+        const auto slot = as_global(S.counters) + (size_t)blockIdx.x * PK_NUM_COUNTERS;
         slot[PK_C_STEPS] += steps; slot[PK_C_HANDS] += hands; slot[PK_C_EVALS] += evals; slot[PK_C_GAMES] += games;
     }
 }
 
+#ifndef PK_TABLES_ONLY   // (the per-seat-count translation units, pk_tables.hip, hold the table kernel templates only)
 // Sums and clears the per-wave counter slots: one workgroup, grid-stride over the slots.
 __global__ void __launch_bounds__(256) k_sum_counters(unsigned long long *slots, int nslots, unsigned long long *out) {
     __shared__ unsigned long long part[256][PK_NUM_COUNTERS];
@@ -40,6 +42,8 @@ __global__ void __launch_bounds__(256) k_sum_counters(unsigned long long *slots,
     }
     if (threadIdx.x < PK_NUM_COUNTERS) out[threadIdx.x] = part[0][threadIdx.x];
 }
+
+#endif
 
 template <int N>
 __global__ void __launch_bounds__(PK_TABLE_BLOCK) k_reset(State S, Hot H, const uint8_t *mask, int dealer) {  // Game.reset, game.py:397-412
@@ -101,12 +105,15 @@ __global__ void __launch_bounds__(PK_TABLE_BLOCK) k_pick(State S, Hot H, int pol
 // an invalid one leaves the table untouched (game.py:649-651).  PASSES = betting passes between two looks at the parked
 // lanes: four for the multi-step kernels, one for the single-step ones (a lane makes one step; three more passes
 // would run empty).
+// k_step's formal parameter = the layout of its kernarg segment: the two output pointers are read through the kernarg
+// segment pointer after the loop (see EnvArgs below for why).
+struct StepKernArgs { const State *Sp; Hot H; const int32_t *actions; uint8_t *flags, *terr; int park; };
 template <int N, bool ONE_PASS, int POLICY, int PASSES = 0>
 __device__ __forceinline__ void rollout_body(const State *__restrict__ Sp, const Hot &H, int K, int auto_reset, int park, int slack, int clear_terr,
-                                             const int32_t *actions = nullptr, uint8_t *flags_out = nullptr, uint8_t *terr_out = nullptr) {
+                                             const int32_t *actions = nullptr, const StepKernArgs *ext = nullptr) {
     // Array bases by pointer (loaded only where the table is loaded / stored), loop scalars by value: see pk::Hot.
     constexpr int policy = POLICY;
-    const State &S = *Sp;
+    const auto &S = *as_global(Sp);
     __shared__ Lds<N> lds;
     const int t = blockIdx.x * H.tpb + threadIdx.x;
     const bool live = (int)threadIdx.x < H.tpb && t < S.T;
@@ -116,7 +123,7 @@ __device__ __forceinline__ void rollout_body(const State *__restrict__ Sp, const
     Table<N>::stage_fresh(lds, H.fresh);
     stage_nth(lds);
     constexpr bool EXTERNAL = POLICY == PK_POLICY_EXTERNAL;
-    if (live) { tb.load(S, t); tb.hands_this_step = (int)S.mid[t]; owed = S.owed[t] + (uint32_t)K; } else tb.blank();
+    if (live) { tb.load(S, t); tb.hands_this_step = (int)as_global(S.mid)[t]; owed = as_global(S.owed)[t] + (uint32_t)K; } else tb.blank();
     uint32_t steps = 0;
     bool alive = live;
     ActionRing ring;
@@ -125,11 +132,13 @@ __device__ __forceinline__ void rollout_body(const State *__restrict__ Sp, const
     bool ext_ok = true;
     if (EXTERNAL) {                                                                // game.py:648-651
         const uint32_t vm = tb.valid_mask(high_bet);
-        ext_action = live ? actions[t] : -1;
+        ext_action = live ? as_global(actions)[t] : -1;
         ext_ok = live && ext_action >= 0 && ext_action < PK_NUM_MOVES && ((vm >> ext_action) & 1);
         owed = ext_ok ? 1u : 0u;                                                   // (the host has flushed: nothing was owed)
         alive = ext_ok;
     }
+    uint32_t late = (live ? 1u : 0u) | (ext_ok ? 2u : 0u);   // the epilogue's lane predicates travel through the loop in ONE VGPR
+    if (EXTERNAL) asm volatile("" : "+v"(late));               // (as lane masks: an SGPR pair each, live across the loop; see env_step_body)
     // lanes that can work at all in this launch; the launch ends once more than `slack` of them have run out of work
     // (slack >= 64: never, i.e. run to completion)
     const int cap = __popcll(__ballot(live && (owed > 0 || tb.lstate == LS_END)));
@@ -199,16 +208,19 @@ __device__ __forceinline__ void rollout_body(const State *__restrict__ Sp, const
     // side pots restart from the unchanged committed bets), so the next launch redoes it together with its own arrivals.
     if (tb.lstate == LS_POT) { tb.lstate = LS_END; tb.evals -= (uint32_t)__popc((tb.st_called | tb.st_allin) & Table<N>::FULL); }
     if (EXTERNAL) {
-        if (live) {
-            if (ext_ok) {
+        asm volatile("" : "+v"(late));
+        const bool ext_ok_l = late & 2u;
+        if (late & 1u) {
+            const auto flags_out = as_global(ext->flags), terr_out = as_global(ext->terr);
+            if (ext_ok_l) {
                 tb.store(S, t);
                 tb.store_show(S.show, S.T, t, lds);
-                S.mid[t] = 0;
-                S.valid[t] = (uint8_t)tb.valid_mask(high_bet);
+                as_global(S.mid)[t] = 0;
+                as_global(S.valid)[t] = (uint8_t)tb.valid_mask(high_bet);
             }
-            const uint8_t te = ext_ok ? (uint8_t)tb.terr : (uint8_t)PK_TERR_INVALID_ACTION;
-            flags_out[t] = ext_ok ? (uint8_t)tb.flags : (uint8_t)0;                // :649-651: no mutation
-            S.terr[t] = te;
+            const uint8_t te = ext_ok_l ? (uint8_t)tb.terr : (uint8_t)PK_TERR_INVALID_ACTION;
+            flags_out[t] = ext_ok_l ? (uint8_t)tb.flags : (uint8_t)0;              // :649-651: no mutation
+            as_global(S.terr)[t] = te;
             if (terr_out) terr_out[t] = te;
         }
         PK_PROF(tb.prof.flush(S.prof);)
@@ -217,9 +229,10 @@ __device__ __forceinline__ void rollout_body(const State *__restrict__ Sp, const
     if (live) {
         tb.store(S, t);
         tb.store_show(S.show, S.T, t, lds);
-        S.owed[t] = owed; S.mid[t] = (uint32_t)tb.hands_this_step;
-        S.valid[t] = (uint8_t)tb.valid_mask(high_bet);
-        S.terr[t] = (uint8_t)((clear_terr ? 0 : S.terr[t]) | tb.terr | tb.seen);
+        as_global(S.owed)[t] = owed; as_global(S.mid)[t] = (uint32_t)tb.hands_this_step;
+        as_global(S.valid)[t] = (uint8_t)tb.valid_mask(high_bet);
+        const auto g_terr = as_global(S.terr);
+        g_terr[t] = (uint8_t)((clear_terr ? 0 : g_terr[t]) | tb.terr | tb.seen);
     }
     wave_add_counters(S, steps, tb.hands, tb.evals, tb.games);  // every lane takes part in the shuffles
     PK_PROF(tb.prof.flush(S.prof);)
@@ -238,8 +251,10 @@ __global__ void __launch_bounds__(PK_TABLE_BLOCK, 2) PK_ROLLOUT_ATTR k_rollout_a
 // Game.step (game.py:621-700) with the caller's actions, and the single-step form of the random-agent rollout (pk_rollout
 // with fused == 0: the state round-trips HBM every step): the same body with one betting pass per look at the parked lanes.
 template <int N>
-__global__ void __launch_bounds__(PK_TABLE_BLOCK, 2) k_step(const State *__restrict__ Sp, Hot H, const int32_t *actions, uint8_t *flags, uint8_t *terr, int park) {
-    rollout_body<N, false, PK_POLICY_EXTERNAL, 1>(Sp, H, 0, 0, park, PK_WAVE, 1, actions, flags, terr);
+__global__ void __launch_bounds__(PK_TABLE_BLOCK, 2) k_step(StepKernArgs) {
+    const StepKernArgs *ka = (const StepKernArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+    const Hot H = ka->H;
+    rollout_body<N, false, PK_POLICY_EXTERNAL, 1>(ka->Sp, H, 0, 0, ka->park, PK_WAVE, 1, ka->actions, ka);
 }
 template <int N>
 __global__ void __launch_bounds__(PK_TABLE_BLOCK, 2) k_rollout_single(const State *__restrict__ Sp, Hot H, int K, int auto_reset, int park, int slack, int clear_terr) {
@@ -272,11 +287,17 @@ __global__ void __launch_bounds__(PK_TABLE_BLOCK, PK_OCC_CAP) k_rollout_occ3_all
 
 // PokerGameEnv.reset: Game.reset() (:23), then opponents play until seat 0 is to act (:24-26); a game that ends before
 // seat 0 ever acts is reset again (:27).
+struct EnvResetKernArgs { const State *Sp; Hot H; const uint8_t *mask; uint64_t seatpol; int park; };   // = the kernarg segment (see EnvArgs)
 template <int N>
-__global__ void __launch_bounds__(PK_TABLE_BLOCK) k_env_reset(const State *__restrict__ Sp, Hot H, const uint8_t *mask, uint64_t seatpol, int park) {
-    const State &S = *Sp;
+__global__ void __launch_bounds__(PK_TABLE_BLOCK) k_env_reset(EnvResetKernArgs) {
+    const EnvResetKernArgs *ka = (const EnvResetKernArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+    const auto &S = *as_global(ka->Sp);
+    const Hot H = ka->H;
+    const uint64_t seatpol = ka->seatpol;
+    const int park = ka->park;
     __shared__ Lds<N> lds;
     const int t = blockIdx.x * H.tpb + threadIdx.x;
+    const auto mask = as_global(ka->mask);
     const bool live = (int)threadIdx.x < H.tpb && t < S.T && (!mask || mask[t < S.T ? t : 0]);
     const uint32_t table_id = H.table_id_base + (uint32_t)t;
     Table<N> tb;
@@ -284,6 +305,8 @@ __global__ void __launch_bounds__(PK_TABLE_BLOCK) k_env_reset(const State *__res
     ActionRng rng;
     double high_bet = 0.0;
     bool more = live, due_reset = live;
+    uint32_t late = live ? 1u : 0u;                      // (`live` for the epilogue, through the loop in a VGPR: see env_step_body)
+    asm volatile("" : "+v"(late));
     int budget = PK_ENV_STEP_CAP;  // every wave-uniform loop in this file has an exit all lanes reach
     auto retire = [&]() {          // an opponent's Game.step() has returned
         if (tb.stepped && tb.lstate == LS_DONE) {
@@ -295,7 +318,7 @@ __global__ void __launch_bounds__(PK_TABLE_BLOCK) k_env_reset(const State *__res
     };
     for (;;) {
         if (more && tb.lstate == LS_DONE) {                                        // no step in flight on this lane
-            if (due_reset) { tb.reset_state(H, 0); tb.deal(H, table_id); due_reset = false; }   // :23 / :27
+            if (due_reset) { tb.reset_state(ka->H, 0); tb.deal(H, table_id); due_reset = false; }   // :23 / :27 (start credits: read from the argument block here)
             more = tb.active != 0;                                                 // :24
             if (more) {
                 uint32_t vm = tb.valid_mask(high_bet);
@@ -312,11 +335,12 @@ __global__ void __launch_bounds__(PK_TABLE_BLOCK) k_env_reset(const State *__res
             retire();
         }
     }
-    if (live) {
+    asm volatile("" : "+v"(late));
+    if (late) {
         tb.store(S, t);
         tb.store_show(S.show, S.T, t, lds);
-        S.valid[t] = (uint8_t)tb.valid_mask(high_bet);
-        S.terr[t] = (uint8_t)tb.terr;
+        as_global(S.valid)[t] = (uint8_t)tb.valid_mask(high_bet);
+        as_global(S.terr)[t] = (uint8_t)tb.terr;
     }
 }
 
@@ -352,7 +376,7 @@ constexpr uint16_t env_transition(int idx) {
     if (!live_phase) return (uint16_t)phase;                                   // (no Game.step can return in PH_RESET / PH_END)
     return (uint16_t)(ph | (done_set << 3) | (done_val << 4) | (hand_set << 5) | (hand_val << 6) | (take_rew << 7) | (fin << 8));
 }
-struct EnvTransitions {
+struct alignas(16) EnvTransitions {   // (copied into LDS as 32-bit words)
     uint16_t e[256];
     constexpr EnvTransitions() : e{} { for (int i = 0; i < 256; ++i) e[i] = env_transition(i); }
 };
@@ -378,25 +402,54 @@ __device__ __constant__ const EnvTransitions g_env_transitions{};
 // to act inside a PokerGameEnv.step / .reset, the table YIELDS (ready[t] = 2, who[t] = the seat, obs row = that seat's
 // StateView), its env call stays in flight exactly like a step that ran out of passes, and the next launch takes
 // actions[t] as that seat's action.  reset_req[t] != 0 starts PokerGameEnv.reset() on that table instead of a step.
+// First 8 bytes of a packed observation row (pokerl_hip.h PK_OBS_PACKED_BYTES): seat, turn, valid mask, hole cards, flop.
+__device__ __forceinline__ uint64_t obs_packed_header0(uint32_t who, uint32_t turn, uint32_t vmask, uint32_t h0, uint32_t h1, uint32_t c0, uint32_t c1, uint32_t c2) {
+    return (uint64_t)(who | (turn << 8) | ((vmask & 0x7fu) << 16) | (h0 << 24)) | ((uint64_t)(h1 | (c0 << 8) | (c1 << 16) | (c2 << 24)) << 32);
+}
+
+// The arguments of the PokerGameEnv.step kernels as ONE block, read through the kernarg segment pointer WHERE A FIELD IS USED:
+// formal kernel parameters are all s_load-ed in the entry block and then live across the whole step loop -- the seven output
+// pointers, needed only after it, cost k_env_step<6> 14 SGPRs there (31 spilled SGPRs in round 3).  A load the kernel writes
+// itself stays where it is written.
+struct EnvArgs {
+    const int32_t *actions;      // [T] seat 0's action per table (or the yielded seat's, MULTI); NULL: seat 0 plays `seat0_policy`
+    const uint8_t *reset_req;    // [T] MULTI: != 0 starts PokerGameEnv.reset() on that table; may be NULL
+    double *reward; uint8_t *done, *hand, *terr;   // [T] outputs of a returned PokerGameEnv.step (game_env.py:53)
+    double *obs;                 // [T][PK_OBS_DIM] or NULL
+    uint8_t *obs_packed;         // [T][PK_OBS_PACKED_BYTES] or NULL (pk_get_obs_packed's row, written from registers)
+    uint8_t *ready, *who;        // [T] ASYNC / MULTI status bytes
+    uint64_t seatpol;            // one policy nibble per seat
+    int seat0_policy, auto_reset, park, max_passes, abandon, t0, tend;   // [t0, tend): the sub-range of the handle this launch serves
+};
+struct EnvKernArgs { const State *Sp; Hot H; EnvArgs A; };   // the kernels' single formal parameter = the layout of their kernarg segment
+static_assert(std::is_trivially_copyable<EnvKernArgs>::value, "kernel argument block");
+
 template <int N, bool ASYNC, bool MULTI>
-__device__ __forceinline__ void env_step_body(const State *__restrict__ Sp, const Hot &H, const int32_t *actions, int seat0_policy, uint64_t seatpol, int auto_reset, double *reward, uint8_t *done_out, uint8_t *hand_out, uint8_t *terr, double *obs, int park, uint8_t *ready, int max_passes, const uint8_t *reset_req, uint8_t *who_out, int abandon, int t0 = 0, int tend = 0x7fffffff) {
+__device__ __forceinline__ void env_step_body() {
     static_assert(ASYNC || !MULTI, "yielding to the caller needs the in-flight context of the asynchronous form");
-    const State &S = *Sp;
+    const EnvKernArgs *ka = (const EnvKernArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+    const EnvArgs &A = ka->A;                                    // (fields are loaded at their uses)
+    const auto &S = *as_global(ka->Sp);
+    const Hot H = ka->H;                                         // the loop's scalars: loaded once, here
+    const auto actions = as_global(A.actions);
+    const int seat0_policy = A.seat0_policy, auto_reset = A.auto_reset, park = A.park, max_passes = A.max_passes;
+    const uint64_t seatpol = A.seatpol;
     __shared__ Lds<N> lds;
-    const int t = t0 + blockIdx.x * H.tpb + threadIdx.x;        // [t0, tend): the sub-range of the handle this launch serves
-    const bool live = (int)threadIdx.x < H.tpb && t < S.T && t < tend;
+    const int t = A.t0 + blockIdx.x * H.tpb + threadIdx.x;      // [t0, tend): the sub-range of the handle this launch serves
+    const bool live = (int)threadIdx.x < H.tpb && t < S.T && t < A.tend;
     const uint32_t table_id = H.table_id_base + (uint32_t)t;
     Table<N> tb;
     PK_PROF(tb.prof.start();)
     if (live) tb.load(S, t); else tb.blank();
     uint64_t ctx = 0;                                          // != 0: a PokerGameEnv.step of this table is in flight
-    if (ASYNC && live) ctx = S.env_ctx[t];
+    if (ASYNC && live) ctx = as_global(S.env_ctx)[t];
+    const auto reset_req = as_global(A.reset_req);
     const bool want_reset = MULTI && live && reset_req && reset_req[t];
     if (want_reset) { ctx = 0; tb.idle(); }                    // PokerGameEnv.reset(): whatever was in flight is dropped
     const bool carried = ctx != 0;
     bool yielded = MULTI && carried && ((ctx >> 6) & 1);       // waiting for the caller's action for seat tb.active
     ActionRing ring;
-    __shared__ uint16_t trans[256];                            // env_transition() of every input (see above)
+    __shared__ alignas(16) uint16_t trans[256];                // env_transition() of every input (see above); copied as 32-bit words
     for (int i = threadIdx.x & (PK_WAVE - 1); i < 128; i += PK_WAVE)
         reinterpret_cast<uint32_t *>(trans)[i] = reinterpret_cast<const uint32_t *>(g_env_transitions.e)[i];
     stage_nth(lds);                                            // (its barrier covers the table above)
@@ -416,11 +469,16 @@ __device__ __forceinline__ void env_step_body(const State *__restrict__ Sp, cons
     if (ASYNC && carried) {
         phase = (int)(ctx >> 1) & 7; done = (ctx >> 4) & 1; hand = (ctx >> 5) & 1; terr_step = (uint32_t)(ctx >> 8) & 0xff;
         budget = (int)((ctx >> 16) & 0xffff) - 1; budget_reset = (int)((ctx >> 32) & 0xffff) - 1;
-        rew = S.env_rew[t];
-        tb.hands_this_step = (int)S.mid[t];
+        rew = as_global(S.env_rew)[t];
+        tb.hands_this_step = (int)as_global(S.mid)[t];
     }
     bool have_ext = MULTI && yielded && action_ok;             // the yielded seat's action has arrived and is valid
     const bool ext_invalid = MULTI && yielded && !action_ok;   // ... is invalid: the table is untouched and keeps waiting
+    // What only the epilogue needs of the lane predicates above travels through the loop as bits of ONE VGPR: kept as lane masks
+    // they are an SGPR pair each, live across the whole loop (a dozen of k_env_step<6>'s 31 spilled SGPRs in round 3).  The empty
+    // asm keeps the optimiser from seeing through the packing.
+    uint32_t late = (live ? 1u : 0u) | (ok ? 2u : 0u) | (carried ? 4u : 0u) | (skip ? 8u : 0u) | (ext_invalid ? 16u : 0u);
+    asm volatile("" : "+v"(late));
     yielded = yielded && !have_ext;
     int passes = 0;
     const uint32_t caps = PK_TERR_HAND_CAP | PK_TERR_ENV_CAP;
@@ -478,12 +536,12 @@ __device__ __forceinline__ void env_step_body(const State *__restrict__ Sp, cons
         const bool last = closing && !__any(tb.stepped && tb.hands_this_step >= PK_ENV_ROLLING);   // (parked, or between a deal and its first seat)
         PK_PROF(tb.prof.lap(PF_CURSOR);)
         if (!closing && phase == PH_RESET && tb.lstate == LS_DONE) {               // game_env.py:23 / :27
-            tb.reset_state(H, 0); tb.deal(H, table_id);
+            tb.reset_state(ka->H, 0); tb.deal(H, table_id);   // (the start credits: read from the argument block here, not kept in SGPRs)
             phase = tb.active != 0 ? PH_RESET_PLAY : PH_END;                       // :24
         }
         PK_PROF(tb.prof.lap(14);)                   // (diagnostic build: slot 14 = the episode-reset branch, 15 = the action draws,
         if (draws) __builtin_amdgcn_s_waitcnt(0);   // as in k_rollout: no stray full wait behind the passes' LDS reads
-        if (draws && !closing) ring.ensure(lds, H, table_id, tb.step_serial, live && phase != PH_END && !yielded, EP);
+        if (draws && !closing) ring.ensure(lds, H, table_id, tb.step_serial, phase != PH_END && !yielded, EP);   // (a lane without a table: PH_END)
         PK_PROF(tb.prof.lap(15);)                   //  PF_CURSOR = load + census between the rounds)
         int made = 0;
 #pragma unroll
@@ -527,13 +585,18 @@ __device__ __forceinline__ void env_step_body(const State *__restrict__ Sp, cons
         }
     }
     PK_PROF(tb.prof.lap(PF_OTHER); tb.prof.flush(S.prof);)
-    if (!live) return;
-    if (MULTI && skip) {                                       // nothing ran, nothing is written but the two status bytes
+    asm volatile("" : "+v"(late));
+    const bool live_l = late & 1u, ok_l = late & 2u, carried_l = late & 4u, skip_l = late & 8u, ext_invalid_l = late & 16u;
+    if (!live_l) return;
+    // ---- outputs: the pointers are loaded from the argument block only now
+    const auto ready = as_global(ASYNC ? A.ready : nullptr), who_out = as_global(MULTI ? A.who : nullptr);
+    const auto terr = as_global(A.terr);
+    if (MULTI && skip_l) {                                     // nothing ran, nothing is written but the two status bytes
         if (ready) ready[t] = 3;
         if (who_out) who_out[t] = (uint8_t)tb.active;
         return;
     }
-    if (ok) {
+    if (ok_l) {
         tb.store(S, t);
         tb.store_show(S.show, S.T, t, lds);
     }
@@ -542,28 +605,31 @@ __device__ __forceinline__ void env_step_body(const State *__restrict__ Sp, cons
     if (ASYNC) {
         // pk_env_end_multi_d: after a drain only yielded tables (between two Game.steps) are still in flight; their env
         // call is abandoned and the table is an ordinary idle table again
-        const bool keep = !returned && !(MULTI && abandon);
-        S.env_ctx[t] = keep ? (1ull | ((uint64_t)phase << 1) | ((uint64_t)done << 4) | ((uint64_t)hand << 5) | ((uint64_t)(yielded ? 1 : 0) << 6) |
-                               ((uint64_t)(terr_step & 0xff) << 8) | ((uint64_t)(budget + 1) << 16) | ((uint64_t)(budget_reset + 1) << 32))
-                            : 0ull;
-        S.mid[t] = keep ? (uint32_t)tb.hands_this_step : 0u;
-        S.valid[t] = (uint8_t)vmask;
+        const bool keep = !returned && !(MULTI && A.abandon);
+        as_global(S.env_ctx)[t] = keep ? (1ull | ((uint64_t)phase << 1) | ((uint64_t)done << 4) | ((uint64_t)hand << 5) | ((uint64_t)(yielded ? 1 : 0) << 6) |
+                                          ((uint64_t)(terr_step & 0xff) << 8) | ((uint64_t)(budget + 1) << 16) | ((uint64_t)(budget_reset + 1) << 32))
+                                       : 0ull;
+        as_global(S.mid)[t] = keep ? (uint32_t)tb.hands_this_step : 0u;
+        as_global(S.valid)[t] = (uint8_t)vmask;
         if (ready) ready[t] = returned ? 1 : ((MULTI && yielded) ? 2 : 0);
         if (MULTI && who_out) who_out[t] = (uint8_t)tb.active;
         if (!returned) {
-            S.env_rew[t] = rew;
+            as_global(S.env_rew)[t] = rew;
             if (!(MULTI && yielded) || !terr) return;
-            terr[t] = ext_invalid ? (uint8_t)PK_TERR_INVALID_ACTION : (uint8_t)0;   // the yielded seat's action was refused / is awaited
+            terr[t] = ext_invalid_l ? (uint8_t)PK_TERR_INVALID_ACTION : (uint8_t)0;   // the yielded seat's action was refused / is awaited
         }
     }
     if (returned) {
-        const uint32_t te = ok ? (terr_step | tb.terr) : (uint32_t)PK_TERR_INVALID_ACTION;
-        reward[t] = ok ? rew : 0.0; done_out[t] = ok && done; hand_out[t] = ok && hand;  // :53
-        if (ok) S.valid[t] = (uint8_t)vmask;
-        S.terr[t] = (uint8_t)te; terr[t] = (uint8_t)te;
+        const uint32_t te = ok_l ? (terr_step | tb.terr) : (uint32_t)PK_TERR_INVALID_ACTION;
+        as_global(A.reward)[t] = ok_l ? rew : 0.0; as_global(A.done)[t] = ok_l && done; as_global(A.hand)[t] = ok_l && hand;  // :53
+        if (ok_l) as_global(S.valid)[t] = (uint8_t)vmask;
+        // (an idle table the abandoning launch of pk_env_end_multi_d merely passes over keeps its error byte: it made no call)
+        if (!(MULTI && A.abandon && !carried_l)) as_global(S.terr)[t] = (uint8_t)te;
+        terr[t] = (uint8_t)te;
     }
+    const auto obs = as_global(A.obs);
     if (obs) {  // Game.StateView(player to act), game.py:117-131, from registers (same row k_obs builds from HBM)
-        double *o = obs + (size_t)t * PK_OBS_DIM(N);
+        const auto o = obs + (size_t)t * PK_OBS_DIM(N);
         const int who = tb.active;
         o[0] = who; o[1] = tb.turn; o[2] = tb.min_raise;
         for (int a = 0; a < PK_NUM_MOVES; ++a) o[3 + a] = (vmask >> a) & 1;
@@ -573,20 +639,29 @@ __device__ __forceinline__ void env_step_body(const State *__restrict__ Sp, cons
         PK_FOR(c, 5) o[12 + c] = (tb.turn != 0 && c < tb.turn + 2) ? (double)tb.card(c) : -1.0; PK_END   // game.py:278
         PK_FOR(p, N) o[17 + p] = tb.credits[p]; o[17 + N + p] = tb.bets[p]; o[17 + 2 * N + p] = tb.pending[p]; PK_END
     }
+    const auto obs_packed = as_global(A.obs_packed);
+    if (obs_packed) {  // the same row, compact (layout: pokerl_hip.h PK_OBS_PACKED_BYTES): 16 header bytes + (3N+1) f64
+        const auto o = (PK_GLOBAL uint64_t *)(obs_packed + (size_t)t * PK_OBS_PACKED_BYTES(N));
+        const uint32_t who = (uint32_t)tb.active;
+        uint32_t h0 = 0, h1 = 0;
+        PK_FOR(p, N) h0 = (who == (uint32_t)p) ? tb.card(5 + 2 * p) : h0; h1 = (who == (uint32_t)p) ? tb.card(6 + 2 * p) : h1; PK_END
+        uint32_t cc[5];
+        PK_FOR(c, 5) cc[c] = (tb.turn != 0 && c < tb.turn + 2) ? tb.card(c) : 0xffu; PK_END
+        o[0] = obs_packed_header0(who, (uint32_t)tb.turn, vmask, h0, h1, cc[0], cc[1], cc[2]);
+        o[1] = (uint64_t)cc[3] | ((uint64_t)cc[4] << 8);
+        const auto m = (PK_GLOBAL double *)(o + 2);
+        m[0] = tb.min_raise;
+        PK_FOR(p, N) m[1 + p] = tb.credits[p]; m[1 + N + p] = tb.bets[p]; m[1 + 2 * N + p] = tb.pending[p]; PK_END
+    }
 }
 template <int N>
-__global__ void __launch_bounds__(PK_TABLE_BLOCK) k_env_step(const State *__restrict__ Sp, Hot H, const int32_t *actions, int seat0_policy, uint64_t seatpol, int auto_reset, double *reward, uint8_t *done_out, uint8_t *hand_out, uint8_t *terr, double *obs, int park) {
-    env_step_body<N, false, false>(Sp, H, actions, seat0_policy, seatpol, auto_reset, reward, done_out, hand_out, terr, obs, park, nullptr, 0, nullptr, nullptr, 0);
-}
+__global__ void __launch_bounds__(PK_TABLE_BLOCK) k_env_step(EnvKernArgs) { env_step_body<N, false, false>(); }
 template <int N>
-__global__ void __launch_bounds__(PK_TABLE_BLOCK, (N <= 6 ? 3 : 2)) k_env_step_async(const State *__restrict__ Sp, Hot H, const int32_t *actions, int seat0_policy, uint64_t seatpol, int auto_reset, double *reward, uint8_t *done_out, uint8_t *hand_out, uint8_t *terr, double *obs, int park, uint8_t *ready, int max_passes, int t0, int tend) {
-    env_step_body<N, true, false>(Sp, H, actions, seat0_policy, seatpol, auto_reset, reward, done_out, hand_out, terr, obs, park, ready, max_passes, nullptr, nullptr, 0, t0, tend);
-}
+__global__ void __launch_bounds__(PK_TABLE_BLOCK, (N <= 6 ? 3 : 2)) k_env_step_async(EnvKernArgs) { env_step_body<N, true, false>(); }
 template <int N>
-__global__ void __launch_bounds__(PK_TABLE_BLOCK, 2) k_env_step_multi(const State *__restrict__ Sp, Hot H, const int32_t *actions, int seat0_policy, uint64_t seatpol, int auto_reset, double *reward, uint8_t *done_out, uint8_t *hand_out, uint8_t *terr, double *obs, int park, uint8_t *ready, int max_passes, const uint8_t *reset_req, uint8_t *who_out, int abandon) {
-    env_step_body<N, true, true>(Sp, H, actions, seat0_policy, seatpol, auto_reset, reward, done_out, hand_out, terr, obs, park, ready, max_passes, reset_req, who_out, abandon);
-}
+__global__ void __launch_bounds__(PK_TABLE_BLOCK, 2) k_env_step_multi(EnvKernArgs) { env_step_body<N, true, true>(); }
 
+#ifndef PK_TABLES_ONLY
 // ---- exports: device-side conversion from the SoA/bitmask layout to the reference's table-major arrays
 __global__ void k_export_f64(const double *src, int T, int N, double *out) {  // [N][T] -> [T][N]
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -681,6 +756,37 @@ __global__ void k_obs(State S, int N, int player, double *out) {
         o[17 + N + p] = S.bets[(size_t)p * T + t];
         o[17 + 2 * N + p] = S.pending[(size_t)p * T + t];
     }
+}
+// The same row as k_obs, compact: 16 header bytes (seat, turn, valid-mask bits, 2 hole cards, 5 community cards with 0xFF for a
+// card not yet visible, 6 zero bytes) + (3N+1) f64 (minimum_raise_value, credits, bets, pending_bets): pokerl_hip.h.
+__global__ void k_obs_packed(State S, int N, int player, uint8_t *out) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= S.T) return;
+    const int T = S.T;
+    uint64_t *o = reinterpret_cast<uint64_t *>(out + (size_t)t * PK_OBS_PACKED_BYTES(N));
+    uint32_t cur = S.cursors[t];
+    int active = cur & 0xf, turn = (cur >> 16) & 0xf;
+    const int who = player < 0 ? active : player;
+    const uint32_t vm = player < 0 ? S.valid[t] : valid_bits_of(S, t, N, who);
+    auto card = [&](int c) { return (uint32_t)((S.cards[(size_t)(c >> 2) * T + t] >> (8 * (c & 3))) & 0xff); };
+    auto comm = [&](int c) { return (turn != 0 && c < turn + 2) ? card(c) : 0xffu; };
+    o[0] = obs_packed_header0((uint32_t)who, (uint32_t)turn, vm, card(5 + 2 * who), card(6 + 2 * who), comm(0), comm(1), comm(2));
+    o[1] = (uint64_t)comm(3) | ((uint64_t)comm(4) << 8);
+    double *m = reinterpret_cast<double *>(o + 2);
+    m[0] = S.min_raise[t];
+    for (int p = 0; p < N; ++p) {
+        m[1 + p] = S.credits[(size_t)p * T + t];
+        m[1 + N + p] = S.bets[(size_t)p * T + t];
+        m[1 + 2 * N + p] = S.pending[(size_t)p * T + t];
+    }
+}
+// Game.step's precondition (game.py:648-651) over a batch: the lowest table index whose action is not in its active player's mask.
+__global__ void k_check_actions(const uint8_t *valid, const int32_t *actions, int T, int32_t *first_bad) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    const int a = actions[t];
+    const bool ok = a >= 0 && a < PK_NUM_MOVES && ((valid[t] >> a) & 1);
+    if (!ok) atomicMin(first_bad, t);
 }
 // Game.pot (np.sum(bets) in numpy's association order, game.py:281-284 + SURVEY A.5) / Game.high_bet
 // (np.max(pending_bets), game.py:287-290) per table; Game.game_over (game.py:317-320).
@@ -845,3 +951,28 @@ __global__ void k_eval7_prefix(int a, int b, int fast, uint32_t count, uint32_t 
     } else out[i] = fast ? eval7_distinct(h) : eval_hand(h, 7, nk);
 }
 
+#endif  // PK_TABLES_ONLY
+
+// ================================================================================================ instantiation lists
+// The table kernels are compiled once per seat count in translation units of their own (pk_tables.hip with -DPK_SEATS=N:
+// explicit instantiations), in parallel; pk_api.hip declares them `extern template` and launches them.
+#define PK_ROLLOUT_SIG (const State *__restrict__, Hot, int, int, int, int, int)
+#define PK_TABLE_KERNELS(X, N)                                               \
+    X(N, k_reset, (State, Hot, const uint8_t *, int))                        \
+    X(N, k_make_fresh, (Hot, Fresh *))                                       \
+    X(N, k_pick, (State, Hot, int, int32_t *))                               \
+    X(N, k_rollout, PK_ROLLOUT_SIG)                                          \
+    X(N, k_rollout_allin, PK_ROLLOUT_SIG)                                    \
+    X(N, k_rollout_call, PK_ROLLOUT_SIG)                                     \
+    X(N, k_rollout_single, PK_ROLLOUT_SIG)                                   \
+    X(N, k_step, (StepKernArgs))                                             \
+    X(N, k_env_reset, (EnvResetKernArgs))                                    \
+    X(N, k_env_step, (EnvKernArgs))                                          \
+    X(N, k_env_step_async, (EnvKernArgs))                                    \
+    X(N, k_env_step_multi, (EnvKernArgs))
+// ... and the ones that exist up to ten seats only (the 168-register variants: beyond ten seats they would spill)
+#define PK_TABLE_KERNELS_LE10(X, N)                                          \
+    X(N, k_rollout_occ3, PK_ROLLOUT_SIG)                                     \
+    X(N, k_rollout_occ3_allin, PK_ROLLOUT_SIG)
+#define PK_INSTANTIATE_KERNEL(N, name, sig) template __global__ void name<N> sig;
+#define PK_DECLARE_KERNEL(N, name, sig) extern template __global__ void name<N> sig;

@@ -60,6 +60,9 @@ class VecPokerGameEnv:
                 b.free()
             setattr(self, name, {})
         self.game.close()
+        for b in (getattr(self, '_pin', None) or {}).values():
+            b.free()
+        self._pin = {}
 
     def __del__(self):
         try:
@@ -114,8 +117,16 @@ class VecPokerGameEnv:
                     if len(idx):
                         acts[idx] = self._call_agent(self.agents[seat], obs[idx], idx)
                 reset_ptr = None
-        finally:
-            L.check(lib.pk_env_end_multi_d(h), h)     # nothing is left in flight: getters and the other entry points work again
+        except BaseException:
+            # (a host agent's invalid action, or an exception it raised: the env calls still in flight are abandoned -- those
+            #  tables stand between two Game.steps of an unfinished PokerGameEnv.step, whose reward / done are lost: reset() the
+            #  env before using it again.  The original exception must not be masked by a failure of the clean-up.)
+            try:
+                L.check(lib.pk_env_end_multi_d(h), h)
+            except Exception:
+                pass
+            raise
+        L.check(lib.pk_env_end_multi_d(h), h)         # nothing is left in flight: getters and the other entry points work again
         return (b['rew'].download(np.float64, T), b['done'].download(np.uint8, T), b['hand'].download(np.uint8, T),
                 b['terr'].download(np.uint8, T))
 
@@ -133,15 +144,49 @@ class VecPokerGameEnv:
 
     def check_actions(self, actions, table_offset=0):
         """Raises the reference's ValueError (game.py:649-651) if any table's action is not valid for its active player;
-        nothing is mutated."""
+        nothing is mutated.  Checked on the device (pk_check_actions): one upload, one small kernel, four bytes back."""
+        self.game.check_actions(actions, table_offset)
+
+    # ------------------------------------------------------------------ host-array fast path (pinned buffers, two halves)
+    def send(self, actions, obs='packed', auto_reset=False, strict=False):
+        """First half of a PokerGameEnv.step through host arrays at PCIe line rate (pk_env_step_begin): uploads the actions,
+        launches the step and queues the copies of reward / done / hand / terr and of the observation rows -- obs='packed'
+        (state_view.packed_dtype rows, 168 B per table at six seats), 'dense' (f64 [T, PK_OBS_DIM], 280 B) or None -- into
+        PINNED arrays this env keeps and reuses (so nothing here blocks, and another env's send / the caller's own work
+        overlaps with the copies).  recv() completes it.  Needs ONE in-kernel policy for all opponents."""
+        from .hipmem import pinned_empty
+        from .state_view import packed_dtype
         g = self.game
+        if self._opp_policy is None:
+            raise ValueError('send / recv need ONE in-kernel policy for all opponents; per-seat / host agents: step()')
+        if obs not in ('packed', 'dense', None):
+            raise ValueError("obs: 'packed', 'dense' or None")
+        T, n = g.num_tables, g.num_players
+        if not getattr(self, '_pin', None):
+            self._pin = dict(act=pinned_empty(T, np.int32), rew=pinned_empty(T, np.float64), done=pinned_empty(T, np.uint8),
+                             hand=pinned_empty(T, np.uint8), terr=pinned_empty(T, np.uint8))
+        b = self._pin
+        if obs == 'packed' and 'packed' not in b:
+            b['packed'] = pinned_empty(T, packed_dtype(n))
+        if obs == 'dense' and 'dense' not in b:
+            b['dense'] = pinned_empty((T, 17 + 3 * n), np.float64)
         a = g._actions(actions)
-        valid = g.get_valid_actions()[0]
-        ok = (a >= 0) & (a < valid.shape[1])
-        ok[ok] = valid[np.nonzero(ok)[0], a[ok]] != 0
-        if not ok.all():
-            t = int(np.argmin(ok))
-            raise ValueError('Player %d invalid move: `%d` (table %d)' % (int(g.active_player[t]), int(a[t]), t + table_offset))
+        if strict:
+            self.check_actions(a)
+        b['act'].array[:] = a
+        L.check(g._lib.pk_env_step_begin(g._h, L.ptr(b['act'].array), self._opp_policy, 1 if auto_reset else 0, L.ptr(b['rew'].array),
+                                         L.ptr(b['done'].array), L.ptr(b['hand'].array), L.ptr(b['terr'].array),
+                                         L.ptr(b['dense'].array) if obs == 'dense' else None,
+                                         L.ptr(b['packed'].array) if obs == 'packed' else None), g._h)
+        self._sent = obs
+
+    def recv(self):
+        """Second half: waits for the copies send() queued and returns (obs, reward, done, hand, terr) -- VIEWS of the env's
+        pinned arrays, overwritten by the next send(); copy what must outlive it.  obs is None / packed rows / dense rows."""
+        g, b = self.game, self._pin
+        L.check(g._lib.pk_env_step_end(g._h), g._h)
+        obs = None if self._sent is None else b[self._sent].array
+        return obs, b['rew'].array, b['done'].array.view(np.bool_), b['hand'].array.view(np.bool_), b['terr'].array
 
     def step(self, actions, strict=True):
         """game_env.py:31-53: returns (obs, reward f64[T], done bool[T], hand bool[T]) -- the reference's 4-tuple.
@@ -244,21 +289,50 @@ class VecPokerGameEnvPool:
     `envs[b]` is an ordinary VecPokerGameEnv over tables `slices[b]`; reset() / step() below are the synchronous
     convenience forms over the whole pool, the asynchronous device-pointer calls are made per batch (envs[b].step_async_d)."""
 
-    def __init__(self, agents=Policy.RANDOM, num_tables=1, num_batches=4, **game_config):
+    def __init__(self, agents=Policy.RANDOM, num_tables=1, num_batches=4, devices=None, **game_config):
+        """devices: None -- every batch on game_config['device'] (default 0) -- or a list with one device index per batch
+        (then num_batches = len(devices)): ONE process driving several GPUs, SURVEY 8e's single-process form.  The batches'
+        calls are made from one Python thread per batch (ctypes releases the GIL for the duration of a library call), so
+        the devices -- or the streams of one device -- work at the same time.  Tables are sharded as pokerl_amd.shard_tables
+        does for ranks: contiguous blocks, global table ids."""
         base = int(game_config.pop('table_id_base', 0))
-        num_batches = max(1, min(int(num_batches), int(num_tables)))
-        per = -(-int(num_tables) // num_batches)
-        self.slices = [slice(b * per, min(int(num_tables), (b + 1) * per)) for b in range(num_batches)]
-        self.slices = [s for s in self.slices if s.stop > s.start]
-        self.envs = [VecPokerGameEnv(agents, num_tables=s.stop - s.start, table_id_base=base + s.start, **game_config)
-                     for s in self.slices]
+        if devices is not None:
+            game_config.pop('device', None)
+        self.slices, self.devices = self.plan(num_tables, num_batches, devices, int(game_config.get('device', 0)))
+        self.envs = [VecPokerGameEnv(agents, num_tables=s.stop - s.start, table_id_base=base + s.start,
+                                     **dict(game_config, device=d))
+                     for s, d in zip(self.slices, self.devices)]
         self.num_tables = int(num_tables)
+        self._pool = None
+
+    @staticmethod
+    def plan(num_tables, num_batches=4, devices=None, default_device=0):
+        """(slices, devices) of the pool's batches: contiguous blocks of the tables as pokerl_amd.shard_tables cuts them for
+        ranks, one per entry of `devices` (or num_batches of them on default_device); empty blocks are dropped."""
+        from .sharding import shard_tables
+        if devices is not None:
+            devices = [int(d) for d in devices]
+            num_batches = len(devices)
+        num_batches = max(1, min(int(num_batches), int(num_tables)))
+        shards = [shard_tables(int(num_tables), b, num_batches) for b in range(num_batches)]
+        slices = [slice(start, start + n) for n, start in shards if n > 0]
+        devs = list(devices[:len(slices)]) if devices is not None else [int(default_device)] * len(slices)
+        return slices, devs
 
     def __len__(self):
         return len(self.envs)
 
+    def _map(self, fn, *iterables):
+        """fn over the batches, one thread per batch (a single batch: inline)."""
+        if len(self.envs) == 1:
+            return [fn(*args) for args in zip(*iterables)]
+        if self._pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._pool = ThreadPoolExecutor(len(self.envs))
+        return list(self._pool.map(fn, *iterables))
+
     def reset(self):
-        return np.concatenate([e.reset() for e in self.envs])
+        return np.concatenate(self._map(lambda e: e.reset(), self.envs))
 
     def step(self, actions, strict=True):
         """PokerGameEnv.step on every table of the pool.  strict: every batch is checked BEFORE any is stepped, so that an
@@ -267,13 +341,22 @@ class VecPokerGameEnvPool:
         if strict:
             for e, s in zip(self.envs, self.slices):
                 e.check_actions(a[s], table_offset=s.start)
-        outs = [e.step(a[s], strict=False) for e, s in zip(self.envs, self.slices)]
+        outs = self._map(lambda e, s: e.step(a[s], strict=False), self.envs, self.slices)
         cat = tuple(np.concatenate([o[i] for o in outs]) for i in range(5))
         if not strict:
             return cat
         if cat[4].any():
             raise L.PokerlHipError('table error bits %s' % np.unique(cat[4]))
         return cat[:4]
+
+    def step_pipelined(self, actions, obs='packed', auto_reset=False):
+        """The host-array fast path over the pool: send() on every batch, then recv() on every batch -- batch b+1's launch
+        and the other devices' work overlap with batch b's device-to-host copies.  Returns one (obs, reward, done, hand,
+        terr) tuple of pinned VIEWS per batch (see VecPokerGameEnv.recv): no concatenation, no copy."""
+        a = np.ascontiguousarray(np.broadcast_to(np.asarray(actions), (self.num_tables,)))
+        for e, s in zip(self.envs, self.slices):
+            e.send(a[s], obs=obs, auto_reset=auto_reset)
+        return [e.recv() for e in self.envs]
 
     def sync(self):
         for e in self.envs:
@@ -282,3 +365,6 @@ class VecPokerGameEnvPool:
     def close(self):
         for e in self.envs:
             e.close()
+        if self._pool is not None:
+            self._pool.shutdown()
+            self._pool = None

@@ -87,13 +87,7 @@ class VecGame:
         """
         a = self._actions(actions)
         if strict:
-            valid = self.get_valid_actions()[0]
-            ok = (a >= 0) & (a < PokerMoves.NUM_MOVES)
-            ok[ok] = valid[np.nonzero(ok)[0], a[ok]] != 0
-            if not ok.all():
-                t = int(np.argmin(ok))
-                name = PokerMoves.as_string[a[t]] if 0 <= a[t] < PokerMoves.NUM_MOVES else str(int(a[t]))
-                raise ValueError('Player %d invalid move: `%s` (table %d)' % (int(self.active_player[t]), name, t))
+            self.check_actions(a)
         flags = np.zeros(self.num_tables, np.uint8)
         terr = np.zeros(self.num_tables, np.uint8)
         rc = self._lib.pk_step(self._h, L.ptr(a), L.ptr(flags), L.ptr(terr))
@@ -106,6 +100,17 @@ class VecGame:
                 raise L.PokerlHipError('table error bits %s' % np.unique(terr))
             return out
         return out + (terr,)
+
+    def check_actions(self, actions, table_offset=0):
+        """Game.step's precondition (game.py:648-651) for the whole batch, checked on the device (pk_check_actions): raises
+        the reference's ValueError naming the first offending table; nothing is mutated."""
+        a = self._actions(actions)
+        bad = C.c_int32(-1)
+        L.check(self._lib.pk_check_actions(self._h, L.ptr(a), C.byref(bad)), self._h)
+        if bad.value >= 0:
+            t = bad.value
+            name = PokerMoves.as_string[a[t]] if 0 <= a[t] < PokerMoves.NUM_MOVES else str(int(a[t]))
+            raise ValueError('Player %d invalid move: `%s` (table %d)' % (int(self.active_player[t]), name, t + table_offset))
 
     def _seat(self, player):
         """None -> -1 (each table's active player); else a seat index valid for every table."""
@@ -291,12 +296,30 @@ class VecGame:
         L.check(self._lib.pk_get_game_over(self._h, L.ptr(out)), self._h)
         return out != 0
 
-    def observations_of(self, player=None):
+    def observations_of(self, player=None, out=None):
         """Dense `StateView(game, player)` rows (game.py:117-131), f64 [T, PK_OBS_DIM(N)]; layout in pokerl_hip.h.
-        player=None or 0: each table's active player (`player or game.active_player`, game.py:122)."""
+        player=None or 0: each table's active player (`player or game.active_player`, game.py:122).
+        out: a C-contiguous f64 [T, PK_OBS_DIM] array to fill (a pinned one -- pokerl_amd.pinned_empty -- copies at PCIe rate)."""
         seat = -1 if not player else self._seat(player)
-        out = np.zeros((self.num_tables, 17 + 3 * self.num_players), np.float64)
+        shape = (self.num_tables, 17 + 3 * self.num_players)
+        if out is None:
+            out = np.empty(shape, np.float64)
+        elif out.shape != shape or out.dtype != np.float64 or not out.flags.c_contiguous:
+            raise ValueError('out must be a C-contiguous f64 array of shape %s' % (shape,))
         L.check(self._lib.pk_get_obs(self._h, seat, L.ptr(out)), self._h)
+        return out
+
+    def observations_packed_of(self, player=None, out=None):
+        """The same rows in the compact form (pk_get_obs_packed: 16 header bytes + (3N+1) f64 per table, 168 B against 280 at six
+        seats) as a structured array [T] of state_view.packed_dtype(N); state_view.unpack_obs() gives the dense rows back."""
+        from .state_view import packed_dtype
+        seat = -1 if not player else self._seat(player)
+        dt = packed_dtype(self.num_players)
+        if out is None:
+            out = np.empty(self.num_tables, dt)
+        elif out.shape != (self.num_tables,) or out.dtype != dt or not out.flags.c_contiguous:
+            raise ValueError('out must be a C-contiguous array of packed_dtype(N) with one row per table')
+        L.check(self._lib.pk_get_obs_packed(self._h, seat, L.ptr(out)), self._h)
         return out
 
     observations = property(lambda self: self.observations_of(None))

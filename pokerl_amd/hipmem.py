@@ -55,6 +55,41 @@ class DeviceBuffer:
             pass
 
 
+class PinnedArray:
+    """Owner of a pinned host allocation (pk_host_alloc = hipHostMalloc); `.array` is a numpy view of it.  Copies between a
+    pinned array and the device run at PCIe line rate and hipMemcpyAsync does not block on them; the memory is released when
+    this object is collected or free()d (the views must not outlive it: keep the object, not just `.array`)."""
+
+    def __init__(self, shape, dtype):
+        from . import _lib as L
+        self._L = L
+        dtype = np.dtype(dtype)
+        n = int(np.prod(shape)) * dtype.itemsize
+        self.nbytes = max(n, 1)
+        self._p = C.c_void_p()
+        L.check(L.lib().pk_host_alloc(C.byref(self._p), C.c_size_t(self.nbytes)))
+        buf = (C.c_char * self.nbytes).from_address(self._p.value)
+        self.array = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+        self.array[...] = np.zeros((), dtype)
+
+    def free(self):
+        if self._p and self._p.value:
+            self.array = None
+            self._L.lib().pk_host_free(self._p)
+            self._p = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def pinned_empty(shape, dtype=np.float64):
+    """A PinnedArray (use `.array`); see there."""
+    return PinnedArray(shape, dtype)
+
+
 class DeviceEvent:
     """A hipEvent_t for timing a region of a stream: pass `.handle` to VecGame.record_event (which records it on the
     handle's stream after completing deferred work); elapsed_ms(start, stop) waits for `stop`."""

@@ -34,7 +34,14 @@ def gather_f64(game, field=3, dist=None, device_tensors=None):
     if use_gpu:
         from . import _lib as L
         dev = torch.device("cuda", game.device)
-        local = torch.zeros((cmax, n), dtype=torch.float64, device=dev)
+        # The send tensor is written by TWO streams: torch's current stream (the zero fill of the padding rows) and the
+        # handle's own non-blocking stream (k_export_f64), which have no implicit order.  So: only the padding is filled, and
+        # torch's stream is drained before the export is queued -- a fill landing after (or during) the export would zero
+        # the payoffs (round 3's torch.zeros over the whole tensor could) -- and the handle's stream before the collective.
+        local = torch.empty((cmax, n), dtype=torch.float64, device=dev)
+        if cmax > game.num_tables:
+            local[game.num_tables:].zero_()
+        torch.cuda.current_stream(dev).synchronize()
         L.check(game._lib.pk_get_f64_d(game._h, int(field), L.C.c_void_p(local.data_ptr())), game._h)
         game.sync()
     else:

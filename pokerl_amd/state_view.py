@@ -7,6 +7,35 @@ import numpy as np
 from .cards import card_id, card_rank, card_suit, card_value
 
 
+def packed_dtype(num_players):
+    """numpy structured dtype of ONE packed observation row (include/pokerl_hip.h PK_OBS_PACKED_BYTES): zero-copy field access
+    to what pk_get_obs_packed / the PokerGameEnv kernels write -- rows['credits'] is an f64 [T, N] view, and so on."""
+    n = int(num_players)
+    dt = np.dtype([('player', np.uint8), ('turn', np.uint8), ('valid_bits', np.uint8), ('player_cards', np.uint8, (2,)),
+                   ('community_cards', np.uint8, (5,)), ('_pad', np.uint8, (6,)), ('minimum_raise_value', np.float64),
+                   ('credits', np.float64, (n,)), ('bets', np.float64, (n,)), ('pending_bets', np.float64, (n,))])
+    assert dt.itemsize == 16 + 8 * (3 * n + 1)
+    return dt
+
+
+def unpack_obs(rows, num_players):
+    """Packed rows (structured array of packed_dtype, or raw bytes [T, PK_OBS_PACKED_BYTES]) -> the dense f64 rows
+    [T, PK_OBS_DIM] of pk_get_obs, value for value (0xFF community bytes become -1)."""
+    n = int(num_players)
+    r = np.asarray(rows)
+    if r.dtype != packed_dtype(n):
+        r = np.ascontiguousarray(r, np.uint8).reshape(-1, 16 + 8 * (3 * n + 1)).view(packed_dtype(n)).reshape(-1)
+    out = np.empty((r.shape[0], 17 + 3 * n), np.float64)
+    out[:, 0] = r['player']; out[:, 1] = r['turn']; out[:, 2] = r['minimum_raise_value']
+    out[:, 3:10] = (r['valid_bits'][:, None] >> np.arange(7, dtype=np.uint8)[None, :]) & 1
+    out[:, 10:12] = r['player_cards']
+    cc = r['community_cards'].astype(np.float64)
+    cc[r['community_cards'] == 0xFF] = -1.0
+    out[:, 12:17] = cc
+    out[:, 17:17 + n] = r['credits']; out[:, 17 + n:17 + 2 * n] = r['bets']; out[:, 17 + 2 * n:] = r['pending_bets']
+    return out
+
+
 class Card:
     """A playing card: `value` = (suit << 4) | rank0 (pokerl/cards.py:28-62)."""
     __slots__ = ("value",)

@@ -316,32 +316,80 @@ sys.path.insert(0, %r)
 import numpy as np
 import pokerl_amd
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29561")
-os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
-torch.cuda.set_device(0)
-dist.init_process_group("nccl", device_id=torch.device("cuda", 0))      # RCCL
-g = pokerl_amd.VecGame(3000, num_players=5, seed=9)
+rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+local = int(os.environ.get("LOCAL_RANK", str(rank)))
+torch.cuda.set_device(local)
+dist.init_process_group("nccl", device_id=torch.device("cuda", local), rank=rank, world_size=world)      # RCCL
+TOTAL = 3000 * world + 1                                                 # uneven shards: the padding rows are exercised
+n_local, base = pokerl_amd.shard_tables(TOTAL, rank, world)
+g = pokerl_amd.VecGame(n_local, num_players=5, seed=9, device=local, table_id_base=base)
 g.reset()
 g.rollout(200, 0)
-for field, want in ((3, g.payoffs), (0, g.credits)):
+# the job's tables in ONE handle on this rank's GPU: what every rank must receive (global table ids: same trajectories)
+whole = pokerl_amd.VecGame(TOTAL, num_players=5, seed=9, device=local)
+whole.reset()
+whole.rollout(200, 0)
+# a busy default stream right before the gather: the export on the handle's own stream must not race torch's work on the
+# send tensor (round 3: torch.zeros over the whole tensor could land after the export)
+busy = torch.randn(4096, 4096, device="cuda")
+for field, want in ((3, whole.payoffs), (0, whole.credits)):
+    for _ in range(8):
+        busy = busy @ busy * 1e-4
     got = pokerl_amd.gather_f64(g, field, dist)                          # pk_get_f64_d -> all_gather on the device
-    assert got.shape == want.shape and got.tobytes() == want.tobytes(), field
+    assert got.shape == want.shape and got.tobytes() == want.tobytes(), (rank, field)
+dist.barrier()
 dist.destroy_process_group()
-print("GATHER-OK")
+if rank == 0:
+    print("GATHER-OK world=%%d" %% world)
 '''
 
 
 def test_optional_payoff_gather_over_rccl(tmp_path):
     """north_star's optional RCCL gather of payoffs: the local block is exported on the device (pk_get_f64_d) into the send
-    tensor of an RCCL all-gather -- one rank here (a one-GPU box), the collective and the device path are the real ones."""
+    tensor of an RCCL all-gather.  One rank per visible GPU, at most 8 (a one-GPU box: one rank -- the collective and the
+    device path are the real ones; on a node the same test exercises N > 1), uneven shards, a busy default stream."""
     import os
     import subprocess
     import sys
-    pytest.importorskip("torch")
+    torch = pytest.importorskip("torch")
+    import pokerl_amd
+    world = max(1, min(pokerl_amd.device_count(), 8))
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "gather.py"
     script.write_text(GATHER_GPU % root)
-    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600, cwd=root)
-    assert out.returncode == 0 and "GATHER-OK" in out.stdout, (out.stdout[-2000:], out.stderr[-3000:])
+    if world == 1:
+        cmd = [sys.executable, str(script)]
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+               "--master-port", "29561", str(script)]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0 and ("GATHER-OK world=%d" % world) in out.stdout, (out.stdout[-2000:], out.stderr[-3000:])
+
+
+def test_pool_over_a_device_list_plays_the_single_handle_trajectories(O):
+    """VecPokerGameEnvPool(devices=[...]): SURVEY 8e's single-process form -- one handle and one Python thread per entry of
+    `devices` (here the one GPU twice; a node lists its eight), tables sharded like ranks.  The pool's tables play what one
+    handle holding all of them plays, through reset / step (threads) and through the pinned send / recv pipeline."""
+    import pokerl_amd
+    T, N = 1500, 4
+    cfg = dict(num_players=N, seed=5, table_id_base=100)
+    pool = pokerl_amd.VecPokerGameEnvPool(pokerl_amd.Policy.CALL, num_tables=T, devices=[0, 0, 0], **cfg)
+    one = pokerl_amd.VecPokerGameEnv(pokerl_amd.Policy.CALL, num_tables=T, **cfg)
+    assert len(pool) == 3 and pool.devices == [0, 0, 0] and [s.stop - s.start for s in pool.slices] == [500, 500, 500]
+    assert pool.reset().tobytes() == one.reset().tobytes()
+    for it in range(6):
+        acts = one.game.pick_actions(0)
+        a = pool.step(acts)
+        b = one.step(acts)
+        for x, y in zip(a, b):
+            assert np.asarray(x).tobytes() == np.asarray(y).tobytes(), it
+    acts = one.game.pick_actions(0)
+    outs = pool.step_pipelined(acts, obs='dense')
+    obs, rew, done, hand = one.step(acts)
+    assert np.concatenate([o[0] for o in outs]).tobytes() == obs.tobytes()
+    assert np.concatenate([o[1] for o in outs]).tobytes() == rew.tobytes()
+    assert np.array_equal(np.concatenate([o[2] for o in outs]), done)
+    pool.close(); one.close()
 
 
 def test_single_table_drop_in_reads_like_the_reference():

@@ -58,6 +58,10 @@ def test_golden_state_views(HB, name):
         per_player = [g.state_views(p) for p in range(n)]
         valid_for = [g.get_valid_actions(p)[0] for p in range(n)]
         pot, high_bet, over = g.pot, g.high_bet, g.game_over
+        # the packed rows (pk_get_obs_packed) hold the same values, field by field, for the active player and for every seat
+        from pokerl_amd import unpack_obs
+        for p in [None] + list(range(1, n)):
+            assert unpack_obs(g.observations_packed_of(p), n).tobytes() == g.observations_of(p).tobytes(), (s, p)
         for t in range(T):
             assert _tuple_of(active_views[t]) == rec[t]["active"], (s, t)
             for p in range(n):
@@ -492,3 +496,54 @@ def test_async_env_step_host_arrays(HB, O):
     assert GU.bits_equal(before[0], env.game.credits) and np.array_equal(before[1], env.game.step_serial)
     assert GU.bits_equal(obs2, obs)
     env.game.close(); sync_env.game.close()
+
+
+def test_packed_rows_from_the_env_kernels_and_the_pinned_host_path(O):
+    """PK_OBS_PACKED_BYTES rows written from registers by the PokerGameEnv kernels (pk_set_env_obs_packed) and by the getter
+    kernel are the same bytes, and unpack to the f64 rows; VecPokerGameEnv.send / recv (pk_env_step_begin / _end, pinned
+    buffers) delivers what step() delivers; check_actions (pk_check_actions) names the first invalid table and mutates nothing."""
+    import pokerl_amd
+    from pokerl_amd import _lib as L, packed_dtype, unpack_obs
+    from pokerl_amd.hipmem import DeviceBuffer
+    T, N = 1000, 6
+    cfg = dict(num_tables=T, num_players=N, seed=77, start_credits=[50, 100, 20, 100, 80, 100])
+    ea, eb = pokerl_amd.VecPokerGameEnv(0, **cfg), pokerl_amd.VecPokerGameEnv(0, **cfg)
+    ea.reset(); eb.reset()
+    dt = packed_dtype(N)
+    # device-pointer path: fused step writes dense AND packed rows from registers
+    g, lib = ea.game, ea.game._lib
+    D = 17 + 3 * N
+    bufs = dict(act=DeviceBuffer(T * 4), rew=DeviceBuffer(T * 8), done=DeviceBuffer(T), hand=DeviceBuffer(T), terr=DeviceBuffer(T),
+                obs=DeviceBuffer(T * D * 8), packed=DeviceBuffer(T * dt.itemsize))
+    L.check(lib.pk_set_env_obs_packed(g._h, bufs['packed'].ptr), g._h)
+    for it in range(12):
+        acts = g.pick_actions(0)
+        with pytest.raises(ValueError, match=r"table 17\)"):          # nothing mutated by a refused batch
+            bad = acts.copy(); bad[17] = 9; bad[500] = -1
+            ea.check_actions(bad)
+        bufs['act'].upload(acts)
+        L.check(lib.pk_env_step_fused_d(g._h, bufs['act'].ptr, 0, 0, 1, bufs['rew'].ptr, bufs['done'].ptr, bufs['hand'].ptr,
+                                        bufs['terr'].ptr, bufs['obs'].ptr), g._h)
+        g.sync()
+        dense = bufs['obs'].download(np.float64, T * D).reshape(T, D)
+        packed = bufs['packed'].download(np.uint8, T * dt.itemsize).view(dt)
+        assert unpack_obs(packed, N).tobytes() == dense.tobytes(), it
+        assert packed.tobytes() == g.observations_packed_of(None).tobytes(), it      # register-written == getter kernel
+        assert dense.tobytes() == g.observations.tobytes()
+        # host path on the twin env: send / recv with packed rows, auto-reset like the fused call
+        eb.send(acts, obs='packed', auto_reset=True, strict=True)
+        obs_b, rew_b, done_b, hand_b, terr_b = eb.recv()
+        assert obs_b.dtype == dt and obs_b.tobytes() == packed.tobytes(), it
+        assert rew_b.tobytes() == bufs['rew'].download(np.float64, T).tobytes()
+        assert np.array_equal(done_b, bufs['done'].download(np.uint8, T) != 0) and np.array_equal(hand_b, bufs['hand'].download(np.uint8, T) != 0)
+        assert not terr_b.any()
+    # dense rows through the pinned path, and the getter into a caller-supplied pinned array
+    acts = g.pick_actions(0)
+    eb.send(acts, obs='dense', auto_reset=True)
+    obs_b = eb.recv()[0]
+    pin = pokerl_amd.pinned_empty((T, D), np.float64)
+    assert eb.game.observations_of(None, out=pin.array) is pin.array and pin.array.tobytes() == obs_b.tobytes()
+    L.check(lib.pk_set_env_obs_packed(g._h, None), g._h)
+    pin.free(); ea.close(); eb.close()
+    for b in bufs.values():
+        b.free()

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     L = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(L, name), name
-    assert _lib.lib().pk_abi_version() == _lib.ABI_VERSION == 3
+    assert _lib.lib().pk_abi_version() == _lib.ABI_VERSION == 4
 
 
 def test_no_device_fails_loudly():
@@ -32,6 +32,78 @@ def test_no_device_fails_loudly():
         pokerl_amd.VecGame(4, num_players=3)
     with pytest.raises(pokerl_amd.PokerlHipError):
         pokerl_amd.eval_hand(["AD", "KD"])
+
+
+def test_create_refuses_bad_arguments_before_looking_for_a_device():
+    """The argument checks of pk_create run on any machine: seat counts outside the ABI's range and NON-FINITE money (the
+    library is built with -fno-honor-nans: an inf stack would become NaN at the first all-in) are PK_E_INVALID_ARG; a valid
+    configuration gets as far as the device check."""
+    import ctypes as C
+    from pokerl_amd import _lib as L
+    lib = L.lib()
+
+    def create(n=6, credits=None, scalar=100.0, bb=2.0, sb=1.0):
+        h = C.c_void_p()
+        sc = None if credits is None else np.ascontiguousarray(credits, np.float64)
+        rc = lib.pk_create(C.byref(h), 0, 64, n, L.ptr(sc), scalar, bb, sb, 0, 1, 0)
+        msg = (lib.pk_last_error(None) or b"").decode()
+        if rc == L.PK_OK:
+            lib.pk_destroy(h)
+        return rc, msg
+
+    inf, nan = float("inf"), float("nan")
+    for kw in (dict(scalar=inf), dict(scalar=nan), dict(bb=inf), dict(sb=-inf), dict(bb=nan),
+               dict(credits=[100, 100, inf, 100, 100, 100]), dict(credits=[100, nan, 1, 1, 1, 1])):
+        rc, msg = create(**kw)
+        assert rc == L.PK_E_INVALID_ARG and "finite" in msg, (kw, rc, msg)
+    for n in (1, L.MAX_PLAYERS + 1, 24):
+        rc, msg = create(n=n)
+        assert rc == L.PK_E_INVALID_ARG and "num_players" in msg, (n, rc, msg)
+    rc, msg = create()
+    assert rc in (L.PK_OK, L.PK_E_NO_DEVICE), (rc, msg)
+    with pytest.raises(ValueError):
+        import pokerl_amd
+        pokerl_amd.VecGame(4, num_players=L.MAX_PLAYERS + 1)
+
+
+def test_packed_observation_rows_unpack_to_the_dense_layout():
+    """state_view.packed_dtype / unpack_obs: the host side of PK_OBS_PACKED_BYTES (the device side is a -m gpu test)."""
+    from pokerl_amd import packed_dtype, unpack_obs
+    header = open(os.path.join(ROOT, "include", "pokerl_hip.h")).read()
+    assert "#define PK_OBS_PACKED_BYTES(n) (16 + 8 * (3 * (n) + 1))" in header
+    for n in (2, 6, 9, 15):
+        dt = packed_dtype(n)
+        assert dt.itemsize == 16 + 8 * (3 * n + 1) and dt.fields['minimum_raise_value'][1] == 16
+        rng = np.random.default_rng(n)
+        rows = np.zeros(5, dt)
+        rows['player'] = rng.integers(0, n, 5); rows['turn'] = [0, 1, 2, 3, 4]; rows['valid_bits'] = [0x43, 0x7f, 0x45, 0x41, 0x47]
+        rows['player_cards'] = rng.integers(0, 0x3d, (5, 2))
+        cc = rng.integers(0, 0x3d, (5, 5)).astype(np.uint8)
+        for i, turn in enumerate(rows['turn']):
+            cc[i, (0 if turn == 0 else turn + 2):] = 0xFF
+        rows['community_cards'] = cc
+        for f in ('credits', 'bets', 'pending_bets'):
+            rows[f] = rng.random((5, n)) * 100 - 3
+        rows['minimum_raise_value'] = rng.random(5)
+        dense = unpack_obs(rows, n)
+        assert dense.shape == (5, 17 + 3 * n)
+        assert dense[:, 0].tolist() == rows['player'].tolist() and dense[:, 1].tolist() == [0, 1, 2, 3, 4]
+        assert dense[1, 3:10].tolist() == [1] * 7 and dense[0, 3:10].tolist() == [1, 1, 0, 0, 0, 0, 1]
+        assert dense[0, 12:17].tolist() == [-1] * 5 and (dense[1, 12:15] >= 0).all() and dense[1, 15:17].tolist() == [-1, -1]
+        assert dense[:, 17:17 + n].tobytes() == rows['credits'].tobytes() and dense[:, 2].tobytes() == rows['minimum_raise_value'].tobytes()
+        # raw bytes in, same rows out
+        assert np.array_equal(unpack_obs(rows.view(np.uint8).reshape(5, -1), n), dense)
+
+
+def test_pool_plan_shards_like_ranks():
+    """VecPokerGameEnvPool(devices=[...]): one contiguous block per device, cut as shard_tables cuts them for ranks."""
+    from pokerl_amd import VecPokerGameEnvPool, shard_tables
+    slices, devs = VecPokerGameEnvPool.plan(524288, devices=list(range(8)))
+    assert devs == list(range(8)) and [(s.stop - s.start, s.start) for s in slices] == [shard_tables(524288, r, 8) for r in range(8)]
+    slices, devs = VecPokerGameEnvPool.plan(10, devices=[0, 0, 1])
+    assert [(s.start, s.stop) for s in slices] == [(0, 4), (4, 7), (7, 10)] and devs == [0, 0, 1]
+    slices, devs = VecPokerGameEnvPool.plan(2, num_batches=4, default_device=3)
+    assert [(s.start, s.stop) for s in slices] == [(0, 1), (1, 2)] and devs == [3, 3]
 
 
 def test_product_never_imports_oracle():

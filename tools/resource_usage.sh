@@ -1,23 +1,18 @@
 #!/bin/bash
-# Register / spill / LDS / occupancy figures of every kernel of libpokerl_hip.so as the compiler reports them
-# (-Rpass-analysis=kernel-resource-usage), with the library's own build flags.  usage: tools/resource_usage.sh > profiles/rNN_resource_usage.txt
+# Register / spill / LDS / occupancy figures and the memory-instruction kinds (flat / global / scratch) of every table kernel
+# of libpokerl_hip.so for every seat count, as the compiler reports them with the library's own build flags, plus the VALU
+# opcode histogram's half-rate share that bench.py's `ceiling_mix` uses (tools/isa_report.py does the work; the seat counts
+# are compiled in parallel).
+# usage: tools/resource_usage.sh rNN     -> profiles/rNN_resource_usage.txt, profiles/rNN_isa_report.json
 cd "$(dirname "$0")/.."
-FLAGS=$(python3 -c "from pokerl_amd import build; print(' '.join(f for f in build.FLAGS if f not in ('-shared',)))")
-/opt/rocm/bin/hipcc $FLAGS -Rpass-analysis=kernel-resource-usage -c pokerl_amd/csrc/pk_api.hip -o /tmp/pk_api_ru.o 2>&1 | python3 -c "
-import re, sys
-cur = None; rows = {}
-for line in sys.stdin:
-    m = re.search(r'remark: .*Function Name: (\S+)', line)
-    if m:
-        cur = m.group(1); rows[cur] = {}; continue
-    m = re.search(r'remark:\s+([A-Za-z][A-Za-z /\[\]]*?): (\S+) \[-Rpass', line)
-    if m and cur:
-        rows[cur][m.group(1).strip()] = m.group(2)
-import subprocess
-names = {k: subprocess.run(['c++filt', k], capture_output=True, text=True).stdout.strip() for k in rows}
-keys = ['VGPRs', 'AGPRs', 'TotalSGPRs', 'VGPRs Spill', 'SGPRs Spill', 'ScratchSize [bytes/lane]', 'Occupancy [waves/SIMD]', 'LDS Size [bytes/block]']
-print('%-62s' % 'kernel' + ''.join('%12s' % k.split(' [')[0][:11] for k in keys))
-for k in sorted(rows, key=lambda x: names[x]):
-    short = re.sub(r'\(.*', '', names[k]).replace('void ', '')
-    print('%-62s' % short[:62] + ''.join('%12s' % rows[k].get(kk, '-') for kk in keys))
-"
+tag=${1:-r04}
+seq 2 15 | xargs -P 8 -I{} sh -c 'python3 tools/isa_report.py {} --json /tmp/isa_report_{}.json > /tmp/isa_report_{}.txt'
+for n in $(seq 2 15); do cat /tmp/isa_report_$n.txt; done > profiles/${tag}_resource_usage.txt
+python3 - "$tag" <<'PY'
+import json, sys
+out = {}
+for n in range(2, 16):
+    out.update(json.load(open("/tmp/isa_report_%d.json" % n)))
+json.dump(out, open("profiles/%s_isa_report.json" % sys.argv[1], "w"), indent=1)
+PY
+echo "profiles/${tag}_resource_usage.txt profiles/${tag}_isa_report.json"
