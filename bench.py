@@ -125,15 +125,17 @@ VALU_PEAK_WAVE_INSTS_PER_S = 256 * 4 * 2.4e9 / 2.0   # 256 CUs x 4 SIMDs, one wa
 # at half rate).  A lone wave issues ~one instruction per 5 cycles whatever its kind; three waves per SIMD are interpolated
 # (towards the four-wave figures: with the two-wave ones the 1 M-table run exceeded its own ceiling by 1 %).
 ISSUE_CYCLES = {1: (5.0, 5.0), 2: (2.7, 4.5), 3: (2.5, 4.3), 4: (2.45, 4.3)}
-HALF_RATE_SHARE = 0.60   # of k_rollout<6>'s VALU instructions, by the opcode histogram of its ISA with v_mov and the 32-bit
-#                          v_cmp counted as plain (v_cndmask 20 %, f64 10 %, shifts / bfe / bcnt / ffbl / mul / perm 15 %,
-#                          three-operand and 64-bit integer forms 15 %): an estimate -- the ceiling is a model, not a measurement
+HALF_RATE_SHARE = 0.60   # fallback only (round 3's hand estimate): half_rate_share() below reads the figure GENERATED from
+#                          k_rollout<6>'s ISA (tools/isa_report.py -> profiles/rNN_isa_report.json: v_mov and the 32-bit v_cmp
+#                          count as plain; v_cndmask, every f64 op, shifts / bfe / bcnt / ffbl / mul / perm, the three-operand
+#                          and 64-bit integer forms as half rate).  The ceiling stays a model, not a measurement.
 
 
 def mix_ceiling(waves_per_simd):
     """Issue rate this kernel's instruction MIX can reach at its occupancy: (wave-instr/s, cycles per instruction)."""
     full, half = ISSUE_CYCLES[max(1, min(4, int(round(waves_per_simd))))]
-    cyc = HALF_RATE_SHARE * half + (1.0 - HALF_RATE_SHARE) * full
+    share = half_rate_share()[0]
+    cyc = share * half + (1.0 - share) * full
     return 256 * 4 * 2.4e9 / cyc, cyc
 
 
@@ -179,8 +181,10 @@ def evaluator_leg(device, log2_m=None, reps=20):
     gbs = 12.0 * m / (ms * 1e-3) / 1e9
     roof = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
             "bytes_per_eval": 12, "traffic": None}
-    src = os.path.join(ROOT, "profiles", "r03_eval7_summary.json")
-    if os.path.exists(src):
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_eval7_summary.json")))
+    src = cands[-1] if cands else ""
+    if src:
         d = json.load(open(src))
         per_eval = d.get("hbm_traffic_bytes_per_launch", 0) / float(d.get("hands_per_launch", 1))
         roof.update({"traffic": per_eval * m, "traffic_unit": "HBM bytes per launch of this size (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE, KiB), = %.3f x algorithmic" % (per_eval / 12.0),
@@ -236,16 +240,42 @@ def cpu_baseline(n_players, policy, budget_s=None):
     return out
 
 
-def env_mode(args, ctx, device):
-    """--mode env: the RL-facing path as a device-resident loop -- seat 0 picks with the in-kernel random
-    agent (pk_pick_actions_d), PokerGameEnv.step auto-plays the opponents (pk_env_step_d), finished episodes are reset
-    (pk_env_reset_d with the done mask), observations are exported (pk_get_obs_d).  Not the headline metric."""
+ENV_KERNEL = {"sync": "k_env_step", "async": "k_env_step_async"}
+
+
+def env_profile_summary(tables, players, batches, inner, async_passes):
+    """The committed rocprofv3 summary of THIS PokerGameEnv workload (profiles/rNN_env_*_summary.json, made by
+    tools/profile_env.sh + tools/summarize_env_profile.py), latest round; None if none."""
+    import glob
+    import re
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_env_*_summary.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        w = d.get("workload", {})
+        if (w.get("tables"), w.get("players"), w.get("env_batches", 1), w.get("env_inner_batches", 1), w.get("env_async", 0)) == \
+                (tables, players, batches, inner, async_passes):
+            m = re.match(r"r(\d+)_", os.path.basename(f))
+            key = int(m.group(1)) if m else -1
+            if best is None or key >= best[0]:
+                best = (key, d, os.path.basename(f))
+    return (best[1], best[2]) if best else None
+
+
+def env_workload(ctx, device, tables, players, batches=1, inner=1, async_passes=0, steps=200, warmup=20, unfused=False):
+    """The RL-facing path as a device-resident loop: seat 0 picks with the in-kernel random agent,
+    PokerGameEnv.step auto-plays the opponents, finished episodes are reset, the observation row is written -- ONE launch
+    per step (pk_env_step_fused_d), or bounded launches whose unfinished steps stay in flight (pk_env_step_async_d,
+    async_passes > 0; `inner` > 1: sub-batches inside each handle).  Timed with wall clock AND HIP events on each handle's
+    stream (pk_record_event waits for the launches on the handle's internal streams too).  Returns the measurements."""
     import ctypes as C
     import numpy as np
     import pokerl_amd
     from pokerl_amd import _lib as L
-    from pokerl_amd.hipmem import DeviceBuffer
-    T, N, B = args.tables, args.players, max(1, args.env_batches)
+    from pokerl_amd.hipmem import DeviceBuffer, DeviceEvent
+    T, N, B = tables, players, max(1, batches)
     D = 17 + 3 * N
     lib = L.lib()
 
@@ -262,22 +292,23 @@ def env_mode(args, ctx, device):
                 DeviceBuffer(T * 4, device), DeviceBuffer(T * 8, device), DeviceBuffer(T, device),
                 DeviceBuffer(T, device), DeviceBuffer(T, device), DeviceBuffer(T * D * 8, device))
             L.check(lib.pk_env_reset_d(self.g._h, None, 0), self.g._h)
-            self.inner = self.env.set_env_batches(args.env_inner_batches) if (args.env_async > 0 and args.env_inner_batches > 1) else 1
-            # --env-async: one ready[T] slice per timed launch, summed after the timed region
-            self.ready = DeviceBuffer(T * (args.steps + 1), device) if args.env_async > 0 else None
+            self.inner = self.env.set_env_batches(inner) if (async_passes > 0 and inner > 1) else 1
+            # async: one ready[T] slice per timed launch, summed after the timed region
+            self.ready = DeviceBuffer(T * (steps + 1), device) if async_passes > 0 else None
             self.launch = 0
             self.delivered = []     # per timed launch: (slot, begin, end) of the delivered range (inner batches)
+            self.ev0, self.ev1 = DeviceEvent(), DeviceEvent()
 
         def step(self, timed=False):
             g, h = self.g, self.g._h
-            if args.env_async > 0:   # bounded launches: tables whose env.step has not returned stay in flight
+            if async_passes > 0:   # bounded launches: tables whose env.step has not returned stay in flight
                 slot = 1 + self.launch if timed else 0
                 self.launch += 1 if timed else 0
                 if self.inner > 1 and timed:    # the range this call LAUNCHES = the range the previous call delivered; its ready
                     self.delivered.append((slot, self.env.last_range()[:2]))   # flags go to this call's slot
-                L.check(lib.pk_env_step_async_d(h, None, 0, 0, 1, args.env_async, self.rew.ptr, self.done.ptr, self.hand.ptr,
+                L.check(lib.pk_env_step_async_d(h, None, 0, 0, 1, async_passes, self.rew.ptr, self.done.ptr, self.hand.ptr,
                                                 self.terr.ptr, self.obs.ptr, C.c_void_p(self.ready.ptr.value + slot * T)), h)
-            elif args.env_unfused:   # five launches per env step
+            elif unfused:   # five launches per env step
                 L.check(lib.pk_pick_actions_d(h, 0, self.act.ptr), h)
                 L.check(lib.pk_env_step_d(h, self.act.ptr, 0, self.rew.ptr, self.done.ptr, self.hand.ptr, self.terr.ptr), h)
                 L.check(lib.pk_env_reset_d(h, self.done.ptr, 0), h)   # finished episodes ...
@@ -287,63 +318,308 @@ def env_mode(args, ctx, device):
                 L.check(lib.pk_env_step_fused_d(h, None, 0, 0, 1, self.rew.ptr, self.done.ptr, self.hand.ptr, self.terr.ptr,
                                                 self.obs.ptr), h)
 
-    batches = [Batch(b) for b in range(B)]
+        def free(self):
+            for b in (self.act, self.rew, self.done, self.hand, self.terr, self.obs, self.ready):
+                if b is not None:
+                    b.free()
+
+    bs = [Batch(b) for b in range(B)]
 
     def loop(k, timed=False):   # round-robin over the batches: each handle launches on its own stream, nothing waits in between
         for _ in range(k):
-            for b in batches:
+            for b in bs:
                 b.step(timed)
 
     def sync():
-        for b in batches:
+        for b in bs:
             b.g.sync()
 
-    loop(args.warmup)
+    loop(warmup)
     sync()
-    s0 = sum(int(b.g.step_serial.sum()) for b in batches)
+    s0 = sum(int(b.g.step_serial.sum()) for b in bs)
     ctx.barrier()
+    for b in bs:
+        b.g.record_event(b.ev0.handle)
     t0 = time.perf_counter()
-    loop(args.steps, True)
+    loop(steps, True)
+    for b in bs:
+        b.g.record_event(b.ev1.handle)      # after everything launched so far, the handle's internal streams included
     sync(); ctx.barrier()
     dt = time.perf_counter() - t0
-    env_steps = B * T * args.steps
+    dev_ms = max(DeviceEvent.elapsed_ms(b.ev0, b.ev1) for b in bs)
+    env_steps = B * T * steps
     launched_tables = env_steps
-    if args.env_async > 0 and batches[0].inner > 1:     # a call steps ONE range of its handle
-        launched_tables = sum(r1 - r0 for b in batches for _, (r0, r1) in b.delivered)
-    if args.env_async > 0:   # delivered env.steps = ready flags of the timed launches; then drain so that the tables can be read
+    if async_passes > 0 and bs[0].inner > 1:     # a call steps ONE range of its handle
+        launched_tables = sum(r1 - r0 for b in bs for _, (r0, r1) in b.delivered)
+    if async_passes > 0:   # delivered env.steps = ready flags of the timed launches; then drain so that the tables can be read
         def delivered_steps(b):
-            flags = b.ready.download(np.uint8, T * (args.steps + 1))
+            flags = b.ready.download(np.uint8, T * (steps + 1))
             if b.inner <= 1:
                 return int(flags[T:].sum(dtype=np.int64))
             # inner batches: every timed call wrote the flags of the ONE range it launched into its own slot
             return sum(int(flags[slot * T + r0:slot * T + r1].sum(dtype=np.int64)) for slot, (r0, r1) in b.delivered)
-        env_steps = sum(delivered_steps(b) for b in batches)
-        for b in batches:
+        env_steps = sum(delivered_steps(b) for b in bs)
+        for b in bs:
             L.check(lib.pk_env_step_async_d(b.g._h, None, 0, 0, 1, 0, b.rew.ptr, b.done.ptr, b.hand.ptr, b.terr.ptr, b.obs.ptr,
                                             b.ready.ptr), b.g._h)
         sync()
-    game_steps = sum(int(b.g.step_serial.sum()) for b in batches) - s0
-    capped = sum(int((b.terr.download(np.uint8, T) != 0).sum()) for b in batches)
-    if ctx.rank == 0:
-        print(json.dumps({
-            "metric": "PokerGameEnv.step seat-0 steps/s (device-resident loop: pick + env_step + env_reset(done) + obs; %s)"
-                      % ("bounded launches of %d betting passes, steps that have not returned stay in flight "
-                         "(pk_env_step_async_d); value counts DELIVERED env.steps" % args.env_async if args.env_async > 0 else
-                         "five launches per step" if args.env_unfused else "fused into one launch per step"),
-            "value": env_steps / dt, "unit": "env.step/s", "n_gpus": ctx.world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%d batch(es) x %d tables x %d seats per GPU, seat 0 + opponents random in-kernel, "
-                                   "episodes auto-reset%s; reference pokerl/envs/game_env.py:20-53"
-                                   % (B, T, N, ", each handle in %d sub-batches (pk_set_env_batches): one call launches one of them"
-                                      % batches[0].inner if batches[0].inner > 1 else ""),
-                       "env_batches": B, "env_inner_batches": batches[0].inner,
-                       "note": "one env.step of a batch lasts as long as its slowest table (a busted seat 0 waits for the "
-                               "rest of the game, game_env.py:44-47); independent batches on their own streams fill that tail"},
-            "game_steps_per_s": game_steps / dt, "game_steps_per_env_step": game_steps / max(1, env_steps),
-            "ready_fraction_per_launch": env_steps / float(launched_tables), "inner_batches": batches[0].inner,
-            "tables_with_error_bits_in_last_step": capped}))
+    game_steps = sum(int(b.g.step_serial.sum()) for b in bs) - s0
+    capped = sum(int((b.terr.download(np.uint8, T) != 0).sum()) for b in bs)
+    launches = B * steps * (5 if (unfused and async_passes == 0) else 1)
+    res = dict(tables=T, players=N, batches=B, inner=bs[0].inner, async_passes=async_passes, unfused=unfused, steps=steps, warmup=warmup,
+               seconds=dt, device_ms=dev_ms, env_steps=env_steps, launched_tables=launched_tables, game_steps=game_steps,
+               capped=capped, launches=launches)
+    for b in bs:
+        b.free()
     pool.close()
+    return res
+
+
+def env_roofline(res):
+    """Roofline block of a PokerGameEnv workload: VALU issue (binding) from the committed PMC summary of THAT workload x
+    this run's HIP-event time, with the measured HBM traffic of the same passes beside it."""
+    kern = ENV_KERNEL["async" if res["async_passes"] > 0 else "sync"]
+    ms_launch = res["device_ms"] / max(1, res["launches"])
+    roof = {"bound": "valu-issue", "achieved": None, "peak": VALU_PEAK_WAVE_INSTS_PER_S, "unit": "wave-instr/s", "frac": None,
+            "traffic": None, "kernel": kern, "kernel_ms": ms_launch, "launches_timed": res["launches"],
+            "kernel_ms_source": "HIP events (pk_record_event) around the timed region on each handle's stream (the launches on a handle's "
+                                "internal sub-batch streams are waited for first); the region's device time / the launches inside it -- "
+                                "launches of different handles / sub-batches OVERLAP, so this is the effective time per launch"}
+    prof = env_profile_summary(res["tables"], res["players"], res["batches"], res["inner"], res["async_passes"]) if not res["unfused"] else None
+    if prof:
+        d, src = prof
+        per_launch = d.get("valu_wave_insts_per_launch")
+        if per_launch:
+            rate = per_launch * res["launches"] / (res["device_ms"] * 1e-3)
+            resident = d.get("waves_per_simd_resident") or 1.0
+            ceil_rate, ceil_cyc = mix_ceiling(resident)
+            traffic = d.get("hbm_traffic_bytes_per_launch")
+            roof.update({"achieved": rate, "frac": rate / VALU_PEAK_WAVE_INSTS_PER_S, "source": src,
+                         "valu_wave_insts_per_launch": per_launch, "lanes_active": d.get("lanes_active"),
+                         "waves_per_simd": resident, "wait_any_frac": d.get("wait_any_frac_of_wave_cycles"),
+                         "ceiling_mix": {"peak": ceil_rate, "frac_of_ceiling": rate / ceil_rate, "cycles_per_instruction": ceil_cyc,
+                                         "half_rate_share": half_rate_share()[0], "source": "profiles/r03_valu_rates.txt + " + half_rate_share()[1]},
+                         "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE, KiB)",
+                         "hbm": {"bound": "hbm (measured traffic)", "achieved": (traffic or 0.0) * res["launches"] / (res["device_ms"] * 1e-3) / 1e9,
+                                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": (traffic or 0.0) * res["launches"] / (res["device_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                 "note": "real traffic of the committed PMC passes (table state in and out once per launch + the "
+                                         "observation rows and outputs of the delivered tables) x this run's launches / its device time"},
+                         "note": "achieved = wave-level VALU instructions per launch (SQ_INSTS_VALU of the COMMITTED rocprofv3 PMC pass of "
+                                 "this workload) x this run's launches / its HIP-event device time; peak = 256 CU x 4 SIMD x 2.4 GHz / 2"})
+    if roof["achieved"] is None:
+        roof["note"] = "no rocprofv3 PMC summary of this PokerGameEnv workload under profiles/ (tools/profile_env.sh makes one)"
+    return roof
+
+
+def env_line(res, ctx):
+    B, T, N = res["batches"], res["tables"], res["players"]
+    dt = res["seconds"]
+    return {
+        "metric": "PokerGameEnv.step seat-0 steps/s (device-resident loop: pick + env_step + env_reset(done) + obs; %s)"
+                  % ("bounded launches of %d betting passes, steps that have not returned stay in flight "
+                     "(pk_env_step_async_d); value counts DELIVERED env.steps" % res["async_passes"] if res["async_passes"] > 0 else
+                     "five launches per step" if res["unfused"] else "fused into one launch per step"),
+        "value": res["env_steps"] / dt, "unit": "env.step/s", "n_gpus": ctx.world, "steps": res["steps"],
+        "warmup": res["warmup"], "ms_per_step": dt / res["steps"] * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "%d batch(es) x %d tables x %d seats per GPU, seat 0 + opponents random in-kernel, "
+                               "episodes auto-reset%s; reference pokerl/envs/game_env.py:20-53"
+                               % (B, T, N, ", each handle in %d sub-batches (pk_set_env_batches): one call launches one of them"
+                                  % res["inner"] if res["inner"] > 1 else ""),
+                   "env_batches": B, "env_inner_batches": res["inner"],
+                   "note": "one env.step of a batch lasts as long as its slowest table (a busted seat 0 waits for the "
+                           "rest of the game, game_env.py:44-47); independent batches on their own streams fill that tail"},
+        "game_steps_per_s": res["game_steps"] / dt, "game_steps_per_env_step": res["game_steps"] / max(1, res["env_steps"]),
+        "ready_fraction_per_launch": res["env_steps"] / float(res["launched_tables"]), "inner_batches": res["inner"],
+        "tables_with_error_bits_in_last_step": res["capped"], "device_ms": res["device_ms"], "launches": res["launches"],
+        "roofline": env_roofline(res)}
+
+
+def env_mode(args, ctx, device):
+    """--mode env: the RL-facing path as its own bench line (not the headline metric)."""
+    res = env_workload(ctx, device, args.tables, args.players, args.env_batches, args.env_inner_batches, args.env_async,
+                       args.steps, args.warmup, args.env_unfused)
+    if ctx.rank == 0:
+        print(json.dumps(env_line(res, ctx)))
+
+
+def rollout_workload(ctx, device, tables, players, policy_name, K, warmup, chunk=4096, reps=0, min_steps=524288, samples=7,
+                     fused=True, coalesce=-1):
+    """The fused rollout of one configuration: `samples` timed samples of reps x K steps per table, each bracketed by HIP
+    events on the handle's stream and completed by a sync; the device counters prove the steps were executed."""
+    import pokerl_amd
+    from pokerl_amd.hipmem import DeviceEvent
+    policy = 0 if policy_name == "random" else 1
+    total_tables = tables * ctx.world
+    n_local, base = shard(total_tables, ctx)
+    game = pokerl_amd.VecGame(n_local, num_players=players, device=device, table_id_base=base)
+    game.reset()
+    if coalesce >= 0:
+        game.set_coalesce(coalesce)
+    K = max(1, K)
+    if reps <= 0:   # auto: as many blocks as make a sample >= min_steps steps (unfused: one block -- K launches -- per sample)
+        reps = max(1, -(-min_steps // K)) if fused else 1
+
+    def block():  # K steps on every table; launches are asynchronous and may defer their stragglers to the next launch
+        done = 0
+        while done < K:
+            k = min(chunk, K - done)
+            game.rollout(k, policy, True, fused, counters=False)
+            done += k
+
+    done = 0
+    while done < warmup:
+        k = min(chunk, warmup - done)
+        game.rollout(k, policy, True, fused, counters=False)
+        done += k
+    game.rollout(0, policy, True, fused, counters=True)  # complete + zero the device counters
+    ev0, ev1 = DeviceEvent(), DeviceEvent()
+    stats_warm = game.launch_stats(reset=True)           # launches so far (reset + warm-up): a profiler sees those too
+    sample_s, sample_dev_ms, sample_stats = [], [], []
+    for _ in range(max(1, samples)):
+        ctx.barrier(); game.sync()
+        game.record_event(ev0.handle)                    # HIP events on the stream the kernel is launched on
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            block()
+        game.record_event(ev1.handle)                    # completes every deferred / host-held step first, then records
+        game.sync(); ctx.barrier()   # exactly reps*K steps per table are inside
+        sample_s.append(ctx.aggregate(0, time.perf_counter() - t0)[1])   # MAX over ranks
+        sample_dev_ms.append(DeviceEvent.elapsed_ms(ev0, ev1))
+        sample_stats.append(game.launch_stats(reset=True))
+    stats = dict(launches=sum(x["launches"] for x in sample_stats), steps=sum(x["steps"] for x in sample_stats),
+                 min=min(x["min"] for x in sample_stats), max=max(x["max"] for x in sample_stats))
+    c = game.rollout(0, policy, True, fused, counters=True)
+    assert c["steps"] == n_local * K * reps * len(sample_s), (c, n_local, K, reps)
+    assert stats["steps"] == K * reps * len(sample_s), (stats, K, reps)
+    med = sorted(range(len(sample_s)), key=lambda i: sample_s[i])[len(sample_s) // 2]   # the MEDIAN sample: value, ms_per_step and kernel_ms are all its
+    seconds = sample_s[med]
+    total_steps = ctx.aggregate(n_local * K * reps, 0.0)[0]
+    scale = 1.0 / (sum(sample_s))   # counters cover all samples
+    hands, evals, games = ctx.sum_list([c["hands"], c["evals"], c["games"]])
+    # roofline leg: the timed region itself, bracketed by HIP events on the handle's stream; the dominant kernel is the only
+    # kernel in it, so its average launch duration (launch gaps included) = event time / launches
+    launches = max(1, sample_stats[med]["launches"])
+    ms_launch = sample_dev_ms[med] / launches            # of the median sample, like `value` and `ms_per_step`
+    kern_steps = sample_stats[med]["steps"] / float(launches)        # mean Game.step()s per table per launch
+    game.close()
+    return dict(tables=tables, players=players, policy=policy_name, K=K, warmup=warmup, chunk=chunk, reps=reps, fused=fused,
+                n_local=n_local, seconds=seconds, total_steps=total_steps, sample_s=sample_s, sample_dev_ms=sample_dev_ms,
+                stats=stats, stats_warm=stats_warm, launches=launches, ms_launch=ms_launch, kern_steps=kern_steps,
+                hand_evals_per_s=evals * scale, hands_per_s=hands * scale, games_per_s=games * scale)
+
+
+_HALF = None
+
+
+def half_rate_share():
+    """(share, source): half-rate share of k_rollout<6>'s static VALU instructions, GENERATED from its ISA by tools/isa_report.py
+    (profiles/rNN_isa_report.json, made by tools/resource_usage.sh); the hand estimate of round 3 if no report is committed."""
+    global _HALF
+    if _HALF is None:
+        import glob
+        _HALF = (HALF_RATE_SHARE, "bench.py HALF_RATE_SHARE (hand estimate)")
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_isa_report.json"))):
+            try:
+                v = json.load(open(f))["6"]["k_rollout<6>"]["half_rate_share_static"]
+                _HALF = (float(v), "profiles/" + os.path.basename(f) + " (opcode histogram of k_rollout<6>'s ISA)")
+            except Exception:
+                pass
+    return _HALF
+
+
+def rollout_roofline(w, world):
+    """The `roofline` object of a rollout workload (dict from rollout_workload): VALU issue leads (binding), SURVEY 8d's
+    algorithmic-HBM figure and the measured traffic are nested."""
+    n_local, kern_steps, ms_launch, launches = w["n_local"], w["kern_steps"], w["ms_launch"], w["launches"]
+    alg_bytes = b_step(w["players"]) * n_local * kern_steps
+    achieved = alg_bytes / (ms_launch * 1e-3) / 1e9
+    prof = profile_summary(w["tables"], w["players"], w["policy"], int(round(kern_steps))) if w["fused"] else None
+    hbm = {"bound": "hbm (algorithmic bytes, SURVEY 8d)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": achieved / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": alg_bytes,
+           "note": "ALGORITHMIC bytes ((2*(35N+21)+16) B/env-step x tables x steps per launch) / launch time: what a "
+                   "one-HBM-round-trip-per-step design would move.  The fused kernel keeps the table state in VGPRs "
+                   "for all steps of a launch and really moves `traffic` (one read + one write of the state per "
+                   "launch), so this fraction can exceed 1 and bounds nothing; kept because SURVEY 8d defines it."}
+    roof = {"bound": "valu-issue", "achieved": None, "peak": VALU_PEAK_WAVE_INSTS_PER_S, "unit": "wave-instr/s",
+            "frac": None, "traffic": None,
+            "traffic_unit": "HBM bytes per launch (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE, KiB)",
+            "kernel_ms": ms_launch, "launches_timed": launches, "steps_per_launch": kern_steps,
+            "kernel_ms_source": "HIP events (pk_record_event) around the timed samples on the handle's stream; the median "
+                                "sample's device time / the launches inside it (pk_get_launch_stats)",
+            "hbm_algorithmic": hbm}
+    if prof:
+        d, src = prof
+        pmc = d.get("pmc_per_full_launch", {})
+        roof["traffic"] = hbm["traffic"] = d.get("hbm_traffic_bytes_per_launch")
+        roof["traffic_source"] = src
+        per_wave_step = d.get("valu_insts_per_wave_step")
+        waves = pmc.get("SQ_WAVES")
+        if per_wave_step and waves:
+            waves_here = waves * (n_local / float(w["tables"]))
+            valu_rate = per_wave_step * waves_here * kern_steps / (ms_launch * 1e-3)
+            lanes = d.get("lanes_active")
+            # resident waves per SIMD: the launch's waves, capped by what the kernel's registers allow (rocprofv3's VGPR_Count
+            # is half the allocation; 512 registers per lane and SIMD: guides/MI355X_MICROARCH.md, register files)
+            resident = min(waves / 1024.0, float(max(1, min(8, 512 // (2 * d["vgpr"]))))) if d.get("vgpr") else waves / 1024.0
+            ceil_rate, ceil_cyc = mix_ceiling(resident)
+            roof.update({"achieved": valu_rate, "frac": valu_rate / VALU_PEAK_WAVE_INSTS_PER_S,
+                         "valu_insts_per_wave_step": per_wave_step, "salu_insts_per_wave_step": d.get("salu_insts_per_wave_step"),
+                         "lanes_active": lanes, "waves_per_simd": resident, "waves_per_simd_launched": waves / 1024.0,
+                         "wait_any_frac": d.get("wait_any_frac_of_wave_cycles"), "source": src,
+                         "ceiling_mix": {"peak": ceil_rate, "frac_of_ceiling": valu_rate / ceil_rate,
+                                         "cycles_per_instruction": ceil_cyc, "source": "profiles/r03_valu_rates.txt",
+                                         "half_rate_share": half_rate_share()[0], "half_rate_share_source": half_rate_share()[1],
+                                         "note": "what this instruction mix can issue at this occupancy: measured cycles per "
+                                                 "wave-instruction of the plain and of the half-rate kinds, weighted by their "
+                                                 "share of the kernel's VALU instructions (ISSUE_CYCLES / mix_ceiling in bench.py)"},
+                         "note": "HYBRID figure: achieved = wave-level VALU instructions per wave-step from the COMMITTED rocprofv3 PMC "
+                                 "pass of this workload (`source`: SQ_INSTS_VALU / waves / steps; valid while kernel and profile "
+                                 "stay in step) x waves x steps per launch / THIS run's HIP-event launch time; peak = 256 CU x 4 "
+                                 "SIMD x 2.4 GHz / 2 cycles per wave64 VALU instruction (guides/MI355X_MICROARCH.md)"})
+    if roof["achieved"] is None:   # no committed PMC summary for this shape: only the SURVEY 8d figure can be given
+        roof.update({"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "note": "no rocprofv3 PMC summary of this workload under profiles/: algorithmic-HBM figure only (see hbm_algorithmic)"})
+    return roof
+
+
+def kernel_description(w):
+    stats, K, chunk = w["stats"], w["K"], w["chunk"]
+    if not w["fused"]:
+        return "k_rollout_single (1 step/launch, the state round-trips HBM every step)"
+    return ("k_rollout (fused; %d launches in the median sample, mean %.1f steps per launch, min %d, max %d over all samples: "
+            "asynchronous calls of %d steps %s)"
+            % (w["launches"], w["kern_steps"], stats["min"], stats["max"], min(chunk, K),
+               "merged on the host while two launches are in flight (pk_set_coalesce)" if stats["max"] > min(chunk, K) else "launched one by one"))
+
+
+def extra_workloads(ctx, device):
+    """The other single-GPU BASELINE configs and the PokerGameEnv path, as SHORT driver-timed legs after the headline leg
+    (~1 s of GPU work each, same event-bracketed timing, same counter assertion): configs[1], configs[4] (showdown-heavy:
+    1.000 in-game evaluation per env-step), PokerGameEnv.step synchronous and asynchronous."""
+    out = []
+    for cfg, (tables, players, policy) in ((1, (4096, 2, "random")), (4, (65536, 9, "allin"))):
+        w = rollout_workload(ctx, device, tables, players, policy, K=4096, warmup=512, min_steps=262144, samples=3)
+        out.append({"name": "BASELINE configs[%d]: %d tables x %d seats, %s agents" % (cfg, tables, players, policy),
+                    "metric": "env-steps/s", "value": w["total_steps"] / w["seconds"], "unit": "env-steps/s",
+                    "hand_evals_per_s": w["hand_evals_per_s"], "hands_per_s": w["hands_per_s"],
+                    "ms_per_step": w["seconds"] / (w["K"] * w["reps"]) * 1e3, "steps_per_sample": w["K"] * w["reps"], "samples": len(w["sample_s"]),
+                    "kernel": kernel_description(w), "kernel_ms": w["ms_launch"], "launches": w["launches"],
+                    "launch_stats": w["stats"], "roofline": rollout_roofline(w, ctx.world)})
+    for name, kw in (("PokerGameEnv.step synchronous (pk_env_step_fused_d), 65 536 x 6", dict(tables=65536, players=6, steps=1000, warmup=50)),
+                     ("PokerGameEnv.step asynchronous (pk_env_step_async_d, 8 betting passes per launch), one handle of 65 536 x 6",
+                      dict(tables=65536, players=6, async_passes=8, steps=4000, warmup=300)),
+                     ("PokerGameEnv.step asynchronous, ONE handle of 524 288 x 6 in three sub-batches (pk_set_env_batches)",
+                      dict(tables=524288, players=6, async_passes=8, inner=3, steps=1500, warmup=300))):
+        res = env_workload(ctx, device, **kw)
+        line = env_line(res, ctx)
+        out.append({"name": name, "metric": "PokerGameEnv.step/s (delivered)", "value": line["value"], "unit": "env.step/s",
+                    "game_steps_per_s": line["game_steps_per_s"], "game_steps_per_env_step": line["game_steps_per_env_step"],
+                    "ready_fraction_per_launch": line["ready_fraction_per_launch"], "kernel": line["roofline"]["kernel"],
+                    "kernel_ms": line["roofline"]["kernel_ms"], "launches": res["launches"], "device_ms": res["device_ms"],
+                    "seconds": res["seconds"], "roofline": line["roofline"]})
+    return out
 
 
 def main():
@@ -373,6 +649,7 @@ def main():
                          "range of the handle's tables and delivers the range launched longest ago")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-evaluator", action="store_true", help="skip the stand-alone evaluator kernel leg")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra_workloads legs (the other BASELINE configs, PokerGameEnv)")
     ap.add_argument("--coalesce", type=int, default=-1,
                     help="host-side merging of asynchronous rollout calls into launches of up to this many steps "
                          "(pk_set_coalesce; -1: the library default 1024, 0: one launch per call)")
@@ -381,131 +658,26 @@ def main():
     ctx = DistContext()
     if ctx.world != max(1, args.gpus) and ctx.rank == 0:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, ctx.world), file=sys.stderr)
-    import pokerl_amd
+    import pokerl_amd  # noqa: F401  (fails loudly here if the HIP library is missing)
     device = 0 if os.environ.get("PK_BENCH_SAME_DEVICE") else ctx.local_rank  # rehearsal knob: all ranks on GPU 0
     if args.mode == "env":
         env_mode(args, ctx, device)
         ctx.close()
         return
     policy = 0 if args.policy == "random" else 1
-    total_tables = args.tables * ctx.world
-    n_local, base = shard(total_tables, ctx)
-    game = pokerl_amd.VecGame(n_local, num_players=args.players, device=device, table_id_base=base)
-    game.reset()
-    if args.coalesce >= 0:
-        game.set_coalesce(args.coalesce)
     fused = not args.unfused
-    K = max(1, args.steps)
-    reps = args.reps if args.reps > 0 else max(1, -(-args.min_steps // K))
-    if not fused:
-        reps = args.reps if args.reps > 0 else 1
-
-    def block():  # K steps on every table; launches are asynchronous and may defer their stragglers to the next launch
-        done = 0
-        while done < K:
-            k = min(args.chunk, K - done)
-            game.rollout(k, policy, True, fused, counters=False)
-            done += k
-
-    done = 0
-    while done < args.warmup:
-        k = min(args.chunk, args.warmup - done)
-        game.rollout(k, policy, True, fused, counters=False)
-        done += k
-    game.rollout(0, policy, True, fused, counters=True)  # complete + zero the device counters
-    from pokerl_amd.hipmem import DeviceEvent
-    ev0, ev1 = DeviceEvent(), DeviceEvent()
-    stats_warm = game.launch_stats(reset=True)           # launches so far (reset + warm-up): a profiler sees those too
-    sample_s, sample_dev_ms, sample_stats = [], [], []
-    for _ in range(max(1, args.samples)):
-        ctx.barrier(); game.sync()
-        game.record_event(ev0.handle)                    # HIP events on the stream the kernel is launched on
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            block()
-        game.record_event(ev1.handle)                    # completes every deferred / host-held step first, then records
-        game.sync(); ctx.barrier()   # exactly reps*K steps per table are inside
-        sample_s.append(ctx.aggregate(0, time.perf_counter() - t0)[1])   # MAX over ranks
-        sample_dev_ms.append(DeviceEvent.elapsed_ms(ev0, ev1))
-        sample_stats.append(game.launch_stats(reset=True))
-    stats = dict(launches=sum(x["launches"] for x in sample_stats), steps=sum(x["steps"] for x in sample_stats),
-                 min=min(x["min"] for x in sample_stats), max=max(x["max"] for x in sample_stats))
-    c = game.rollout(0, policy, True, fused, counters=True)
-    assert c["steps"] == n_local * K * reps * len(sample_s), (c, n_local, K, reps)
-    assert stats["steps"] == K * reps * len(sample_s), (stats, K, reps)
-    med = sorted(range(len(sample_s)), key=lambda i: sample_s[i])[len(sample_s) // 2]   # the MEDIAN sample: value, ms_per_step and kernel_ms are all its
-    seconds = sample_s[med]
-    total_steps = ctx.aggregate(n_local * K * reps, 0.0)[0]
-    scale = 1.0 / (sum(sample_s))   # counters cover all samples
-    hands, evals, games = ctx.sum_list([c["hands"], c["evals"], c["games"]])
-
-    # roofline leg (rank 0): the timed region itself, bracketed by HIP events on the handle's stream; the dominant kernel
-    # is the only kernel in it, so its average launch duration (launch gaps included) = event time / launches
-    launches = max(1, sample_stats[med]["launches"])
-    ms_launch = sample_dev_ms[med] / launches            # of the median sample, like `value` and `ms_per_step`
-    kern_steps = sample_stats[med]["steps"] / float(launches)        # mean Game.step()s per table per launch
+    w = rollout_workload(ctx, device, args.tables, args.players, args.policy, args.steps, args.warmup, args.chunk,
+                         args.reps, args.min_steps, args.samples, fused, args.coalesce)
+    K, reps = w["K"], w["reps"]
     ctx.barrier()
     if ctx.rank == 0:
-        alg_bytes = b_step(args.players) * n_local * kern_steps
-        achieved = alg_bytes / (ms_launch * 1e-3) / 1e9
         cfg_idx = baseline_config_index(args.tables, args.players, args.policy, ctx.world)
-        prof = profile_summary(args.tables, args.players, args.policy, int(round(kern_steps))) if fused else None
-        hbm = {"bound": "hbm (algorithmic bytes, SURVEY 8d)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-               "frac": achieved / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": alg_bytes,
-               "note": "ALGORITHMIC bytes ((2*(35N+21)+16) B/env-step x tables x steps per launch) / launch time: what a "
-                       "one-HBM-round-trip-per-step design would move.  The fused kernel keeps the table state in VGPRs "
-                       "for all steps of a launch and really moves `traffic` (one read + one write of the state per "
-                       "launch), so this fraction can exceed 1 and bounds nothing; kept because SURVEY 8d defines it."}
-        roof = {"bound": "valu-issue", "achieved": None, "peak": VALU_PEAK_WAVE_INSTS_PER_S, "unit": "wave-instr/s",
-                "frac": None, "traffic": None,
-                "traffic_unit": "HBM bytes per launch (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE, KiB)",
-                "kernel_ms": ms_launch, "launches_timed": launches, "steps_per_launch": kern_steps,
-                "kernel_ms_source": "HIP events (pk_record_event) around the timed samples on the handle's stream; the median "
-                                    "sample's device time / the launches inside it (pk_get_launch_stats)",
-                "hbm_algorithmic": hbm}
-        if prof:
-            d, src = prof
-            pmc = d.get("pmc_per_full_launch", {})
-            roof["traffic"] = hbm["traffic"] = d.get("hbm_traffic_bytes_per_launch")
-            roof["traffic_source"] = src
-            per_wave_step = d.get("valu_insts_per_wave_step")
-            waves = pmc.get("SQ_WAVES")
-            if per_wave_step and waves:
-                waves_here = waves * (n_local / float(args.tables))
-                valu_rate = per_wave_step * waves_here * kern_steps / (ms_launch * 1e-3)
-                lanes = d.get("lanes_active")
-                # resident waves per SIMD: the launch's waves, capped by what the kernel's registers allow (rocprofv3's VGPR_Count
-                # is half the allocation; 512 registers per lane and SIMD: guides/MI355X_MICROARCH.md, register files)
-                resident = min(waves / 1024.0, float(max(1, min(8, 512 // (2 * d["vgpr"]))))) if d.get("vgpr") else waves / 1024.0
-                ceil_rate, ceil_cyc = mix_ceiling(resident)
-                roof.update({"achieved": valu_rate, "frac": valu_rate / VALU_PEAK_WAVE_INSTS_PER_S,
-                             "valu_insts_per_wave_step": per_wave_step, "salu_insts_per_wave_step": d.get("salu_insts_per_wave_step"),
-                             "lanes_active": lanes, "waves_per_simd": resident, "waves_per_simd_launched": waves / 1024.0,
-                             "wait_any_frac": d.get("wait_any_frac_of_wave_cycles"), "source": src,
-                             "ceiling_mix": {"peak": ceil_rate, "frac_of_ceiling": valu_rate / ceil_rate,
-                                             "cycles_per_instruction": ceil_cyc, "source": "profiles/r03_valu_rates.txt",
-                                             "half_rate_share": HALF_RATE_SHARE,
-                                             "note": "what this instruction mix can issue at this occupancy: measured cycles per "
-                                                     "wave-instruction of the plain and of the half-rate kinds, weighted by their "
-                                                     "share of the kernel's VALU instructions (ISSUE_CYCLES / mix_ceiling in bench.py)"},
-                             "note": "achieved = wave-level VALU instructions per wave-step (SQ_INSTS_VALU of the committed "
-                                     "rocprofv3 PMC pass of this workload / waves / steps) x waves x steps per launch / "
-                                     "this run's HIP-event launch time; peak = 256 CU x 4 SIMD x 2.4 GHz / 2 cycles per "
-                                     "wave64 VALU instruction (guides/MI355X_MICROARCH.md)"})
-        if roof["achieved"] is None:   # no committed PMC summary for this shape: only the SURVEY 8d figure can be given
-            roof.update({"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "note": "no rocprofv3 PMC summary of this workload under profiles/: algorithmic-HBM figure only (see hbm_algorithmic)"})
-        kern_desc = ("k_rollout (fused; %d launches in the median sample, mean %.1f steps per launch, min %d, max %d over all samples: "
-                     "asynchronous calls of %d steps %s)"
-                     % (launches, kern_steps, stats["min"], stats["max"], min(args.chunk, K),
-                        "merged on the host while two launches are in flight (pk_set_coalesce)" if stats["max"] > min(args.chunk, K) else "launched one by one")
-                     if fused else "k_rollout_single (1 step/launch, the state round-trips HBM every step)")
         out = {
             "metric": "env-steps/sec (whole node) + showdown hand-evals/sec, 65 536 tables 6-max",
-            "value": total_steps / seconds, "unit": "env-steps/s", "n_gpus": ctx.world, "steps": K,
-            "warmup": args.warmup, "ms_per_step": seconds / (K * reps) * 1e3, "higher_is_better": True,
+            "value": w["total_steps"] / w["seconds"], "unit": "env-steps/s", "n_gpus": ctx.world, "steps": K,
+            "warmup": args.warmup, "ms_per_step": w["seconds"] / (K * reps) * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "reps": reps, "samples": len(sample_s), "sample_seconds": sample_s, "sample_device_ms": sample_dev_ms,
+            "reps": reps, "samples": len(w["sample_s"]), "sample_seconds": w["sample_s"], "sample_device_ms": w["sample_dev_ms"],
             "timing": "each sample = %d block(s) of %d steps per table, launched back to back and completed by a sync inside "
                       "the timed region; value = steps of one sample / MEDIAN sample time (MAX over ranks per sample)" % (reps, K),
             "config": {"workload": "%d tables/GPU x %d GPU(s), num_players=%d, %s agents in-kernel (Philox4x32-10), "
@@ -513,17 +685,18 @@ def main():
                                    % (args.tables, ctx.world, args.players, args.policy,
                                       "BASELINE configs[%d]" % cfg_idx if cfg_idx is not None else "not a BASELINE config"),
                        "tables_per_gpu": args.tables, "num_players": args.players, "policy": args.policy,
-                       "kernel": kern_desc, "launch_stats": stats, "launch_stats_before_timed_region": stats_warm,
+                       "kernel": kernel_description(w), "launch_stats": w["stats"], "launch_stats_before_timed_region": w["stats_warm"],
                        "parallelism": "env-parallel, %d shard(s), no collective on the step path" % ctx.world},
-            "hand_evals_per_s": evals * scale, "hands_per_s": hands * scale, "games_per_s": games * scale,
-            "roofline": roof,
+            "hand_evals_per_s": w["hand_evals_per_s"], "hands_per_s": w["hands_per_s"], "games_per_s": w["games_per_s"],
+            "roofline": rollout_roofline(w, ctx.world),
         }
         if not args.no_evaluator:
             out["evaluator"] = evaluator_leg(device)
+        if not args.no_extra and ctx.world == 1 and fused:
+            out["extra_workloads"] = extra_workloads(ctx, device)
         if not args.no_cpu_baseline and ctx.world == 1:
             out["cpu_baseline"] = cpu_baseline(args.players, policy)
         print(json.dumps(out))
-    game.close()
     ctx.close()
 
 

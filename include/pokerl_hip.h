@@ -362,7 +362,9 @@ int pk_env_end_multi_d(pk_handle *h);
  * stream of another device is refused (PK_E_INVALID_ARG).  pk_use_own_stream goes back to the handle's own stream.
  * Or keep two streams and order them with events:
  * pk_wait_event = the handle's stream waits for `event` (record it on your stream after producing actions_d),
- * pk_record_event = records `event` on the handle's stream (wait for it on your stream before reading obs_d). */
+ * pk_record_event = records `event` on the handle's stream (wait for it on your stream before reading obs_d); deferred
+ * rollout steps are completed first, and the launches pk_env_step_async_d made on the handle's internal sub-batch streams
+ * (pk_set_env_batches) are waited for, so the event covers everything requested so far. */
 int pk_get_stream(pk_handle *h, void **stream_out);
 int pk_set_stream(pk_handle *h, void *stream);
 int pk_use_own_stream(pk_handle *h);

@@ -488,6 +488,9 @@ int pk_record_event(pk_handle *h, void *event) {
     if (!h || !event) return PK_E_INVALID_ARG;
     ON_DEVICE(h);
     if (!h->env_pending) FLUSH(h);  // "everything requested so far" includes deferred rollout steps (env steps in flight stay so)
+    // ... and the launches of pk_env_step_async_d's sub-batches on the handle's internal streams (pk_set_env_batches)
+    for (int b = 0; b < h->env_batches && h->env_batches > 1; ++b)
+        if (h->env_launched[b]) HIPCHK(h, hipStreamWaitEvent(h->stream, h->env_done[b], 0));
     HIPCHK(h, hipEventRecord((hipEvent_t)event, h->stream));
     return PK_OK;
 }
