@@ -253,6 +253,30 @@ static int export_to_host(pk_handle *h, void *out, size_t bytes, F launch) {
     return PK_OK;
 }
 
+// Streams are RECYCLED through a per-device pool instead of being destroyed with their handle.  HIP maps the streams a process
+// creates onto a few hardware queues in creation order (4 by default), and a destroyed stream does not give its place back: a
+// process that had created and closed a few handles found the four streams of a sub-batched env handle (pk_set_env_batches: the
+// handle's own + three internal ones) sharing queues, and the cross-stream waits serialised -- 2.55 G env.step/s instead of 3.5 G
+// for the same call sequence in a fresh process (bench.py's extra legs).  A recycled stream keeps its queue.
+static std::mutex g_stream_mu;
+static std::vector<hipStream_t> g_stream_pool[PK_MAX_DEVICES];
+static hipError_t stream_acquire(int device, hipStream_t *out) {   // the device is current
+    if (device >= 0 && device < PK_MAX_DEVICES) {
+        std::lock_guard<std::mutex> lock(g_stream_mu);
+        auto &pool = g_stream_pool[device];
+        if (!pool.empty()) { *out = pool.back(); pool.pop_back(); return hipSuccess; }
+    }
+    return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+}
+static void stream_release(int device, hipStream_t s) {           // the device is current; s is idle or about to be
+    if (!s) return;
+    (void)hipStreamSynchronize(s);
+    if (device >= 0 && device < PK_MAX_DEVICES) {
+        std::lock_guard<std::mutex> lock(g_stream_mu);
+        g_stream_pool[device].push_back(s);
+    } else (void)hipStreamDestroy(s);
+}
+
 static int check_device_any() {
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -340,7 +364,7 @@ int pk_create(pk_handle **out, int device, int num_tables, int num_players, cons
     auto bail = [&](int code) { g_err = h->err; pk_destroy(h); return code; };
     DeviceGuard guard(device);
     if (!guard.ok) return bail(h->fail(PK_E_HIP, "hipSetDevice"));
-    if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) return bail(h->fail(PK_E_HIP, "hipStreamCreate"));
+    if (stream_acquire(device, &h->own_stream) != hipSuccess) return bail(h->fail(PK_E_HIP, "hipStreamCreate"));
     h->stream = h->own_stream;
     if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_ring[0], hipEventDisableTiming) != hipSuccess ||
@@ -438,11 +462,11 @@ int pk_destroy(pk_handle *h) {
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     for (int i = 0; i < 2; ++i) if (h->ev_ring[i]) (void)hipEventDestroy(h->ev_ring[i]);
     for (int b = 0; b < PK_MAX_ENV_BATCHES; ++b) {
-        if (h->env_streams[b]) { (void)hipStreamSynchronize(h->env_streams[b]); (void)hipStreamDestroy(h->env_streams[b]); }
+        stream_release(h->device, h->env_streams[b]);
         if (h->env_done[b]) (void)hipEventDestroy(h->env_done[b]);
     }
     if (h->env_in) (void)hipEventDestroy(h->env_in);
-    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    stream_release(h->device, h->own_stream);
     delete h;
     return PK_OK;
 }
@@ -846,7 +870,7 @@ int pk_set_env_batches(pk_handle *h, int batches) {
     range = (range + 63) / 64 * 64;                   // whole waves per range
     const int nb = (h->T + range - 1) / range;        // (fewer ranges than asked for when the batch is small)
     for (int b = 0; b < nb && nb > 1; ++b) {
-        if (!h->env_streams[b]) HIPCHK(h, hipStreamCreateWithFlags(&h->env_streams[b], hipStreamNonBlocking));
+        if (!h->env_streams[b]) HIPCHK(h, stream_acquire(h->device, &h->env_streams[b]));
         if (!h->env_done[b]) HIPCHK(h, hipEventCreateWithFlags(&h->env_done[b], hipEventDisableTiming));
         h->env_launched[b] = false;
     }
