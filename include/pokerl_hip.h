@@ -35,8 +35,12 @@ extern "C" {
 
 #define PK_ABI_VERSION 4
 #define PK_MIN_PLAYERS 2
-#define PK_MAX_PLAYERS 15 /* the reference takes any num_players (game.py:246); up to 15 every numpy routine it calls behaves as
-                             for a short array (np.sum: one 8-way block; np.argsort: insertion sort, stable): see DESIGN.md section 9 */
+#define PK_MAX_PLAYERS 16 /* the reference takes any num_players (game.py:246; the deck allows 23).  Up to 16 the numpy routines it
+                             calls are restated exactly: np.sum's eight-lane pairwise blocks (one up to 15 seats, two at 16) and
+                             np.argsort's stable insertion sort (the pinned numpy sorts up to 17 elements that way); from 18 seats on
+                             argsort's order among EQUAL bets -- which decides side pots -- is no longer a rule the reference pins,
+                             and a 17th seat does not fit the 16 nibbles of a policy word: DESIGN.md section 9.  13 ... 16 seats
+                             run kernels that keep part of the table in AGPRs at one wave per SIMD (no scratch memory). */
 #define PK_MAX_ENV_BATCHES 8 /* pk_set_env_batches */
 #define PK_MAX_DEVICES 64 /* the handle-less judger calls keep one scratch arena per device index below this */
 #define PK_NUM_MOVES 7 /* pokerl/enums.py:104-114 PokerMoves */

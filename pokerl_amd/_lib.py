@@ -18,7 +18,7 @@ ACTION_SKIP = -2   # pk_env_step_multi_d: leave an idle table alone (PK_ACTION_S
 POLICY_EXTERNAL = 15
 ABI_VERSION = 4
 NUM_COUNTERS = 4
-MIN_PLAYERS, MAX_PLAYERS = 2, 15
+MIN_PLAYERS, MAX_PLAYERS = 2, 16
 
 # every symbol include/pokerl_hip.h declares (tests check the library exports each one)
 SYMBOLS = ["pk_abi_version", "pk_device_count", "pk_last_error", "pk_create", "pk_destroy", "pk_num_tables",

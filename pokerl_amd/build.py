@@ -16,7 +16,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-ffp-contract=off", "-fn
          "-fgpu-rdc=0" if False else "-Wall", "-Wno-unused-function"]
 
 
-SEATS = list(range(2, 16))   # one object per seat count (pk_tables.hip -DPK_SEATS=N), PK_MIN_PLAYERS .. PK_MAX_PLAYERS
+SEATS = list(range(2, 17))   # one object per seat count (pk_tables.hip -DPK_SEATS=N), PK_MIN_PLAYERS .. PK_MAX_PLAYERS
 OBJ = os.path.join(HERE, "_obj")
 SOURCES = ["pk_api.hip", "pk_tables.hip"]
 COMPILE_FLAGS = [f for f in FLAGS if f != "-shared"]

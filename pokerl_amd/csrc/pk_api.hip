@@ -117,8 +117,8 @@ struct DeviceGuard {
 #define PK_SEAT_ENABLED(N) 1
 #endif
 #define PK_FOR_SEATS_LE10(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10)
-#define PK_FOR_SEATS_GT10(X) X(11) X(12) X(13) X(14) X(15)
-static_assert(PK_MIN_PLAYERS == 2 && PK_MAX_PLAYERS == 15, "the lists above name the seat counts");
+#define PK_FOR_SEATS_GT10(X) X(11) X(12) X(13) X(14) X(15) X(16)
+static_assert(PK_MIN_PLAYERS == 2 && PK_MAX_PLAYERS == 16, "the lists above name the seat counts");
 #define PK_DECLARE_ALL(N) PK_TABLE_KERNELS(PK_DECLARE_KERNEL, N)
 #define PK_DECLARE_ALL_LE10(N) PK_TABLE_KERNELS_LE10(PK_DECLARE_KERNEL, N)
 PK_FOR_SEATS_LE10(PK_DECLARE_ALL)
@@ -150,6 +150,7 @@ static inline bool seat_count_built(int n) {
             case 13: if constexpr (PK_SEAT_ENABLED(13)) hipLaunchKernelGGL(KERNEL<13>, g_, b_, 0, strm_, __VA_ARGS__); break; \
             case 14: if constexpr (PK_SEAT_ENABLED(14)) hipLaunchKernelGGL(KERNEL<14>, g_, b_, 0, strm_, __VA_ARGS__); break; \
             case 15: if constexpr (PK_SEAT_ENABLED(15)) hipLaunchKernelGGL(KERNEL<15>, g_, b_, 0, strm_, __VA_ARGS__); break; \
+            case 16: if constexpr (PK_SEAT_ENABLED(16)) hipLaunchKernelGGL(KERNEL<16>, g_, b_, 0, strm_, __VA_ARGS__); break; \
         } \
     } while (0)
 #define DISPATCH_N(h, KERNEL, grid, ...) DISPATCH_N_ON(h, (h)->stream, KERNEL, grid, __VA_ARGS__)
@@ -315,8 +316,9 @@ int pk_create(pk_handle **out, int device, int num_tables, int num_players, cons
     *out = nullptr;
     if (num_tables < 1 || num_players < PK_MIN_PLAYERS || num_players > PK_MAX_PLAYERS) {
         g_err = "pk_create: need num_tables >= 1 and " PK_STR(PK_MIN_PLAYERS) " <= num_players <= " PK_STR(PK_MAX_PLAYERS)
-                " (the reference takes any num_players, game.py:246; beyond " PK_STR(PK_MAX_PLAYERS) " seats numpy's argsort of the bets, "
-                "game.py:495, is no longer a stable insertion sort, so the side-pot order among equal bets is not a rule the reference pins: DESIGN.md section 9)";
+                " (the reference takes any num_players, game.py:246; a 17th seat does not fit the 16 nibbles of a policy word, and from 18 seats on "
+                "numpy's argsort of the bets, game.py:495, is no longer a stable insertion sort, so the side-pot order among equal bets is not a "
+                "rule the reference pins: DESIGN.md section 9)";
         return PK_E_INVALID_ARG;
     }
     if (!seat_count_built(num_players)) { g_err = "pk_create: this development build of the library holds one seat count only (PK_ONLY_SEATS)"; return PK_E_INVALID_ARG; }

@@ -105,8 +105,9 @@ __device__ __forceinline__ double vmax(const double (&a)[N]) {  // np.max
     PK_FOR(p, N) if (p > 0) m = (a[p] > m) ? a[p] : m; PK_END
     return m;
 }
-// np.sum over contiguous f64[N] in numpy's association order: N<8 left to right;
-// 8<=N<16: ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) then the tail left to right.
+// np.sum over contiguous f64[N] in numpy's association order (numpy's pairwise_sum for n <= 128): N<8 left to
+// right; N>=8: eight partial sums r[j] = a[j] (+ a[8+j] + ... one whole block of eight at a time), combined
+// ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), then the tail left to right -- one block up to 15 seats, two at 16.
 template <int N>
 __device__ __forceinline__ double np_sum(const double (&a)[N]) {
     if constexpr (N < 8) {
@@ -114,9 +115,12 @@ __device__ __forceinline__ double np_sum(const double (&a)[N]) {
         PK_FOR(p, N) if (p > 0) r = r + a[p]; PK_END
         return r;
     } else {
-        static_assert(N < 16, "np_sum: second block of 8 not implemented");
-        double r = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
-        PK_FOR(p, N) if (p >= 8) r = r + a[p]; PK_END
+        constexpr int BLOCKS = N / 8;
+        double r8[8];
+        PK_FOR(j, 8) r8[j] = a[j]; PK_END
+        PK_FOR(p, N) if constexpr (p >= 8 && p < 8 * BLOCKS) r8[p % 8] = r8[p % 8] + a[p]; PK_END
+        double r = ((r8[0] + r8[1]) + (r8[2] + r8[3])) + ((r8[4] + r8[5]) + (r8[6] + r8[7]));
+        PK_FOR(p, N) if constexpr (p >= 8 * BLOCKS) r = r + a[p]; PK_END
         return r;
     }
 }
@@ -661,6 +665,7 @@ template <int N>
 struct Table {
     static constexpr int K = 5 + 2 * N;      // cards ever read (game.py:278,388-395)
     static constexpr int W = (K + 3) / 4;    // packed words
+    static_assert(N <= 16, "seat bitmasks are 16 bits wide (State::seat_states), policy words hold 16 nibbles");
     static constexpr uint32_t FULL = (1u << N) - 1;
     double credits[N], bets[N], pending[N], payoffs[N];
     double min_raise;

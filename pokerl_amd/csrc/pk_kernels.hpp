@@ -238,30 +238,36 @@ __device__ __forceinline__ void rollout_body(const State *__restrict__ Sp, const
     PK_PROF(tb.prof.flush(S.prof);)
 }
 
+// From 13 seats on the table state no longer fits 256 VGPRs (k_rollout<15> spilled 131 registers to scratch under the two-wave
+// cap in round 3; running the whole side-pot loop per call -- no pot_wb / pot_hv across the betting passes -- did not cure it:
+// the pressure sits inside end_block).  Those instantiations give up the second wave per SIMD instead: one wave may use the
+// unified 512-register file, the compiler parks what does not fit the 256 architectural VGPRs in AGPRs (one v_accvgpr move per
+// access) and nothing goes to scratch memory.  At 65 536 tables a SIMD holds one wave anyway.
+#define PK_WAVES_PER_SIMD_N(N) ((N) <= 12 ? 2 : 1)
 // Batches of up to two waves per SIMD: registers capped at 256 (no instantiation needs more; N = 10 uses 245), which
 // also steers the max-ILP scheduler to a slightly better schedule than an unlimited budget (24.1 vs 23.4 G at 65 536 x 6 when it was introduced) ...
 template <int N>
-__global__ void __launch_bounds__(PK_TABLE_BLOCK, 2) PK_ROLLOUT_ATTR k_rollout(const State *__restrict__ Sp, Hot H, int K, int auto_reset, int park, int slack, int clear_terr) {
+__global__ void __launch_bounds__(PK_TABLE_BLOCK, PK_WAVES_PER_SIMD_N(N)) PK_ROLLOUT_ATTR k_rollout(const State *__restrict__ Sp, Hot H, int K, int auto_reset, int park, int slack, int clear_terr) {
     rollout_body<N, true, PK_POLICY_RANDOM>(Sp, H, K, auto_reset, park, slack, clear_terr);
 }
 template <int N>
-__global__ void __launch_bounds__(PK_TABLE_BLOCK, 2) PK_ROLLOUT_ATTR k_rollout_allin(const State *__restrict__ Sp, Hot H, int K, int auto_reset, int park, int slack, int clear_terr) {
+__global__ void __launch_bounds__(PK_TABLE_BLOCK, PK_WAVES_PER_SIMD_N(N)) PK_ROLLOUT_ATTR k_rollout_allin(const State *__restrict__ Sp, Hot H, int K, int auto_reset, int park, int slack, int clear_terr) {
     rollout_body<N, true, PK_POLICY_ALLIN>(Sp, H, K, auto_reset, park, slack, clear_terr);
 }
 // Game.step (game.py:621-700) with the caller's actions, and the single-step form of the random-agent rollout (pk_rollout
 // with fused == 0: the state round-trips HBM every step): the same body with one betting pass per look at the parked lanes.
 template <int N>
-__global__ void __launch_bounds__(PK_TABLE_BLOCK, 2) k_step(StepKernArgs) {
+__global__ void __launch_bounds__(PK_TABLE_BLOCK, PK_WAVES_PER_SIMD_N(N)) k_step(StepKernArgs) {
     const StepKernArgs *ka = (const StepKernArgs *)__builtin_amdgcn_kernarg_segment_ptr();
     const Hot H = ka->H;
     rollout_body<N, false, PK_POLICY_EXTERNAL, 1>(ka->Sp, H, 0, 0, ka->park, PK_WAVE, 1, ka->actions, ka);
 }
 template <int N>
-__global__ void __launch_bounds__(PK_TABLE_BLOCK, 2) k_rollout_single(const State *__restrict__ Sp, Hot H, int K, int auto_reset, int park, int slack, int clear_terr) {
+__global__ void __launch_bounds__(PK_TABLE_BLOCK, PK_WAVES_PER_SIMD_N(N)) k_rollout_single(const State *__restrict__ Sp, Hot H, int K, int auto_reset, int park, int slack, int clear_terr) {
     rollout_body<N, false, PK_POLICY_RANDOM, 1>(Sp, H, K, auto_reset, park, slack, clear_terr);
 }
 template <int N>
-__global__ void __launch_bounds__(PK_TABLE_BLOCK, 2) PK_ROLLOUT_ATTR k_rollout_call(const State *__restrict__ Sp, Hot H, int K, int auto_reset, int park, int slack, int clear_terr) {
+__global__ void __launch_bounds__(PK_TABLE_BLOCK, PK_WAVES_PER_SIMD_N(N)) PK_ROLLOUT_ATTR k_rollout_call(const State *__restrict__ Sp, Hot H, int K, int auto_reset, int park, int slack, int clear_terr) {
     rollout_body<N, true, PK_POLICY_CALL>(Sp, H, K, auto_reset, park, slack, clear_terr);
 }
 // ... the same capped at 168 registers for three waves per SIMD.  Up to six seats k_rollout is below the cap anyway
@@ -657,9 +663,9 @@ __device__ __forceinline__ void env_step_body() {
 template <int N>
 __global__ void __launch_bounds__(PK_TABLE_BLOCK) k_env_step(EnvKernArgs) { env_step_body<N, false, false>(); }
 template <int N>
-__global__ void __launch_bounds__(PK_TABLE_BLOCK, (N <= 6 ? 3 : 2)) k_env_step_async(EnvKernArgs) { env_step_body<N, true, false>(); }
+__global__ void __launch_bounds__(PK_TABLE_BLOCK, (N <= 6 ? 3 : PK_WAVES_PER_SIMD_N(N))) k_env_step_async(EnvKernArgs) { env_step_body<N, true, false>(); }
 template <int N>
-__global__ void __launch_bounds__(PK_TABLE_BLOCK, 2) k_env_step_multi(EnvKernArgs) { env_step_body<N, true, true>(); }
+__global__ void __launch_bounds__(PK_TABLE_BLOCK, PK_WAVES_PER_SIMD_N(N)) k_env_step_multi(EnvKernArgs) { env_step_body<N, true, true>(); }
 
 #ifndef PK_TABLES_ONLY
 // ---- exports: device-side conversion from the SoA/bitmask layout to the reference's table-major arrays
@@ -800,9 +806,14 @@ __global__ void k_table_f64(State S, int N, int field, double *out) {
         if (N < 8) {
             r = a[t];
             for (int p = 1; p < N; ++p) r = r + a[(size_t)p * T + t];
-        } else {
-            r = ((a[t] + a[T + t]) + (a[2 * T + t] + a[3 * T + t])) + ((a[4 * T + t] + a[5 * T + t]) + (a[6 * T + t] + a[7 * T + t]));
-            for (int p = 8; p < N; ++p) r = r + a[(size_t)p * T + t];
+        } else {   // numpy's pairwise_sum: eight partial sums over whole blocks of eight, the tree, then the tail
+            double r8[8];
+            for (int j = 0; j < 8; ++j) r8[j] = a[(size_t)j * T + t];
+            int p = 8;
+            for (; p + 8 <= N; p += 8)
+                for (int j = 0; j < 8; ++j) r8[j] = r8[j] + a[(size_t)(p + j) * T + t];
+            r = ((r8[0] + r8[1]) + (r8[2] + r8[3])) + ((r8[4] + r8[5]) + (r8[6] + r8[7]));
+            for (; p < N; ++p) r = r + a[(size_t)p * T + t];
         }
     } else if (field == PK_TF_HIGH_BET) {
         r = S.pending[t];

@@ -496,6 +496,8 @@ GAME_SETS = {
     # round 3: more than ten seats (PK_MAX_PLAYERS 15: np.sum's unrolled block once, np.argsort's insertion sort)
     "game_n12_random": (12, R.POLICY_RANDOM, 1212, 4, 160, 3, None),
     "game_n15_random": (15, R.POLICY_RANDOM, 1515, 4, 160, 0, dict(start_credits=50, big_blind=4, small_blind=2)),
+    # round 4: sixteen seats (PK_MAX_PLAYERS 16: np.sum runs its unrolled block of eight TWICE, np.argsort is still the insertion sort)
+    "game_n16_random": (16, R.POLICY_RANDOM, 1616, 4, 160, 0, dict(start_credits=50, big_blind=4, small_blind=2)),
 }
 # odd configurations found worth pinning by tests/golden/fuzz_oracle_vs_reference.py: (n, policy, seed, tables, steps, base, cfg, dealer)
 # resumed RNG streams: hand_serial crosses 2^32 and the action block index (step_serial >> 3) crosses 2^32 mid-run
@@ -507,6 +509,7 @@ VIEW_SETS = {
     "views_n6_random": (6, R.POLICY_RANDOM, SEED ^ 0x77, 4, 60, 0, None),
     "views_n3_percredits": (3, R.POLICY_RANDOM, 7, 4, 60, 77, dict(start_credits=[30, 100, 5], big_blind=4, small_blind=2)),
     "views_n13_random": (13, R.POLICY_RANDOM, 1313, 2, 24, 0, None),
+    "views_n16_random": (16, R.POLICY_RANDOM, 1616, 2, 24, 3, None),
 }
 ODD_SETS = {
     "game_n5_zero_blinds": (5, R.POLICY_RANDOM, 21, 6, 150, 9, dict(start_credits=10, big_blind=0, small_blind=0), 3),
@@ -515,6 +518,8 @@ ODD_SETS = {
     "game_n8_mixed_allin": (8, R.POLICY_ALLIN, 24, 6, 100, 0, dict(start_credits=[1, 2, 3, 5, 10, 100, 1000, 0.5], big_blind=3, small_blind=1), 0),
     "game_n14_mixed_allin": (14, R.POLICY_ALLIN, 1414, 4, 100, 77,
                              dict(start_credits=[1, 2, 3, 5, 10, 100, 1000, 0.5, 37.5, 3, 2, 10, 5, 100], big_blind=3, small_blind=1), 11),
+    "game_n16_mixed_allin": (16, R.POLICY_ALLIN, 1616, 4, 100, 5,
+                             dict(start_credits=[1, 2, 3, 5, 10, 100, 1000, 0.5, 37.5, 3, 2, 10, 5, 100, 7, 2], big_blind=3, small_blind=1), 13),
 }
 # Configurations whose payoffs DEPEND on the order in which np.argsort(bets) (game.py:495) returns seats with EQUAL bets
 # (found with the fuzz generator): the reference with its pinned numpy (stable), which the fixtures pin, differs from the
@@ -523,6 +528,8 @@ ODD_SETS = {
 TIE_SETS = {
     "game_n8_argsort_tie": (8, R.POLICY_RANDOM, 349423999861, 4, 100, 0, dict(start_credits=1, big_blind=40, small_blind=2)),
     "game_n9_argsort_tie": (9, R.POLICY_RANDOM, 141532477888, 4, 100, 0, dict(start_credits=10, big_blind=7.5, small_blind=40)),
+    # sixteen seats: the widest table whose argsort the pinned numpy still insertion-sorts (found by scanning seeds, round 4)
+    "game_n16_argsort_tie": (16, R.POLICY_RANDOM, 1001, 4, 60, 0, dict(start_credits=1, big_blind=40, small_blind=2)),
 }
 # The one configuration of the fuzz (tests/golden/fuzz_oracle_vs_reference.py, round 200 of its generator) on which the
 # reference DOES return from a Game.step that rolls more than PK_HAND_CAP = 4 096 hands (5 204 of them, step 9): the product
@@ -545,6 +552,7 @@ DIGEST_SETS = {
     "digest_n6_shard1": (6, R.POLICY_RANDOM, SEED, 32, 1000, 65536, None),  # table_id_base of rank 1 at C4
     "digest_n6_shard7": (6, R.POLICY_RANDOM, SEED, 32, 1000, 7 * 65536, None),  # ... of rank 7 (last shard of 524 288)
     "digest_n15_random": (15, R.POLICY_RANDOM, SEED, 16, 800, 0, None),
+    "digest_n16_random": (16, R.POLICY_RANDOM, SEED, 16, 800, 0, None),
 }
 ENV_SETS = {
     "env_n4_random": (4, R.POLICY_RANDOM, R.POLICY_RANDOM, SEED, 8, 200, 0, None),
@@ -569,6 +577,11 @@ ENV_SETS = {
     "env_n12_mixed_opponents": (12, R.POLICY_RANDOM, [R.POLICY_RANDOM, R.POLICY_ALLIN, R.POLICY_RANDOM, R.POLICY_CALL, R.POLICY_RANDOM, R.POLICY_RANDOM,
                                                      R.POLICY_ALLIN, R.POLICY_CALL, R.POLICY_ALLIN, R.POLICY_RANDOM, R.POLICY_CALL],
                                 1212, 4, 100, 9, dict(start_credits=40, big_blind=4, small_blind=2)),
+    # sixteen seats: one agent per opponent seat, the policy nibble of seat 15 in bits 60..63 of the word
+    "env_n16_mixed_opponents": (16, R.POLICY_RANDOM, [R.POLICY_RANDOM, R.POLICY_ALLIN, R.POLICY_RANDOM, R.POLICY_CALL, R.POLICY_RANDOM, R.POLICY_RANDOM,
+                                                     R.POLICY_ALLIN, R.POLICY_CALL, R.POLICY_ALLIN, R.POLICY_RANDOM, R.POLICY_CALL, R.POLICY_RANDOM,
+                                                     R.POLICY_CALL, R.POLICY_RANDOM, R.POLICY_ALLIN],
+                                1616, 4, 100, 16, dict(start_credits=40, big_blind=4, small_blind=2)),
 }
 
 

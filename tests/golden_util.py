@@ -155,10 +155,12 @@ GAME_SETS = ["game_n2_random", "game_n6_random", "game_n9_random", "game_n6_alli
              "game_n4_example_cfg", "game_n3_percredits", "game_n10_random", "game_n2_noreset", "game_n3_noreset",
              "game_n5_zero_blinds", "game_n4_sb_gt_bb_fractional", "game_n7_blinds_gt_stacks", "game_n8_mixed_allin",
              "game_n6_serial_hi", "game_n8_argsort_tie", "game_n9_argsort_tie", "game_n6_hand_cap",
-             "game_n12_random", "game_n15_random", "game_n14_mixed_allin"]
+             "game_n12_random", "game_n15_random", "game_n14_mixed_allin",
+             "game_n16_random", "game_n16_mixed_allin", "game_n16_argsort_tie"]
 DIGEST_SETS = ["digest_n2_random", "digest_n6_random", "digest_n9_random", "digest_n9_allin", "digest_n6_shard1",
-               "digest_n6_shard7", "digest_n15_random"]
-VIEW_SETS = ["views_n6_random", "views_n3_percredits", "views_n13_random"]
+               "digest_n6_shard7", "digest_n15_random", "digest_n16_random"]
+VIEW_SETS = ["views_n6_random", "views_n3_percredits", "views_n13_random", "views_n16_random"]
 ENV_SETS = ["env_n4_random", "env_n6_random", "env_n6_vs_allin", "env_n2_random", "env_n5_percredits",
             "env_n9_random_hi_base", "env_n3_big_blinds_vs_allin", "env_n3_vs_call", "env_n4_mixed_opponents",
-            "env_n6_mixed_percredits", "env_n2_call_vs_call", "env_n11_random", "env_n12_mixed_opponents"]
+            "env_n6_mixed_percredits", "env_n2_call_vs_call", "env_n11_random", "env_n12_mixed_opponents",
+            "env_n16_mixed_opponents"]

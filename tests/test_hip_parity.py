@@ -364,8 +364,8 @@ def test_observation_and_cards(HB, O):
 
 
 def test_all_player_counts_fused_vs_oracle(HB, O):
-    """Every template instantiation (N = 2..15), ragged table count, both policies."""
-    for N in range(2, 16):
+    """Every template instantiation (N = 2..16), ragged table count, both policies."""
+    for N in range(2, 17):
         for policy in (0, 1):
             T, K = 1000 + N, 150
             o = O.OracleGame(T, N, seed=N * 17 + policy)

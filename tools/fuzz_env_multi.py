@@ -27,7 +27,7 @@ stacks = [2, 5, 10, 37.5, 100, 1000]
 blinds = [0.5, 1, 2, 3, 7.5, 40]
 delivered = yields = 0
 for i in range(n_cfg):
-    N = 2 + i % 14
+    N = 2 + i % 15   # 2 ... 16 seats
     start = [rng.choice(stacks) for _ in range(N)] if rng.random() < 0.5 else rng.choice(stacks)
     bb, sb = rng.choice(blinds), rng.choice(blinds)
     # shoving or random opponents for the caller's seats: calling stations would play endless games once seat 0 is broke

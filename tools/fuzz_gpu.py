@@ -30,7 +30,7 @@ def same(a, b, where):
 
 steps = 0
 for i in range(n_cfg):
-    N = 2 + i % 14
+    N = 2 + i % 15   # 2 ... 16 seats
     start = [rng.choice(stacks) for _ in range(N)] if rng.random() < 0.5 else rng.choice(stacks)
     bb, sb = rng.choice(blinds), rng.choice(blinds)
     policy = 1 if rng.random() < 0.25 else 0

@@ -144,14 +144,15 @@ static int fuzz(int rounds, int T, int K) {
     int bad = 0;
     for (int i = 0; i < rounds; ++i) {
         uint64_t r = 0x9E3779B97F4A7C15ull * (uint64_t)(i + 1);
-        switch (i % 14) {
+        switch (i % 15) {
             case 0: bad += fuzz_one<2>(r, T, K); break; case 1: bad += fuzz_one<3>(r, T, K); break;
             case 2: bad += fuzz_one<4>(r, T, K); break; case 3: bad += fuzz_one<5>(r, T, K); break;
             case 4: bad += fuzz_one<6>(r, T, K); break; case 5: bad += fuzz_one<7>(r, T, K); break;
             case 6: bad += fuzz_one<8>(r, T, K); break; case 7: bad += fuzz_one<9>(r, T, K); break;
             case 8: bad += fuzz_one<10>(r, T, K); break; case 9: bad += fuzz_one<11>(r, T, K); break;
             case 10: bad += fuzz_one<12>(r, T, K); break; case 11: bad += fuzz_one<13>(r, T, K); break;
-            case 12: bad += fuzz_one<14>(r, T, K); break; default: bad += fuzz_one<15>(r, T, K); break;
+            case 12: bad += fuzz_one<14>(r, T, K); break; case 13: bad += fuzz_one<15>(r, T, K); break;
+            default: bad += fuzz_one<16>(r, T, K); break;
         }
     }
     printf("fuzz: %d configs, %d mismatching\n", rounds, bad);
@@ -175,5 +176,7 @@ int main(int argc, char **argv) {
     rc |= run<10>(T, K, 0, 99);
     rc |= run<13>(T, K, 0, 1313);
     rc |= run<15>(T, K, 1, 1515);
+    rc |= run<16>(T, K, 0, 1616);
+    rc |= run<16>(T, K, 1, 1616);
     return rc;
 }
