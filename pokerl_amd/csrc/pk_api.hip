@@ -260,21 +260,35 @@ static int export_to_host(pk_handle *h, void *out, size_t bytes, F launch) {
 // handle's own + three internal ones) sharing queues, and the cross-stream waits serialised -- 2.55 G env.step/s instead of 3.5 G
 // for the same call sequence in a fresh process (bench.py's extra legs).  A recycled stream keeps its queue.
 static std::mutex g_stream_mu;
-static std::vector<hipStream_t> g_stream_pool[PK_MAX_DEVICES];
-static hipError_t stream_acquire(int device, hipStream_t *out) {   // the device is current
+static std::vector<hipStream_t> g_stream_pool[PK_MAX_DEVICES][2];   // [device][0: normal priority, 1: the sub-batch streams]
+// The internal streams of pk_set_env_batches are created with the HIGHEST stream priority: HIP keeps separate hardware queues per
+// priority level, so they do not compete for the four normal-priority queues with the caller's stream, the legacy default stream
+// (one hipMemcpy or one torch kernel brings it to life) and whatever else the process has created -- with normal-priority streams a
+// process that had merely made one hipMemcpy before creating the handle found two of the four streams sharing a queue and the
+// cross-stream waits serialising (524 288 x 6, three sub-batches: 2.57 G env.step/s against 3.66 G).  env PK_ENV_STREAM_PRIO=0: off.
+static hipError_t stream_acquire(int device, hipStream_t *out, bool sub_batch = false) {   // the device is current
+    static const bool prio = !(getenv("PK_ENV_STREAM_PRIO") && atoi(getenv("PK_ENV_STREAM_PRIO")) == 0);
+    const int cls = (sub_batch && prio) ? 1 : 0;
     if (device >= 0 && device < PK_MAX_DEVICES) {
         std::lock_guard<std::mutex> lock(g_stream_mu);
-        auto &pool = g_stream_pool[device];
+        auto &pool = g_stream_pool[device][cls];
         if (!pool.empty()) { *out = pool.back(); pool.pop_back(); return hipSuccess; }
+    }
+    if (cls == 1) {
+        int least = 0, greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least)
+            return hipStreamCreateWithPriority(out, hipStreamNonBlocking, greatest);
+        (void)hipGetLastError();
     }
     return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
 }
-static void stream_release(int device, hipStream_t s) {           // the device is current; s is idle or about to be
+static void stream_release(int device, hipStream_t s, bool sub_batch = false) {   // the device is current; s is idle or about to be
     if (!s) return;
     (void)hipStreamSynchronize(s);
+    static const bool prio = !(getenv("PK_ENV_STREAM_PRIO") && atoi(getenv("PK_ENV_STREAM_PRIO")) == 0);
     if (device >= 0 && device < PK_MAX_DEVICES) {
         std::lock_guard<std::mutex> lock(g_stream_mu);
-        g_stream_pool[device].push_back(s);
+        g_stream_pool[device][(sub_batch && prio) ? 1 : 0].push_back(s);
     } else (void)hipStreamDestroy(s);
 }
 
@@ -464,7 +478,7 @@ int pk_destroy(pk_handle *h) {
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     for (int i = 0; i < 2; ++i) if (h->ev_ring[i]) (void)hipEventDestroy(h->ev_ring[i]);
     for (int b = 0; b < PK_MAX_ENV_BATCHES; ++b) {
-        stream_release(h->device, h->env_streams[b]);
+        stream_release(h->device, h->env_streams[b], true);
         if (h->env_done[b]) (void)hipEventDestroy(h->env_done[b]);
     }
     if (h->env_in) (void)hipEventDestroy(h->env_in);
@@ -872,7 +886,7 @@ int pk_set_env_batches(pk_handle *h, int batches) {
     range = (range + 63) / 64 * 64;                   // whole waves per range
     const int nb = (h->T + range - 1) / range;        // (fewer ranges than asked for when the batch is small)
     for (int b = 0; b < nb && nb > 1; ++b) {
-        if (!h->env_streams[b]) HIPCHK(h, stream_acquire(h->device, &h->env_streams[b]));
+        if (!h->env_streams[b]) HIPCHK(h, stream_acquire(h->device, &h->env_streams[b], true));
         if (!h->env_done[b]) HIPCHK(h, hipEventCreateWithFlags(&h->env_done[b], hipEventDisableTiming));
         h->env_launched[b] = false;
     }

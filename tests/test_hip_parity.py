@@ -450,7 +450,8 @@ def test_bad_arguments_are_reported_not_fatal(HB):
     from pokerl_amd import _lib as L
     lib = L.lib()
     h = C.c_void_p()
-    assert lib.pk_create(C.byref(h), 0, 16, 16, None, 100.0, 2.0, 1.0, 0, 1, 0) == L.PK_E_INVALID_ARG   # N > 15
+    assert lib.pk_create(C.byref(h), 0, 16, 17, None, 100.0, 2.0, 1.0, 0, 1, 0) == L.PK_E_INVALID_ARG   # N > 16
+    assert lib.pk_create(C.byref(h), 0, 16, 6, None, float('inf'), 2.0, 1.0, 0, 1, 0) == L.PK_E_INVALID_ARG and b"finite" in lib.pk_last_error(None)
     assert lib.pk_create(C.byref(h), 0, 0, 4, None, 100.0, 2.0, 1.0, 0, 1, 0) == L.PK_E_INVALID_ARG     # T < 1
     assert lib.pk_create(C.byref(h), 99, 16, 4, None, 100.0, 2.0, 1.0, 0, 1, 0) == L.PK_E_INVALID_ARG   # no such device
     assert b"device" in lib.pk_last_error(None)

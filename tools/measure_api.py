@@ -11,7 +11,10 @@ D = 17 + 3 * N
 
 
 def rate(name, fn, n=50, unit="table-ops/s", post=None):
-    fn(); t0 = time.perf_counter()
+    out = fn()
+    if post:
+        post(out)
+    t0 = time.perf_counter()
     for _ in range(n):
         out = fn()
         if post:
