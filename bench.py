@@ -607,6 +607,16 @@ def extra_workloads(ctx, device):
                     "ms_per_step": w["seconds"] / (w["K"] * w["reps"]) * 1e3, "steps_per_sample": w["K"] * w["reps"], "samples": len(w["sample_s"]),
                     "kernel": kernel_description(w), "kernel_ms": w["ms_launch"], "launches": w["launches"],
                     "launch_stats": w["stats"], "roofline": rollout_roofline(w, ctx.world)})
+    # the driver's own call pattern WITHOUT host-side merging: what a caller that observes the tables between its 20-step calls
+    # gets (every getter flushes), beside the headline figure, which holds for a caller that does not
+    w = rollout_workload(ctx, device, 65536, 6, "random", K=20, warmup=5, min_steps=131072, samples=3, coalesce=0)
+    out.append({"name": "BASELINE configs[2] in 20-step calls, one launch per call (pk_set_coalesce(0)): the rate of a caller that "
+                        "observes the tables between calls",
+                "metric": "env-steps/s", "value": w["total_steps"] / w["seconds"], "unit": "env-steps/s",
+                "hand_evals_per_s": w["hand_evals_per_s"], "hands_per_s": w["hands_per_s"],
+                "ms_per_step": w["seconds"] / (w["K"] * w["reps"]) * 1e3, "steps_per_sample": w["K"] * w["reps"], "samples": len(w["sample_s"]),
+                "kernel": kernel_description(w), "kernel_ms": w["ms_launch"], "launches": w["launches"],
+                "launch_stats": w["stats"], "roofline": rollout_roofline(w, ctx.world)})
     for name, kw in (("PokerGameEnv.step synchronous (pk_env_step_fused_d), 65 536 x 6", dict(tables=65536, players=6, steps=1000, warmup=50)),
                      ("PokerGameEnv.step asynchronous (pk_env_step_async_d, 8 betting passes per launch), one handle of 65 536 x 6",
                       dict(tables=65536, players=6, async_passes=8, steps=4000, warmup=300)),

@@ -209,7 +209,11 @@ int pk_rollout(pk_handle *h, int k_steps, int policy, int auto_reset, int fused,
  * as soon as a launch slot frees up, when it reaches `max_steps`, or by the flush every observer issues -- so a stream of
  * short calls (20 steps each) runs as launches of up to max_steps steps and pays the fixed cost of a launch once per
  * launch, not per call.  Invisible like deferral: no entry point can observe fewer than the requested steps.
- * max_steps: 0 = every call launches at once; default 1024 (env PK_COALESCE). */
+ * max_steps: 0 = every call launches at once; default 1024 (env PK_COALESCE).
+ * What it buys depends on the CALLER: a loop that never looks at the tables between calls (bench.py's command: 20-step calls)
+ * runs as ~1 000-step launches (30 G env-steps/s at 65 536 x 6); a caller that reads observations or rewards every 20 steps
+ * flushes each time and gets the one-launch-per-call rate (21 G: bench.py's extra leg "one launch per call").  Held steps start
+ * with the next pk_rollout, flush, getter or pk_wait_event -- not by themselves. */
 int pk_set_coalesce(pk_handle *h, int max_steps);
 /* Launches of the rollout kernel since the last reset: out[4] = {launches (including the 0-step flushes of deferred
  * work), steps summed over them, min and max steps per launch over the launches with steps}.  reset != 0 clears them. */
@@ -343,6 +347,8 @@ int pk_env_last_range(pk_handle *h, int *begin, int *end, int *fresh);
  *   ready_d[t] = 0  the pass budget ran out first (only with max_passes > 0); supply nothing;
  *   ready_d[t] = 3  the table was idle and actions_d[t] was PK_ACTION_SKIP: left alone, no output written (how a caller
  *                   that serves the yielded tables keeps the tables that have already returned out of further launches).
+ *                   PK_ACTION_SKIP is honoured WHATEVER seat 0's agent is: also with an in-kernel policy in nibble 0 (where
+ *                   actions_d[t] is otherwise ignored for idle tables) a -2 parks the table -- write 0 there, not stale data.
  * who_d[t] is always the seat to act next.  reset_d (may be NULL): reset_d[t] != 0 starts PokerGameEnv.reset()
  * (game_env.py:20-29) on table t instead of a step -- delivered like a step, with reward 0, done 0, hand 0 -- dropping
  * whatever that table had in flight.  max_passes <= 0: run until every table has returned or yielded.

@@ -521,6 +521,9 @@ int pk_use_own_stream(pk_handle *h) {
 int pk_wait_event(pk_handle *h, void *event) {
     if (!h || !event) return PK_E_INVALID_ARG;
     ON_DEVICE(h);
+    // rollout steps the host still holds back (coalescing) were requested BEFORE this wait: launch them now, so that they do not
+    // queue up behind the caller's event (and overlap with whatever the caller does until it records it)
+    if (!h->env_pending && h->acc > 0) { int rc = launch_coalesced(h, h->pend_policy, h->pend_auto); if (rc) return rc; }
     HIPCHK(h, hipStreamWaitEvent(h->stream, (hipEvent_t)event, 0));
     return PK_OK;
 }

@@ -708,7 +708,8 @@ def test_bench_json_contract():
     assert cm["half_rate_share_source"] and 0.4 < cm["half_rate_share"] < 0.8
     # the other single-GPU BASELINE configs and the PokerGameEnv path are driver-timed legs of the same line
     xs = r["extra_workloads"]
-    assert len(xs) == 5 and [("configs[1]" in xs[0]["name"]), ("configs[4]" in xs[1]["name"])] == [True, True]
+    assert len(xs) == 6 and [("configs[1]" in xs[0]["name"]), ("configs[4]" in xs[1]["name"])] == [True, True]
+    assert "one launch per call" in xs[2]["name"] and xs[2]["launch_stats"]["max"] == 20 and xs[2]["value"] < r["value"]
     for x in xs:
         for k in ("name", "value", "unit", "kernel", "kernel_ms", "launches", "roofline"):
             assert k in x, (x.get("name"), k)
@@ -718,10 +719,10 @@ def test_bench_json_contract():
         assert abs(xr["frac"] - xr["achieved"] / xr["peak"]) < 1e-9
     # configs[4] is the showdown-heavy half of the metric: one in-game evaluation per env-step
     assert abs(xs[1]["hand_evals_per_s"] / xs[1]["value"] - 1.0) < 1e-3 and xs[0]["unit"] == xs[1]["unit"] == "env-steps/s"
-    for x in xs[2:]:                                               # PokerGameEnv legs: measured HBM traffic beside the VALU figure
+    for x in xs[3:]:                                               # PokerGameEnv legs: measured HBM traffic beside the VALU figure
         assert x["unit"] == "env.step/s" and x["kernel"].startswith("k_env_step") and 0.0 < x["roofline"]["hbm"]["frac"] <= 1.0
         assert x["roofline"]["traffic"] > 0 and 4.0 < x["game_steps_per_env_step"] < 8.0
-    assert xs[2]["ready_fraction_per_launch"] == 1.0 and 0.3 < xs[3]["ready_fraction_per_launch"] < 1.0
+    assert xs[3]["ready_fraction_per_launch"] == 1.0 and 0.3 < xs[4]["ready_fraction_per_launch"] < 1.0
 
 
 @pytest.mark.parametrize("N,policy", [(6, 0), (9, 1), (2, 0), (10, 0)])
