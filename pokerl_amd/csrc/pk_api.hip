@@ -847,10 +847,16 @@ int pk_env_step_async_d(pk_handle *h, const int32_t *actions_d, int seat0_policy
         h->env_last_begin = 0; h->env_last_end = h->T; h->env_last_fresh = 0;
     } else {
         // the caller's writes so far (actions of the range about to be launched) order before the launch(es) below
-        HIPCHK(h, hipEventRecord(h->env_in, h->stream));
+        // ... unless that stream is IDLE (everything the caller queued there has completed: a host-side learner, bench.py): then
+        // there is nothing to order, and no barrier packet is put into any queue (see the note on the delivery wait below)
+        hipError_t qs = hipStreamQuery(h->stream);
+        if (qs != hipSuccess && qs != hipErrorNotReady) return h->fail(PK_E_HIP, "hipStreamQuery", qs);
+        if (qs == hipErrorNotReady) (void)hipGetLastError();
+        const bool caller_busy = qs == hipErrorNotReady;
+        if (caller_busy) HIPCHK(h, hipEventRecord(h->env_in, h->stream));
         auto launch_range = [&](int b, int passes) -> int {
             const int t0 = b * h->env_range, tend = (t0 + h->env_range < h->T) ? t0 + h->env_range : h->T;
-            HIPCHK(h, hipStreamWaitEvent(h->env_streams[b], h->env_in, 0));
+            if (caller_busy) HIPCHK(h, hipStreamWaitEvent(h->env_streams[b], h->env_in, 0));
             EnvKernArgs ka = env_args(h, actions_d, actions_d ? -1 : seat0_policy, uniform_seats(opp_policy), au, reward_d, done_d, hand_d, terr_d, obs_d);
             ka.A.ready = ready_d; ka.A.max_passes = passes; ka.A.t0 = t0; ka.A.tend = tend;
             DISPATCH_N_ON(h, h->env_streams[b], k_env_step_async, (tend - t0 + h->env_tpb - 1) / h->env_tpb, ka);
@@ -869,7 +875,17 @@ int pk_env_step_async_d(pk_handle *h, const int32_t *actions_d, int seat0_policy
             if (rc) return rc;
             h->env_launched[b] = true;
             h->env_last_fresh = h->env_launched[d] ? 0 : 1;
-            if (h->env_launched[d]) HIPCHK(h, hipStreamWaitEvent(h->stream, h->env_done[d], 0));
+            // Delivery of the range launched longest ago.  The HOST waits for it (it was launched B - 1 calls ago and is done or
+            // nearly so), then the caller's stream needs no device-side dependency at all.  A hipStreamWaitEvent on the caller's
+            // stream is a barrier packet parked at the head of its hardware queue: when that queue happens to share a pipe of the
+            // command processor with one of the range queues (which queues share depends on how many the process created before),
+            // the parked barrier holds that range's dispatches back -- the same call sequence ran at 1.5 G env.step/s in a process
+            // that had used another PokerGameEnv handle before, 3.6 G in a fresh one.  env PK_ENV_HOST_WAIT=0: the device-side wait.
+            static const bool host_wait = !(getenv("PK_ENV_HOST_WAIT") && atoi(getenv("PK_ENV_HOST_WAIT")) == 0);
+            if (h->env_launched[d]) {
+                if (host_wait) HIPCHK(h, hipEventSynchronize(h->env_done[d]));
+                else HIPCHK(h, hipStreamWaitEvent(h->stream, h->env_done[d], 0));
+            }
             h->env_last_begin = d * h->env_range;
             h->env_last_end = (h->env_last_begin + h->env_range < h->T) ? h->env_last_begin + h->env_range : h->T;
             h->env_next = d;
