@@ -15,7 +15,7 @@ from oracle import loader as O  # noqa: E402
 
 SCALE = int(os.environ.get("PK_SOAK_SCALE", "1"))   # PK_SOAK_SCALE=8: 5.8 G env-steps, about four minutes
 CASES = [(65536, 6, 0, 4096 * SCALE), (65536, 9, 1, 2048 * SCALE), (65536, 2, 0, 4096 * SCALE), (16384, 10, 0, 3072 * SCALE),
-         (16384, 13, 0, 2048 * SCALE), (8192, 15, 1, 2048 * SCALE)]
+         (16384, 13, 0, 2048 * SCALE), (8192, 15, 1, 2048 * SCALE), (8192, 16, 0, 2048 * SCALE), (8192, 16, 1, 1024 * SCALE)]
 THREADS = 16
 for T, N, policy, K in CASES:
     t0 = time.time()
