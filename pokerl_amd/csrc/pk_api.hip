@@ -360,7 +360,7 @@ int pk_create(pk_handle **out, int device, int num_tables, int num_players, cons
         if (const char *pk = getenv("PK_TPB")) { int v = atoi(pk); if (v >= 1 && v <= 64) tpb = v; }
         h->tpb = tpb;
         // k_rollout_occ3 (registers capped at 168: three waves per SIMD) only where it was measured to pay: six seats
-        // (k_rollout<6> needs 171 registers since round 3, the capped build 160 without a spill) as soon as a SIMD gets a
+        // (k_rollout<6> needs 171 registers -- profiles/r04_resource_usage.txt --, the capped build 162 without a spill) as soon as a SIMD gets a
         // third wave, i.e. beyond 131 072 tables; seven seats from 262 144 tables (+6..10 %), eight from 524 288 (+5..7 %).
         // Up to five seats k_rollout fits 168 registers by itself; at nine and ten seats the cap spills to scratch and
         // loses 10..35 % at every batch size.
