@@ -322,15 +322,19 @@ int pk_env_step_async_d(pk_handle *h, const int32_t *actions_d, int seat0_policy
  * the handle's tables into B contiguous ranges (whole waves each; fewer than B for a small batch: right after the call pk_env_last_range reports range 0, [0, tables per range)),
  * each with an internal stream.  From then on a call with max_passes > 0
  *   - LAUNCHES one range (round robin), reading actions_d only inside it, and
- *   - DELIVERS the range launched longest ago: the handle's stream waits for that launch, and pk_env_last_range reports
- *     [begin, end): ready_d / reward_d / ... / obs_d are complete in stream order INSIDE that range (and untouched outside).
+ *   - DELIVERS the range launched longest ago: the call WAITS ON THE HOST for that launch (made B - 1 calls ago, so done or
+ *     nearly so; ABI 3 queued a device-side wait on the handle's stream instead, whose barrier packet could stall another range's
+ *     hardware queue -- DESIGN.md section 5), and pk_env_last_range reports [begin, end): ready_d / reward_d / ... / obs_d are
+ *     COMPLETE inside that range when the call returns (and untouched outside).  The launch itself is ordered after the work the
+ *     caller queued on the handle's stream (an event pair) unless that stream is idle, in which case nothing needs ordering.
  *     fresh != 0: that range has not been launched yet since pk_set_env_batches / the last drain -- nothing was written, every
  *     table of it awaits its first action (its observation is the one pk_env_reset_d / pk_get_obs_d left).
  * The range delivered by one call is the range the next call launches, so a learner acts on [begin, end) between two
  * calls.  max_passes <= 0 drains every range and delivers [0, T).  Per table nothing changes: the sequence of steps, outputs
  * and RNG draws is that of the synchronous call.  Call it while no env step is in flight (PK_E_BUSY otherwise).
- * Use B <= 3: HIP gives a process 4 hardware queues, the caller's stream + 3 internal ones use them all, and a fourth internal
- * stream shares a queue and serialises on the cross-stream waits (524 288 tables: 3.31 / 3.56 / 2.56 G at B = 2 / 3 / 4).
+ * Use B <= 3 (524 288 tables: 3.40 / 3.65 / 1.5 G env.step/s at B = 2 / 3 / 4): the internal streams are created with the highest
+ * stream priority -- their own set of hardware queues, apart from the caller's stream, the legacy default stream and whatever else
+ * the process created -- and a fourth one shares a queue with another range.
  * Ranges of >= 131 072 tables are the ones that pay (smaller batches: several handles, each on its own stream). */
 int pk_set_env_batches(pk_handle *h, int batches);
 int pk_env_last_range(pk_handle *h, int *begin, int *end, int *fresh);
