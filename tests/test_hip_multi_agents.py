@@ -482,7 +482,14 @@ def test_env_sub_batches_inside_one_handle(O):
         nth = k % mask.sum(axis=1)
         return ((np.cumsum(mask, axis=1) - 1 == nth[:, None]) & mask).argmax(axis=1).astype(np.int32)
 
-    for T, N, opp, K, passes, B in [(3 * 2048 + 100, 6, 0, 25, 5, 3), (4096, 3, 1, 20, 2, 4), (1000, 9, 0, 15, 7, 8)]:
+    # busy: the handle's stream has unfinished work when the call is made (it waits for an event of ANOTHER handle's long rollout), so
+    # the launch is ordered after the caller's stream with an event pair; otherwise that stream is idle and nothing is recorded at all
+    from pokerl_amd.hipmem import DeviceEvent
+    other = pokerl_amd.VecGame(65536, num_players=6, seed=99)
+    other.reset()
+    other_ev = DeviceEvent()
+    for T, N, opp, K, passes, B, busy in [(3 * 2048 + 100, 6, 0, 25, 5, 3, False), (4096, 3, 1, 20, 2, 4, True), (1000, 9, 0, 15, 7, 8, False),
+                                          (2 * 2048 + 7, 6, 0, 12, 4, 3, True)]:
         D = 17 + 3 * N
         rew, done, hand, terr, obs, ready, act = (DeviceBuffer(T * 8), DeviceBuffer(T), DeviceBuffer(T), DeviceBuffer(T),
                                                   DeviceBuffer(T * D * 8), DeviceBuffer(T), DeviceBuffer(T * 4))
@@ -528,6 +535,10 @@ def test_env_sub_batches_inside_one_handle(O):
             a[idx] = choose(row[idx], count[idx])
             waiting[lb:le] = False
             act.upload(a)
+            if busy:
+                other.rollout(1500, 0, True, True, counters=False)      # ~3 ms of work on ANOTHER stream ...
+                other.record_event(other_ev.handle)
+                g.wait_event(other_ev.handle)                           # ... that this handle's stream now waits for
             env.step_async_d(act.ptr, rew.ptr, done.ptr, hand.ptr, terr.ptr, obs.ptr, ready.ptr, max_passes=passes)
             g.sync()
             db, de, fresh = env.last_range()
@@ -563,3 +574,4 @@ def test_env_sub_batches_inside_one_handle(O):
         assert env.last_range() == (0, T, False) and (ready.download(np.uint8, T) != 0).all()
         assert GU.bits_equal(obs.download(np.float64, T * D).reshape(T, D), g.observations)
         env.close()
+    other.close()
