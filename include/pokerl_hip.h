@@ -292,7 +292,8 @@ int pk_get_obs_packed_d(pk_handle *h, int player, uint8_t *out_d);
  * f64 observation rows (obs) and / or the packed ones (obs_packed); pk_env_step_end waits for them.  With buffers from
  * pk_host_alloc nothing in `begin` blocks and the copies run at PCIe line rate, so the caller's own work -- or the step of
  * ANOTHER handle -- overlaps with them.  Per-table errors are in terr[] after `end` (which does not scan them).  The handle
- * must not be used between the two calls. */
+ * must not be used between the two calls, and EVERY buffer -- actions[] included, which a pinned upload reads when the copy
+ * engine gets to it, not when `begin` returns -- must stay valid and untouched until `end` has returned. */
 int pk_env_step_begin(pk_handle *h, const int32_t *actions, int opp_policy, int auto_reset, double *reward, uint8_t *done,
                       uint8_t *hand, uint8_t *terr, double *obs, uint8_t *obs_packed);
 int pk_env_step_end(pk_handle *h);

@@ -254,18 +254,16 @@ static int export_to_host(pk_handle *h, void *out, size_t bytes, F launch) {
     return PK_OK;
 }
 
-// Streams are RECYCLED through a per-device pool instead of being destroyed with their handle.  HIP maps the streams a process
-// creates onto a few hardware queues in creation order (4 by default), and a destroyed stream does not give its place back: a
-// process that had created and closed a few handles found the four streams of a sub-batched env handle (pk_set_env_batches: the
-// handle's own + three internal ones) sharing queues, and the cross-stream waits serialised -- 2.55 G env.step/s instead of 3.5 G
-// for the same call sequence in a fresh process (bench.py's extra legs).  A recycled stream keeps its queue.
+// Streams are RECYCLED through a per-device pool instead of being destroyed with their handle: a process that opens and closes
+// handles (bench.py's legs, a test suite) keeps working on the same few streams -- and therefore on the same hardware queues --
+// instead of walking through HIP's stream-to-queue assignment (see the sub-batch notes below and DESIGN.md section 5).
 static std::mutex g_stream_mu;
 static std::vector<hipStream_t> g_stream_pool[PK_MAX_DEVICES][2];   // [device][0: normal priority, 1: the sub-batch streams]
 // The internal streams of pk_set_env_batches are created with the HIGHEST stream priority: HIP keeps separate hardware queues per
 // priority level, so they do not compete for the four normal-priority queues with the caller's stream, the legacy default stream
 // (one hipMemcpy or one torch kernel brings it to life) and whatever else the process has created -- with normal-priority streams a
-// process that had merely made one hipMemcpy before creating the handle found two of the four streams sharing a queue and the
-// cross-stream waits serialising (524 288 x 6, three sub-batches: 2.57 G env.step/s against 3.66 G).  env PK_ENV_STREAM_PRIO=0: off.
+// process that had merely made one hipMemcpy before creating the handle ran 524 288 x 6 in three sub-batches at 2.57 G env.step/s
+// against 3.66 G (tools/env_queue_scenarios.py).  env PK_ENV_STREAM_PRIO=0: off.
 static hipError_t stream_acquire(int device, hipStream_t *out, bool sub_batch = false) {   // the device is current
     static const bool prio = !(getenv("PK_ENV_STREAM_PRIO") && atoi(getenv("PK_ENV_STREAM_PRIO")) == 0);
     const int cls = (sub_batch && prio) ? 1 : 0;
