@@ -232,6 +232,11 @@ def test_multi_agent_bounded_launches_deliver_the_synchronous_sequences(O, R):
         D = 17 + 3 * N
         rew, done, hand, terr, obs, who, ready, act, rst = (DeviceBuffer(T * 8), DeviceBuffer(T), DeviceBuffer(T), DeviceBuffer(T),
                                                             DeviceBuffer(T * D * 8), DeviceBuffer(T), DeviceBuffer(T), DeviceBuffer(T * 4), DeviceBuffer(T))
+        # the compact row beside the dense one (pk_set_env_obs_packed): the env kernel writes both from registers for every table it
+        # delivers -- also the YIELDED seat's view (ready 2)
+        pdt = pokerl_amd.packed_dtype(N)
+        packed = DeviceBuffer(T * pdt.itemsize)
+        L.check(g._lib.pk_set_env_obs_packed(g._h, packed.ptr), g._h)
         got = {k: np.zeros_like(v) for k, v in want.items()}
         count = np.full(T, -1, np.int64)                  # -1: the delivery of the initial reset is still to come
         rst.upload(np.ones(T, np.uint8))
@@ -253,6 +258,9 @@ def test_multi_agent_bounded_launches_deliver_the_synchronous_sequences(O, R):
             te = terr.download(np.uint8, T)
             assert not te[r == 2].any()
             rows = obs.download(np.float64, T * D).reshape(T, D)
+            deliv = (r == 1) | (r == 2)
+            prow = packed.download(np.uint8, T * pdt.itemsize).view(pdt)
+            assert pokerl_amd.unpack_obs(prow[deliv], N).tobytes() == rows[deliv].tobytes()
             ret = r == 1
             idx = np.nonzero(ret & (count >= 0) & (count < K))[0]
             c = count[idx]
@@ -272,6 +280,7 @@ def test_multi_agent_bounded_launches_deliver_the_synchronous_sequences(O, R):
             same = GU.bits_equal(want[k], got[k]) if want[k].dtype == np.float64 else np.array_equal(want[k], got[k])
             assert same, (T, N, k)
         env.end_multi()
+        L.check(g._lib.pk_set_env_obs_packed(g._h, None), g._h)
         env.close()
     assert seen_all[0] > 0, seen_all                      # ... and some ran out of passes with their call still in flight
 
