@@ -299,8 +299,6 @@ __global__ void __launch_bounds__(PK_TABLE_BLOCK) k_env_reset(EnvResetKernArgs) 
     const EnvResetKernArgs *ka = (const EnvResetKernArgs *)__builtin_amdgcn_kernarg_segment_ptr();
     const auto &S = *as_global(ka->Sp);
     const Hot H = ka->H;
-    const uint64_t seatpol = ka->seatpol;
-    const int park = ka->park;
     __shared__ Lds<N> lds;
     const int t = blockIdx.x * H.tpb + threadIdx.x;
     const auto mask = as_global(ka->mask);
@@ -328,7 +326,8 @@ __global__ void __launch_bounds__(PK_TABLE_BLOCK) k_env_reset(EnvResetKernArgs) 
             more = tb.active != 0;                                                 // :24
             if (more) {
                 uint32_t vm = tb.valid_mask(high_bet);
-                tb.begin_step(H, pick_action(H, rng, table_id, tb.step_serial, vm, seat_policy(seatpol, tb.active)), high_bet);  // :25-26
+                tb.begin_step(H, pick_action(H, rng, table_id, tb.step_serial, vm, seat_policy(ka->seatpol, tb.active)), high_bet);  // :25-26 (the
+                                                                            // policy word and `park`: read from the argument block where used)
             }
         }
         tb.cursor();
@@ -336,7 +335,7 @@ __global__ void __launch_bounds__(PK_TABLE_BLOCK) k_env_reset(EnvResetKernArgs) 
         const int parked = __popcll(__ballot(tb.parked()));
         const int runnable = __popcll(__ballot(more && tb.lstate == LS_DONE));
         if (parked == 0 && runnable == 0) break;
-        if (parked >= park || runnable == 0) {
+        if (parked >= ka->park || runnable == 0) {
             tb.template end_block<false>(H, t, table_id, lds, false);   // (the whole side-pot loop per call: a reset's tail is a few lanes)
             retire();
         }
