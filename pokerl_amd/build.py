@@ -20,6 +20,10 @@ SEATS = list(range(2, 17))   # one object per seat count (pk_tables.hip -DPK_SEA
 OBJ = os.path.join(HERE, "_obj")
 SOURCES = ["pk_api.hip", "pk_tables.hip"]
 COMPILE_FLAGS = [f for f in FLAGS if f != "-shared"]
+# -enable-post-misched=0 for the TABLE kernels only: without the post-register-allocation scheduler pass k_rollout<6> runs 0.6 %
+#   faster and the all-in kernels 2.5 % (A/B of eight scheduling / if-conversion flags, profiles/r04_flag_variants.txt); the
+#   streaming evaluator in pk_api.hip loses 1.5 % with it and keeps the default.
+TABLE_FLAGS = COMPILE_FLAGS + ["-mllvm", "-enable-post-misched=0"]
 
 
 def hipcc():
@@ -42,14 +46,14 @@ def stale(lib=LIB):
 
 def _compile(job):
     src, obj, defines, verbose = job
-    cmd = [hipcc()] + COMPILE_FLAGS + defines + ["-c", os.path.join(CSRC, src), "-o", obj]
+    cmd = [hipcc()] + (TABLE_FLAGS if src == "pk_tables.hip" else COMPILE_FLAGS) + defines + ["-c", os.path.join(CSRC, src), "-o", obj]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
     return obj
 
 
-def build_variant(out, defines=(), seats=None, tag="", verbose=False, jobs=None):
+def build_variant(out, defines=(), seats=None, tag="", verbose=False, jobs=None, table_defines=()):
     """Compiles pk_api.hip and one pk_tables.hip object per seat count IN PARALLEL (the table kernels of one seat count take
     10-40 s of hipcc each; in one translation unit the library took three minutes), then links them.  seats: None = all of
     SEATS; one seat count = a development library that holds that seat count only (-DPK_ONLY_SEATS), built in seconds."""
@@ -67,7 +71,7 @@ def build_variant(out, defines=(), seats=None, tag="", verbose=False, jobs=None)
     os.makedirs(OBJ, exist_ok=True)
     work = [("pk_api.hip", os.path.join(OBJ, "pk_api%s.o" % tag), defines, verbose)]
     # widest tables first: they take longest to compile
-    work += [("pk_tables.hip", os.path.join(OBJ, "pk_tables_%d%s.o" % (n, tag)), defines + ["-DPK_SEATS=%d" % n], verbose)
+    work += [("pk_tables.hip", os.path.join(OBJ, "pk_tables_%d%s.o" % (n, tag)), defines + list(table_defines) + ["-DPK_SEATS=%d" % n], verbose)
              for n in sorted(seats, reverse=True)]
     jobs = jobs or int(os.environ.get("PK_BUILD_JOBS", "0")) or min(8, os.cpu_count() or 1)
     with ThreadPoolExecutor(jobs) as ex:
