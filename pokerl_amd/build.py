@@ -20,11 +20,15 @@ SEATS = list(range(2, 17))   # one object per seat count (pk_tables.hip -DPK_SEA
 OBJ = os.path.join(HERE, "_obj")
 SOURCES = ["pk_api.hip", "pk_tables.hip"]
 COMPILE_FLAGS = [f for f in FLAGS if f != "-shared"]
-# -enable-post-misched=0 for the TABLE kernels only: without the post-register-allocation scheduler pass k_rollout<6> runs 0.6 %
-#   faster and the all-in kernels 2.5 % (A/B of eight scheduling / if-conversion flags, profiles/r04_flag_variants.txt); the
-#   streaming evaluator in pk_api.hip loses 1.5 % with it and keeps the default.
-TABLE_FLAGS = COMPILE_FLAGS + ["-mllvm", "-enable-post-misched=0"]
+# -enable-post-misched=0 (no post-register-allocation scheduler pass) for the table kernels of the seat counts where it was MEASURED
+#   to pay: six seats (k_rollout<6> +0.6 ... 0.9 %, the all-in kernel +2.5 %) and four (+1.5 %); at every other seat count the default
+#   is faster (-0.2 ... -4.6 %, most at the wide tables) and the streaming evaluator in pk_api.hip loses 1.5 % with it.  A scheduling
+#   lottery per kernel, so: picked per seat count like the occ3 kernels (profiles/r04_flag_variants.txt).
+POST_MISCHED_OFF_SEATS = (4, 6)
 
+
+def table_flags(seats):
+    return COMPILE_FLAGS + (["-mllvm", "-enable-post-misched=0"] if seats in POST_MISCHED_OFF_SEATS else [])
 
 def hipcc():
     exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
@@ -46,7 +50,8 @@ def stale(lib=LIB):
 
 def _compile(job):
     src, obj, defines, verbose = job
-    cmd = [hipcc()] + (TABLE_FLAGS if src == "pk_tables.hip" else COMPILE_FLAGS) + defines + ["-c", os.path.join(CSRC, src), "-o", obj]
+    seats = [int(d.split("=")[1]) for d in defines if d.startswith("-DPK_SEATS=")]
+    cmd = [hipcc()] + (table_flags(seats[0]) if seats else COMPILE_FLAGS) + defines + ["-c", os.path.join(CSRC, src), "-o", obj]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

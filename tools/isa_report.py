@@ -17,7 +17,7 @@ FULL_RATE = re.compile(r"^v_(add|sub|subrev|and|or|xor|xnor|not|mov)_(u32|i32|b3
 def report(n):
     with tempfile.TemporaryDirectory() as td:
         asm = os.path.join(td, "t.s")
-        r = subprocess.run([build.hipcc()] + build.TABLE_FLAGS + ["-DPK_SEATS=%d" % n, "--cuda-device-only", "-S",
+        r = subprocess.run([build.hipcc()] + build.table_flags(n) + ["-DPK_SEATS=%d" % n, "--cuda-device-only", "-S",
                             "-Rpass-analysis=kernel-resource-usage", os.path.join(build.CSRC, "pk_tables.hip"), "-o", asm],
                            capture_output=True, text=True)
         if r.returncode:
