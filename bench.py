@@ -594,41 +594,53 @@ def kernel_description(w):
                "merged on the host while two launches are in flight (pk_set_coalesce)" if stats["max"] > min(chunk, K) else "launched one by one"))
 
 
+def _leg(out, name, fn):
+    """Runs one secondary leg; a failure becomes an entry with `error` instead of taking the other legs (or the headline) down."""
+    try:
+        out.append(fn())
+    except Exception as e:   # noqa: BLE001
+        out.append({"name": name, "error": "%s: %s" % (type(e).__name__, e)})
+
+
 def extra_workloads(ctx, device):
     """The other single-GPU BASELINE configs and the PokerGameEnv path, as SHORT driver-timed legs after the headline leg
     (~1 s of GPU work each, same event-bracketed timing, same counter assertion): configs[1], configs[4] (showdown-heavy:
     1.000 in-game evaluation per env-step), PokerGameEnv.step synchronous and asynchronous."""
     out = []
-    for cfg, (tables, players, policy) in ((1, (4096, 2, "random")), (4, (65536, 9, "allin"))):
-        w = rollout_workload(ctx, device, tables, players, policy, K=4096, warmup=512, min_steps=262144, samples=3)
-        out.append({"name": "BASELINE configs[%d]: %d tables x %d seats, %s agents" % (cfg, tables, players, policy),
-                    "metric": "env-steps/s", "value": w["total_steps"] / w["seconds"], "unit": "env-steps/s",
+
+    def rollout_leg(name, tables, players, policy, **kw):
+        def run():
+            w = rollout_workload(ctx, device, tables, players, policy, **kw)
+            return {"name": name, "metric": "env-steps/s", "value": w["total_steps"] / w["seconds"], "unit": "env-steps/s",
                     "hand_evals_per_s": w["hand_evals_per_s"], "hands_per_s": w["hands_per_s"],
                     "ms_per_step": w["seconds"] / (w["K"] * w["reps"]) * 1e3, "steps_per_sample": w["K"] * w["reps"], "samples": len(w["sample_s"]),
                     "kernel": kernel_description(w), "kernel_ms": w["ms_launch"], "launches": w["launches"],
-                    "launch_stats": w["stats"], "roofline": rollout_roofline(w, ctx.world)})
-    # the driver's own call pattern WITHOUT host-side merging: what a caller that observes the tables between its 20-step calls
-    # gets (every getter flushes), beside the headline figure, which holds for a caller that does not
-    w = rollout_workload(ctx, device, 65536, 6, "random", K=20, warmup=5, min_steps=131072, samples=3, coalesce=0)
-    out.append({"name": "BASELINE configs[2] in 20-step calls, one launch per call (pk_set_coalesce(0)): the rate of a caller that "
-                        "observes the tables between calls",
-                "metric": "env-steps/s", "value": w["total_steps"] / w["seconds"], "unit": "env-steps/s",
-                "hand_evals_per_s": w["hand_evals_per_s"], "hands_per_s": w["hands_per_s"],
-                "ms_per_step": w["seconds"] / (w["K"] * w["reps"]) * 1e3, "steps_per_sample": w["K"] * w["reps"], "samples": len(w["sample_s"]),
-                "kernel": kernel_description(w), "kernel_ms": w["ms_launch"], "launches": w["launches"],
-                "launch_stats": w["stats"], "roofline": rollout_roofline(w, ctx.world)})
-    for name, kw in (("PokerGameEnv.step synchronous (pk_env_step_fused_d), 65 536 x 6", dict(tables=65536, players=6, steps=1000, warmup=50)),
-                     ("PokerGameEnv.step asynchronous (pk_env_step_async_d, 8 betting passes per launch), one handle of 65 536 x 6",
-                      dict(tables=65536, players=6, async_passes=8, steps=4000, warmup=300)),
-                     ("PokerGameEnv.step asynchronous, ONE handle of 524 288 x 6 in three sub-batches (pk_set_env_batches)",
-                      dict(tables=524288, players=6, async_passes=8, inner=3, steps=1500, warmup=300))):
-        res = env_workload(ctx, device, **kw)
-        line = env_line(res, ctx)
-        out.append({"name": name, "metric": "PokerGameEnv.step/s (delivered)", "value": line["value"], "unit": "env.step/s",
+                    "launch_stats": w["stats"], "roofline": rollout_roofline(w, ctx.world)}
+        _leg(out, name, run)
+
+    def env_leg(name, **kw):
+        def run():
+            res = env_workload(ctx, device, **kw)
+            line = env_line(res, ctx)
+            return {"name": name, "metric": "PokerGameEnv.step/s (delivered)", "value": line["value"], "unit": "env.step/s",
                     "game_steps_per_s": line["game_steps_per_s"], "game_steps_per_env_step": line["game_steps_per_env_step"],
                     "ready_fraction_per_launch": line["ready_fraction_per_launch"], "kernel": line["roofline"]["kernel"],
                     "kernel_ms": line["roofline"]["kernel_ms"], "launches": res["launches"], "device_ms": res["device_ms"],
-                    "seconds": res["seconds"], "roofline": line["roofline"]})
+                    "seconds": res["seconds"], "roofline": line["roofline"]}
+        _leg(out, name, run)
+
+    for cfg, (tables, players, policy) in ((1, (4096, 2, "random")), (4, (65536, 9, "allin"))):
+        rollout_leg("BASELINE configs[%d]: %d tables x %d seats, %s agents" % (cfg, tables, players, policy), tables, players, policy,
+                    K=4096, warmup=512, min_steps=262144, samples=3)
+    # the driver's own call pattern WITHOUT host-side merging: what a caller that observes the tables between its 20-step calls
+    # gets (every getter flushes), beside the headline figure, which holds for a caller that does not
+    rollout_leg("BASELINE configs[2] in 20-step calls, one launch per call (pk_set_coalesce(0)): the rate of a caller that "
+                "observes the tables between calls", 65536, 6, "random", K=20, warmup=5, min_steps=131072, samples=3, coalesce=0)
+    env_leg("PokerGameEnv.step synchronous (pk_env_step_fused_d), 65 536 x 6", tables=65536, players=6, steps=1000, warmup=50)
+    env_leg("PokerGameEnv.step asynchronous (pk_env_step_async_d, 8 betting passes per launch), one handle of 65 536 x 6",
+            tables=65536, players=6, async_passes=8, steps=4000, warmup=300)
+    env_leg("PokerGameEnv.step asynchronous, ONE handle of 524 288 x 6 in three sub-batches (pk_set_env_batches)",
+            tables=524288, players=6, async_passes=8, inner=3, steps=1500, warmup=300)
     return out
 
 
@@ -703,7 +715,10 @@ def main():
         if not args.no_evaluator:
             out["evaluator"] = evaluator_leg(device)
         if not args.no_extra and ctx.world == 1 and fused:
-            out["extra_workloads"] = extra_workloads(ctx, device)
+            try:    # the headline line must survive whatever happens to a secondary leg
+                out["extra_workloads"] = extra_workloads(ctx, device)
+            except Exception as e:   # noqa: BLE001
+                out["extra_workloads"] = [{"name": "extra_workloads", "error": "%s: %s" % (type(e).__name__, e)}]
         if not args.no_cpu_baseline and ctx.world == 1:
             out["cpu_baseline"] = cpu_baseline(args.players, policy)
         print(json.dumps(out))
