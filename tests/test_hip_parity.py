@@ -241,6 +241,24 @@ def test_deferred_launches_are_invisible(HB, O):
         h.g.rollout(17, 0, True, True, counters=False)
     o.rollout(170, 0, True)
     assert GU.bits_equal(o.f64(0), h.g.credits)        # first call after the launches is a getter
+    # ... and pk_wait_event launches the steps the host still holds back (they were requested before the wait), without changing
+    # what any observer sees
+    from pokerl_amd.hipmem import DeviceEvent
+    h2 = HB(65536, 6, seed=8); h2.reset()
+    o2 = O.OracleGame(65536, 6, seed=8); o2.reset()
+    ev = DeviceEvent()
+    for r in range(6):
+        for _ in range(8):
+            h2.g.rollout(20, 0, True, True, counters=False)             # piles up behind the two launches in flight
+        held_before = h2.g.launch_stats()["steps"]
+        h.g.record_event(ev.handle)                                     # an event of ANOTHER handle's stream (complete or about to be)
+        h2.g.wait_event(ev.handle)
+        assert h2.g.launch_stats()["steps"] >= held_before              # (nothing is lost; what was held has been launched)
+    c2 = h2.rollout(0, 0, True)
+    co2 = o2.rollout(6 * 8 * 20, 0, True)[0]
+    assert c2.tolist() == co2.tolist()
+    assert_same(o2.snapshot(), h2.snapshot(), "held steps launched by pk_wait_event")
+    h2.g.close()
     h.g.rollout(5, 0, True, True, counters=False)
     o.rollout(5, 0, True)
     acts = o.pick_actions(0)
