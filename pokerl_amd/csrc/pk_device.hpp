@@ -366,6 +366,77 @@ __device__ __forceinline__ uint32_t eval7_distinct(const uint32_t (&c)[7]) {
     return (cat << 20) | kick;
 }
 
+// eval7_distinct generalised to n = 3 .. 7 DISTINCT cards, with len(kickers): the fast path of pk_eval_hands(_d) -- the reference's
+// sort-and-scan (eval_hand above, ~570 executed instructions) is needed only for hands that repeat a card, which its own tests feed
+// it and a game never does.  Same derivation as eval7_distinct (the scan of judger.py:50-99 visits fewer cards, its rules are the
+// same); what changes with fewer cards is the LENGTH of the kicker lists -- `islice(others, count)` yields what is there
+// (judger.py:91-99) -- and get_kickers_value (judger.py:101-109) packs the list as it is, so the tail takes min(nm, ranks left) nibbles.
+// Equal to eval_hand on EVERY 3-, 4-, 5-, 6- and 7-card subset of the deck (rank, kickers value and count: tools/host_sim `evaln`).
+__device__ __forceinline__ uint32_t eval_distinct_n(const uint32_t (&c)[7], int n, int &nk) {
+    uint64_t bits = 0;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) bits |= (i < n) ? (1ull << (c[i] & 63)) : 0ull;
+    const uint64_t hi = ((bits >> 1) & 0x0fff0fff0fff0fffull) | ((bits & 0x0001000100010001ull) << 12);
+    const uint32_t h01 = (uint32_t)hi, h23 = (uint32_t)(hi >> 32);
+    const uint32_t sa = h01 & 0x1fff, sb = h01 >> 16, sc = h23 & 0x1fff, sd = h23 >> 16;
+    const uint32_t um = sa | sb | sc | sd;
+    const uint32_t s1 = sa ^ sb, c1 = sa & sb, s2 = sc ^ sd, c2 = sc & sd;
+    const uint32_t bit0 = s1 ^ s2, t = c1 ^ c2 ^ (s1 & s2), quads = c1 & c2;
+    const uint32_t pairs = t & ~bit0, trips = t & bit0;
+    const bool fa = __popc(sa) >= 5, fb = __popc(sb) >= 5, fc = __popc(sc) >= 5, fd = __popc(sd) >= 5;
+    const bool has_flush = fa || fb || fc || fd;
+    uint32_t gm = sa ? sa : (sb ? sb : (sc ? sc : sd));
+    gm = fa ? sa : (fb ? sb : (fc ? sc : (fd ? sd : gm)));
+    const uint32_t run = gm & ~(gm + (gm & (0u - gm)));
+    const int bcount = __popc(run), btop = 31 - __clz((int)run);
+    const uint32_t m5 = um & (um >> 1) & (um >> 2) & (um >> 3) & (um >> 4);
+    uint32_t cat = HR_HIGH, L = 0, base = um, direct = 0;
+    int nl = 0, nm = 5;
+    if (pairs) { cat = HR_PAIR; L = pairs; nl = 1; nm = 3; }
+    if (pairs & (pairs - 1)) { cat = HR_TWO_PAIR; nl = 2; nm = 1; }
+    if (trips) { cat = HR_TRIS; L = trips; nl = 1; nm = 2; }
+    if (m5) { cat = HR_STRAIGHT; direct = (uint32_t)(31 - __clz((int)m5) + 5); nl = 0; nm = 0; }
+    if (has_flush) { cat = HR_FLUSH; L = 0; nl = 0; base = gm; nm = 5; direct = 0; }
+    if (trips && pairs) { cat = HR_FULL; L = trips; nl = 1; base = pairs; nm = 1; direct = 0; }
+    if (trips & (trips - 1)) { cat = HR_FULL; L = trips; nl = 2; nm = 0; direct = 0; }
+    if (quads) { cat = HR_POKER; L = quads; nl = 1; base = um; nm = 1; direct = 0; }
+    if (bcount >= 5) { cat = HR_SF; direct = (uint32_t)(btop + 1); nl = 0; nm = 0; }
+    if (bcount == 4 && btop == 3) {
+        if (gm & (1u << 12)) { cat = HR_SF; direct = 4; nl = 0; nm = 0; }
+    } else if (m5 == 0 && (um & 0x1f) == 0xf) {
+        if (um & (1u << 12)) { cat = HR_STRAIGHT; direct = 4; nl = 0; nm = 0; }
+    }
+    uint32_t kick = direct, taken = 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        uint32_t bit = 0x80000000u >> (__clz((int)L) & 31);
+        bool take = i < nl;
+        kick = take ? ((kick << 4) | (uint32_t)(32 - __clz((int)L))) : kick;
+        taken |= take ? bit : 0; L = take ? (L & ~bit) : L;
+    }
+    uint32_t m = base & ~taken;
+    const int left = __popc(m);
+    nm = nm < left ? nm : left;                                                    // islice yields what is there
+    uint32_t k5 = 0;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const uint32_t lz = (uint32_t)__clz((int)m);
+        k5 = (k5 << 4) | (32u - lz);
+        m &= ~(0x80000000u >> (lz & 31));
+    }
+    kick = (kick << (4 * nm)) | (nm ? (k5 >> (4 * (5 - nm))) : 0u);
+    nk = (direct ? 1 : 0) + nl + nm;
+    return (cat << 20) | kick;
+}
+// pk_eval_hands' evaluator: the fast path above for 3..7 distinct cards, the literal scan otherwise (0..2 cards: its first lines)
+__device__ __forceinline__ uint32_t eval_hand_any(const uint32_t (&c)[7], int n, int &nk) {
+    uint64_t bits = 0;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) bits |= (i < n) ? (1ull << (c[i] & 63)) : 0ull;
+    if (n >= 3 && __popcll(bits) == n) return eval_distinct_n(c, n, nk);
+    return eval_hand(c, n, nk);
+}
+
 // ---------------------------------------------------------------------------------------------- table-driven evaluator
 // The same function as eval7_distinct for the STREAMING evaluator (k_eval7_stream: eight waves per SIMD hide the LDS
 // latency that made a lookup table a dead end inside k_rollout's one-wave-per-SIMD loop): the five-iteration `clz`

@@ -837,7 +837,7 @@ __global__ void k_eval_hands(const uint8_t *cards, const uint8_t *ncards, size_t
     int n = ncards ? ncards[i] : 7;
     n = n < 0 ? 0 : (n > 7 ? 7 : n);
     int nk;
-    uint32_t v = eval_hand(c, n, nk);
+    uint32_t v = eval_hand_any(c, n, nk);     // 3..7 distinct cards: the bitmask fast path; a repeated card, 0..2 cards: the literal scan
     rank[i] = (uint8_t)(v >> 20);
     kick[i] = v & 0xFFFFF;
     if (nkick) nkick[i] = (uint8_t)nk;
@@ -866,7 +866,7 @@ __global__ void __launch_bounds__(256) k_eval7_stream(const uint64_t *__restrict
         uint32_t lo = (uint32_t)w, hi = (uint32_t)(w >> 32);
         uint32_t c[7] = {lo & 0xff, (lo >> 8) & 0xff, (lo >> 16) & 0xff, lo >> 24, hi & 0xff, (hi >> 8) & 0xff, (hi >> 16) & 0xff};
         int nk;
-        return DISTINCT ? eval7_distinct(c) : eval_hand(c, 7, nk);
+        return DISTINCT ? eval7_distinct(c) : eval_hand_any(c, 7, nk);
     };
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < pairs; i += stride) {
         const ulonglong2 w = reinterpret_cast<const ulonglong2 *>(hands)[i];
@@ -958,7 +958,8 @@ __global__ void k_eval7_prefix(int a, int b, int fast, uint32_t count, uint32_t 
         uint32_t r[7];
         for (int j = 0; j < 7; ++j) r[j] = h[(j + i) % 7];
         out[i] = eval7_tab(r[0] | (r[1] << 8) | (r[2] << 16) | (r[3] << 24), r[4] | (r[5] << 8) | (r[6] << 16) | 0xAB000000u, tab);
-    } else out[i] = fast ? eval7_distinct(h) : eval_hand(h, 7, nk);
+    } else if (fast == 3) out[i] = eval_hand_any(h, 7, nk);   // pk_eval_hands' dispatch (its fast path: eval_distinct_n)
+    else out[i] = fast ? eval7_distinct(h) : eval_hand(h, 7, nk);
 }
 
 #endif  // PK_TABLES_ONLY

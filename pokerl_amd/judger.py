@@ -79,7 +79,8 @@ def compare_hands(hands, device=0):
 
 def eval7_prefix(a, b, fast=True, device=0):
     """Values rank<<20|kick of all 7-card hands whose two lowest canonical indices are (a, b) (exhaustive checks).
-    fast=True / 1: the distinct-card evaluator used by the showdown kernels; False / 0: the general evaluator;
+    fast=True / 1: the distinct-card evaluator used by the showdown kernels; False / 0: the general evaluator; 3: what
+    pk_eval_hands applies (fast path for 3..7 distinct cards);
     2: the table-driven distinct-card evaluator of the streaming kernel (eval7_stream)."""
     import ctypes as C
     import math

@@ -75,7 +75,8 @@ def test_golden_judger_vectors(HB):
         assert [[r, k] for r, k in out[2]] == case["rankings"]
 
 
-@pytest.mark.parametrize("fast", [1, 0, 2], ids=["showdown_evaluator", "general_evaluator", "table_evaluator_of_the_streaming_kernel"])
+@pytest.mark.parametrize("fast", [1, 0, 2, 3], ids=["showdown_evaluator", "general_evaluator", "table_evaluator_of_the_streaming_kernel",
+                                                   "eval_hands_dispatch_fast_path"])
 def test_eval7_exhaustive_digest(HB, fast):
     """All C(52,7) = 133 784 560 hands on the GPU against the digest computed from the imported reference, for both
     device evaluators (the bitmask one the showdown kernels use, the general multiset one of pk_eval_hands, and the
@@ -658,6 +659,17 @@ def test_streaming_evaluator(HB, O):
     assert np.array_equal(out_d.download(np.uint32, 4096), (r2.astype(np.uint32) << 20) | k2)
     assert judger.time_eval7_stream(hands_d.ptr, 4096, out_d.ptr, True, reps=2) > 0
     hands_d.free(); out_d.free()
+    # pk_eval_hands: PARTIAL hands of distinct cards (the fast path for 3..7 cards; every subset of the deck is checked on the CPU
+    # build, tools/host_sim evaln), hands that repeat a card and 0..2-card hands (the reference's scan), mixed in one batch
+    rng = np.random.default_rng(12)
+    mm = 300000
+    part = cards[:mm].copy()
+    nc = rng.integers(0, 8, mm).astype(np.uint8)
+    rep = rng.random(mm) < 0.2
+    part[rep, 1] = part[rep, 0]                       # a repeated card (inside the hand wherever ncards >= 2)
+    ro, ko, no = O.eval_hands(np.ascontiguousarray(part), nc)
+    rg, kg, ng = judger.eval_hands(part, nc)
+    assert np.array_equal(ro, rg) and np.array_equal(ko, kg) and np.array_equal(no, ng)
 
 
 def test_empty_and_minimal_inputs(HB, O):

@@ -159,7 +159,45 @@ static int fuzz(int rounds, int T, int K) {
     return bad != 0;
 }
 
+// eval_distinct_n (the fast path of pk_eval_hands) against eval_hand (the literal scan) on EVERY n-card subset of the deck,
+// n = 3 .. 7 (7: 133 784 560 hands; pass a smaller max n for a quick run), cards in a rotated order so that positions vary
+static int check_evaln(int nmax) {
+    auto canon = [](int k) { return (uint32_t)(((k % 4) << 4) | (k / 4)); };
+    long long bad = 0, total = 0;
+    for (int n = 3; n <= nmax; ++n) {
+        int idx[7];
+        for (int i = 0; i < n; ++i) idx[i] = i;
+        long long cnt = 0;
+        for (;;) {
+            uint32_t c[7] = {0, 0, 0, 0, 0, 0, 0};
+            for (int i = 0; i < n; ++i) c[(i + (int)(cnt % 7)) % n] = canon(idx[i]);
+            int nk0 = -1, nk1 = -1;
+            const uint32_t v0 = eval_hand(c, n, nk0), v1 = eval_hand_any(c, n, nk1);
+            if (v0 != v1 || nk0 != nk1) {
+                if (bad < 5) printf("MISMATCH n=%d hand %lld: scan %08x nk %d, fast %08x nk %d\n", n, cnt, v0, nk0, v1, nk1);
+                ++bad;
+            }
+            ++cnt;
+            int i = n - 1;
+            while (i >= 0 && idx[i] == 52 - n + i) --i;
+            if (i < 0) break;
+            ++idx[i];
+            for (int j = i + 1; j < n; ++j) idx[j] = idx[j - 1] + 1;
+        }
+        printf("n=%d: %lld hands\n", n, cnt);
+        total += cnt;
+    }
+    // hands that repeat a card must take the literal scan (and 0..2 cards its first lines): spot-check the dispatch
+    uint32_t d[7] = {0x20, 0x20, 0x0c, 0x1c, 0x2c, 0x3c, 0x01};
+    int a, b;
+    if (eval_hand(d, 7, a) != eval_hand_any(d, 7, b) || a != b) { printf("MISMATCH on a hand with a repeated card\n"); ++bad; }
+    for (int n = 0; n <= 2; ++n) if (eval_hand(d, n, a) != eval_hand_any(d, n, b) || a != b) { printf("MISMATCH n=%d\n", n); ++bad; }
+    printf("evaln: %lld hands, %lld mismatching\n", total, bad);
+    return bad != 0;
+}
+
 int main(int argc, char **argv) {
+    if (argc > 1 && !strcmp(argv[1], "evaln")) return check_evaln(argc > 2 ? atoi(argv[2]) : 7);
     if (argc > 1 && !strcmp(argv[1], "eval7")) return check_eval7();
     if (argc > 1 && !strcmp(argv[1], "eval7tab")) {
         std::vector<uint32_t> tab(EVAL7_TAB_WORDS);
