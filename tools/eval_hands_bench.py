@@ -15,9 +15,17 @@ log2 = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 m = 1 << log2
 rng = np.random.default_rng(3)
 lib = L.lib()
-for name, ncards in (("7 cards", None), ("mixed 2/5/6/7 cards", rng.choice(np.array([2, 5, 6, 7], np.uint8), m))):
-    deck = np.array([(s << 4) | r for r in range(13) for s in range(4)], np.uint8)
-    cards = deck[rng.integers(0, 52, (m, 7))].astype(np.uint8)          # duplicates allowed (multiset semantics)
+from pokerl_amd import judger
+hands = DeviceBuffer(m * 8)
+judger.make_hands(hands.ptr, m)                                       # 7 DISTINCT cards per hand (what a game produces)
+distinct = hands.download(np.uint64, m).view(np.uint8).reshape(m, 8)[:, :7].copy()
+hands.free()
+repeated = distinct.copy()
+sel = rng.random(m) < 0.35
+repeated[sel, 1] = repeated[sel, 0]                                   # 35 % of the hands repeat a card (the reference's tests do)
+for name, cards, ncards in (("7 distinct cards", distinct, None),
+                            ("2/5/6/7 distinct cards, mixed in the batch", distinct, rng.choice(np.array([2, 5, 6, 7], np.uint8), m)),
+                            ("7 cards, 35 % of the hands with a repeated card", repeated, None)):
     d_c, d_n, d_r, d_k, d_nk = DeviceBuffer(m * 7), DeviceBuffer(m), DeviceBuffer(m), DeviceBuffer(m * 4), DeviceBuffer(m)
     d_c.upload(cards)
     if ncards is not None:
