@@ -97,6 +97,16 @@ class DistContext:
         dist.all_reduce(v, op=dist.ReduceOp.SUM)
         return [int(round(x)) for x in v.tolist()]
 
+    def describe(self, device, n_local):
+        """`dist` block of the bench line for N > 1 (None for one process): backend, world size, every rank's device index and
+        table count -- "did the collective library see N ranks" is checkable from the line.  Collective: call on every rank."""
+        if self.dist is None:
+            return None
+        devs = self.sum_list([device if r == self.rank else 0 for r in range(self.world)])
+        tabs = self.sum_list([n_local if r == self.rank else 0 for r in range(self.world)])
+        return {"backend": self.dist.get_backend(), "world": self.dist.get_world_size(), "devices": devs, "tables_per_rank": tabs,
+                "collectives_on_step_path": 0}
+
     def close(self):
         if self.dist is not None:
             self.dist.destroy_process_group()
@@ -584,6 +594,14 @@ def rollout_roofline(w, world):
     return roof
 
 
+def kernel_short(w, players):
+    if not w["fused"]:
+        return "k_rollout_single<%d>, 1 step/launch" % players
+    occ3 = (players == 6 and w["n_local"] > 131072) or (players == 7 and w["n_local"] >= 262144) or (players == 8 and w["n_local"] >= 524288)
+    name = {"random": "k_rollout_occ3" if occ3 else "k_rollout", "allin": "k_rollout_occ3_allin" if occ3 else "k_rollout_allin"}[w["policy"]]
+    return "%s<%d> fused, %.0f steps/launch" % (name, players, w["kern_steps"])
+
+
 def kernel_description(w):
     stats, K, chunk = w["stats"], w["K"], w["chunk"]
     if not w["fused"]:
@@ -602,27 +620,198 @@ def _leg(out, name, fn):
         out.append({"name": name, "error": "%s: %s" % (type(e).__name__, e)})
 
 
+
+def step_workload(ctx, device, tables, players, steps=400, warmup=100, replay=False, fused_reset=True):
+    """`Game.step` with CALLER-SUPPLIED actions on device buffers (reference pokerl/game.py:621-700) as the device-resident loop of
+    examples/random_game.py:8-12: pick (pk_pick_actions_d) + step with the reset of a finished game in the same launch
+    (pk_step_auto_d) -- two launches per step, the table state round-trips HBM in each; fused_reset=False: pk_step_d + pk_reset_d on
+    the step's own flags, three launches.  replay: the actions a first pass recorded are replayed, so that the timed loop is the
+    step kernel alone.  HIP events on the handle's stream around the timed steps; the serials prove the steps were made."""
+    import ctypes as C
+    import numpy as np
+    import pokerl_amd
+    from pokerl_amd import _lib as L
+    from pokerl_amd.hipmem import DeviceBuffer, DeviceEvent
+    T = tables
+    g = pokerl_amd.VecGame(T, num_players=players, device=device, table_id_base=ctx.rank * T)
+    flags, terr = DeviceBuffer(T, device), DeviceBuffer(T, device)
+    total = warmup + steps
+    rec = DeviceBuffer(T * 4 * (total if replay else 1), device)
+    ev0, ev1 = DeviceEvent(), DeviceEvent()
+
+    def act(s):
+        return C.c_void_p(rec.ptr.value + (s * T * 4 if replay else 0))
+
+    def loop(lo, hi, pick):
+        for s in range(lo, hi):
+            if pick:
+                g.pick_actions_d(act(s), 0)
+            g.step_d(act(s), flags, terr, auto_reset=fused_reset)
+            if not fused_reset:
+                g.reset_d(flags, L.FLAG_GAME_OVER)
+
+    if replay:                       # record the action of every step, then start over on the same RNG streams
+        g.reset(); loop(0, total, True); g.sync()
+        g.set_serials(0, 0)
+    g.reset()
+    loop(0, warmup, not replay)
+    g.sync()
+    s0 = int(g.step_serial.sum())
+    ctx.barrier()
+    g.record_event(ev0.handle)
+    t0 = time.perf_counter()
+    loop(warmup, total, not replay)
+    g.record_event(ev1.handle)
+    g.sync(); ctx.barrier()
+    dt = time.perf_counter() - t0
+    dev_ms = DeviceEvent.elapsed_ms(ev0, ev1)
+    made = int(g.step_serial.sum()) - s0
+    bad = int((terr.download(np.uint8, T) != 0).sum())
+    g.close()
+    for b in (flags, terr, rec):
+        b.free()
+    assert made >= 0.999 * T * steps, (made, T * steps, bad)   # every table made every step (a PK_TERR_NO_WINNER step would not count)
+    return dict(tables=T, players=players, steps=steps, warmup=warmup, replay=replay, seconds=dt, device_ms=dev_ms, game_steps=made,
+                tables_with_error_bits=bad, fused_reset=fused_reset, launches_per_step=(1 if replay else 2) + (0 if fused_reset else 1))
+
+
+def step_profile_summary(tables, players):
+    """The committed rocprofv3 summary of the Game.step loop (profiles/rNN_step_*_summary.json: kernel trace + PMC passes of
+    tools/profile_step.sh), latest round; None if none."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_step_*_summary.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        w = d.get("workload", {})
+        if (w.get("tables"), w.get("players")) == (tables, players):
+            best = (d, os.path.basename(f))
+    return best
+
+
+def step_line(res, name):
+    """Bench entry of a Game.step leg: HBM roofline on SURVEY 8d's algorithmic bytes (this path DOES move the table state every step),
+    the measured traffic of the committed PMC passes beside it."""
+    T, N = res["tables"], res["players"]
+    ms_step = res["device_ms"] / res["steps"]
+    rate = res["game_steps"] / (res["device_ms"] * 1e-3)
+    alg = b_step(N) * res["game_steps"] / res["steps"]           # algorithmic bytes of one step of the whole batch
+    gbs = alg / (ms_step * 1e-3) / 1e9
+    roof = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+            "kernel": " + ".join(([] if res["replay"] else ["k_pick"]) + ["k_step"] + ([] if res["fused_reset"] else ["k_reset(masked)"])),
+            "kernel_ms": ms_step, "launches_timed": res["steps"] * res["launches_per_step"], "algorithmic_bytes_per_step": alg,
+            "kernel_ms_source": "HIP events (pk_record_event) around the timed steps on the handle's stream / steps: ALL launches of one "
+                                "loop iteration, launch gaps included"}
+    prof = step_profile_summary(T, N)
+    if prof:
+        d, src = prof
+        mine = [k for k in d.get("kernels", {}) if not (res["replay"] and k == "k_pick") and not (res["fused_reset"] and k == "k_reset")]   # the kernels of THIS leg's loop iteration
+        roof.update({"traffic": sum(d["kernels"][k].get("hbm_traffic_bytes_per_launch", 0.0) for k in mine), "source": src,
+                     "k_step_ms_rocprof": d.get("k_step_avg_ms"), "kernels_in_traffic": mine,
+                     "traffic_unit": "HBM bytes per loop iteration (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE, KiB), summed over its kernels"})
+    return {"name": name, "metric": "Game.step env-steps/s (caller-supplied actions, device-resident)", "value": rate, "unit": "env-steps/s",
+            "ms_per_step": res["seconds"] / res["steps"] * 1e3, "kernel": roof["kernel"], "kernel_ms": ms_step,
+            "launches": res["steps"] * res["launches_per_step"], "device_ms": res["device_ms"], "seconds": res["seconds"],
+            "tables_with_error_bits": res["tables_with_error_bits"], "roofline": roof}
+
+
+# ---------------------------------------------------------------------------------------------- the ONE stdout line
+LINE_LIMIT = 4096        # the driver keeps the last ~8 KB of stdout: the line must fit with room to spare
+DETAIL_FILE = os.path.join(ROOT, "bench_detail.json")   # everything else: notes, per-sample arrays, the full roofline blocks
+
+
+def _sig(x, digits=5):
+    """Floats to `digits` significant digits (the line is for a parser; the exact values are in the detail file)."""
+    if isinstance(x, bool) or not isinstance(x, float):
+        return x
+    if x == 0.0 or x != x or x in (float("inf"), float("-inf")):
+        return x
+    return float("%.*g" % (digits, x))
+
+
+def _short_roofline(rf, with_alg=True):
+    if not isinstance(rf, dict):
+        return None
+    out = {k: _sig(rf.get(k)) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms", "steps_per_launch")
+           if k in rf}
+    if rf.get("source"):
+        out["source"] = rf["source"]
+    hb = rf.get("hbm_algorithmic")
+    if with_alg and isinstance(hb, dict):
+        out["hbm_algorithmic"] = {"frac": _sig(hb.get("frac"))}
+    return out
+
+
+def _short_leg(x):
+    if "error" in x:
+        return {"name": str(x.get("name", ""))[:40], "error": str(x["error"])[:80]}
+    rf = x.get("roofline") or {}
+    hb = rf.get("hbm") if isinstance(rf.get("hbm"), dict) else rf.get("hbm_algorithmic") if isinstance(rf.get("hbm_algorithmic"), dict) else None
+    hbm_frac = rf.get("frac") if rf.get("bound") == "hbm" else (hb or {}).get("frac")
+    out = {"name": str(x.get("short") or x.get("name", ""))[:40], "value": _sig(x.get("value")), "unit": x.get("unit"),
+           "kernel_ms": _sig(x.get("kernel_ms")), "bound": rf.get("bound"), "frac": _sig(rf.get("frac")), "hbm_frac": _sig(hbm_frac)}
+    if x.get("hand_evals_per_s") and x.get("showdown_heavy"):
+        out["hand_evals_per_s"] = _sig(x["hand_evals_per_s"])
+    return out
+
+
+def compact_line(full):
+    """The driver-facing line (<= LINE_LIMIT bytes) out of the full result: the contract's keys, `roofline`, `cpu_baseline`, the
+    evaluator and one short entry per extra leg.  Prose and arrays stay in DETAIL_FILE."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data")
+    line = {k: _sig(full[k]) for k in keep}
+    c = full["config"]
+    line["config"] = {"workload": c["workload"], "tables_per_gpu": c["tables_per_gpu"], "num_players": c["num_players"],
+                      "policy": c["policy"], "kernel": c.get("kernel_short") or str(c.get("kernel", ""))[:60],
+                      "launch_stats": c["launch_stats"], "parallelism": c["parallelism"]}
+    line["hand_evals_per_s"] = _sig(full.get("hand_evals_per_s"))
+    line["roofline"] = _short_roofline(full["roofline"])
+    if "evaluator" in full:
+        ev = full["evaluator"]
+        line["evaluator"] = {"hand_evals_per_s": _sig(ev["hand_evals_per_s"]), "frac": _sig(ev["roofline"]["frac"]),
+                             "bound": "hbm", "kernel_ms": _sig(ev["kernel_ms"])}
+    if "cpu_baseline" in full:
+        cb = full["cpu_baseline"]
+        line["cpu_baseline"] = {"value": _sig(cb["value"]), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
+                                "sample": cb["sample"][:120],
+                                "all_cores": {"value": _sig(cb["all_cores"]["value"]), "cores": cb["all_cores"]["cores"]}}
+    if "extra_workloads" in full:
+        line["extra_workloads"] = [_short_leg(x) for x in full["extra_workloads"]]
+    if "dist" in full:
+        line["dist"] = full["dist"]
+    line["detail"] = os.path.basename(DETAIL_FILE)
+    text = json.dumps(line, separators=(",", ":"))
+    if len(text) >= LINE_LIMIT and "extra_workloads" in line:       # never observed; the contract keys come first
+        line["extra_workloads"] = [{"name": x["name"], "value": x.get("value"), "frac": x.get("frac")} for x in line["extra_workloads"]]
+        text = json.dumps(line, separators=(",", ":"))
+    assert len(text) < LINE_LIMIT, len(text)
+    return text
+
+
 def extra_workloads(ctx, device):
     """The other single-GPU BASELINE configs and the PokerGameEnv path, as SHORT driver-timed legs after the headline leg
     (~1 s of GPU work each, same event-bracketed timing, same counter assertion): configs[1], configs[4] (showdown-heavy:
     1.000 in-game evaluation per env-step), PokerGameEnv.step synchronous and asynchronous."""
     out = []
 
-    def rollout_leg(name, tables, players, policy, **kw):
+    def rollout_leg(name, short, tables, players, policy, **kw):
         def run():
             w = rollout_workload(ctx, device, tables, players, policy, **kw)
-            return {"name": name, "metric": "env-steps/s", "value": w["total_steps"] / w["seconds"], "unit": "env-steps/s",
+            return {"name": name, "short": short, "showdown_heavy": policy == "allin", "metric": "env-steps/s", "value": w["total_steps"] / w["seconds"], "unit": "env-steps/s",
                     "hand_evals_per_s": w["hand_evals_per_s"], "hands_per_s": w["hands_per_s"],
                     "ms_per_step": w["seconds"] / (w["K"] * w["reps"]) * 1e3, "steps_per_sample": w["K"] * w["reps"], "samples": len(w["sample_s"]),
                     "kernel": kernel_description(w), "kernel_ms": w["ms_launch"], "launches": w["launches"],
                     "launch_stats": w["stats"], "roofline": rollout_roofline(w, ctx.world)}
         _leg(out, name, run)
 
-    def env_leg(name, **kw):
+    def env_leg(name, short, **kw):
         def run():
             res = env_workload(ctx, device, **kw)
             line = env_line(res, ctx)
-            return {"name": name, "metric": "PokerGameEnv.step/s (delivered)", "value": line["value"], "unit": "env.step/s",
+            return {"name": name, "short": short, "metric": "PokerGameEnv.step/s (delivered)", "value": line["value"], "unit": "env.step/s",
                     "game_steps_per_s": line["game_steps_per_s"], "game_steps_per_env_step": line["game_steps_per_env_step"],
                     "ready_fraction_per_launch": line["ready_fraction_per_launch"], "kernel": line["roofline"]["kernel"],
                     "kernel_ms": line["roofline"]["kernel_ms"], "launches": res["launches"], "device_ms": res["device_ms"],
@@ -630,17 +819,30 @@ def extra_workloads(ctx, device):
         _leg(out, name, run)
 
     for cfg, (tables, players, policy) in ((1, (4096, 2, "random")), (4, (65536, 9, "allin"))):
-        rollout_leg("BASELINE configs[%d]: %d tables x %d seats, %s agents" % (cfg, tables, players, policy), tables, players, policy,
+        rollout_leg("BASELINE configs[%d]: %d tables x %d seats, %s agents" % (cfg, tables, players, policy),
+                    "cfg%d %dx%d %s" % (cfg, tables, players, policy), tables, players, policy,
                     K=4096, warmup=512, min_steps=262144, samples=3)
     # the driver's own call pattern WITHOUT host-side merging: what a caller that observes the tables between its 20-step calls
     # gets (every getter flushes), beside the headline figure, which holds for a caller that does not
     rollout_leg("BASELINE configs[2] in 20-step calls, one launch per call (pk_set_coalesce(0)): the rate of a caller that "
-                "observes the tables between calls", 65536, 6, "random", K=20, warmup=5, min_steps=131072, samples=3, coalesce=0)
-    env_leg("PokerGameEnv.step synchronous (pk_env_step_fused_d), 65 536 x 6", tables=65536, players=6, steps=1000, warmup=50)
+                "observes the tables between calls", "cfg2 20-step calls, 1 launch/call", 65536, 6, "random", K=20, warmup=5,
+                min_steps=131072, samples=3, coalesce=0)
+    # Game.step itself (row a7): the caller's actions on device buffers, the state round-trips HBM every step
+    _leg(out, "Game.step loop", lambda: step_line(step_workload(ctx, device, 65536, 6, steps=2000, warmup=200),
+                                                  "Game.step, device-resident loop pk_pick_actions_d + pk_step_auto_d (game-over reset in the step's launch), 65 536 x 6")
+         | {"short": "Game.step pick+step_auto_d 65536x6"})
+    _leg(out, "Game.step replay", lambda: step_line(step_workload(ctx, device, 65536, 6, steps=2000, warmup=200, replay=True),
+                                                    "Game.step, pk_step_auto_d alone on pre-picked (replayed) actions, 65 536 x 6")
+         | {"short": "Game.step step_auto_d replay 65536x6"})
+    # ... and at a batch that fills the chip: there the bytes, not the slowest table's serial chain, bound the launch
+    _leg(out, "Game.step 1M", lambda: step_line(step_workload(ctx, device, 1048576, 6, steps=300, warmup=50, replay=True),
+                                                "Game.step, pk_step_auto_d alone on pre-picked (replayed) actions, 1 048 576 x 6")
+         | {"short": "Game.step step_auto_d replay 1048576x6"})
+    env_leg("PokerGameEnv.step synchronous (pk_env_step_fused_d), 65 536 x 6", "env.step sync 65536x6", tables=65536, players=6, steps=1000, warmup=50)
     env_leg("PokerGameEnv.step asynchronous (pk_env_step_async_d, 8 betting passes per launch), one handle of 65 536 x 6",
-            tables=65536, players=6, async_passes=8, steps=4000, warmup=300)
+            "env.step async8 65536x6", tables=65536, players=6, async_passes=8, steps=4000, warmup=300)
     env_leg("PokerGameEnv.step asynchronous, ONE handle of 524 288 x 6 in three sub-batches (pk_set_env_batches)",
-            tables=524288, players=6, async_passes=8, inner=3, steps=1500, warmup=300)
+            "env.step async8 524288x6 inner3", tables=524288, players=6, async_passes=8, inner=3, steps=1500, warmup=300)
     return out
 
 
@@ -661,7 +863,9 @@ def main():
                          "samples keep the GPU busy for ~8 s of a ~16 s run)")
     ap.add_argument("--samples", type=int, default=7, help="timed samples; the MEDIAN is reported")
     ap.add_argument("--unfused", action="store_true", help="one launch per step (state round-trips HBM every step)")
-    ap.add_argument("--mode", choices=["game", "env"], default="game")
+    ap.add_argument("--mode", choices=["game", "env", "step"], default="game")
+    ap.add_argument("--step-replay", action="store_true", help="--mode step: the step kernel alone on replayed (pre-picked) actions")
+    ap.add_argument("--step-unfused-reset", action="store_true", help="--mode step: pk_step_d + pk_reset_d(flags) instead of pk_step_auto_d")
     ap.add_argument("--env-batches", type=int, default=1, help="--mode env: independent batches in flight, one stream each")
     ap.add_argument("--env-async", type=int, default=0, metavar="PASSES",
                     help="--mode env through pk_env_step_async_d with this pass budget per launch (0: synchronous)")
@@ -669,6 +873,9 @@ def main():
     ap.add_argument("--env-inner-batches", type=int, default=1,
                     help="--mode env --env-async: sub-batches INSIDE each handle (pk_set_env_batches): a call launches one "
                          "range of the handle's tables and delivers the range launched longest ago")
+    ap.add_argument("--full-line", action="store_true",
+                    help="print the FULL result (what bench_detail.json holds) on stdout instead of the compact line: for the profiling "
+                         "tools under tools/, never for the driver (it keeps only the last ~8 KB of stdout)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-evaluator", action="store_true", help="skip the stand-alone evaluator kernel leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra_workloads legs (the other BASELINE configs, PokerGameEnv)")
@@ -686,16 +893,23 @@ def main():
         env_mode(args, ctx, device)
         ctx.close()
         return
+    if args.mode == "step":   # Game.step with caller-supplied actions as its own line (tools/profile_step.sh profiles this command)
+        res = step_workload(ctx, device, args.tables, args.players, args.steps, args.warmup, args.step_replay, not args.step_unfused_reset)
+        if ctx.rank == 0:
+            print(json.dumps(step_line(res, "Game.step device-resident loop, %d x %d%s" % (args.tables, args.players, ", replayed actions" if args.step_replay else ""))))
+        ctx.close()
+        return
     policy = 0 if args.policy == "random" else 1
     fused = not args.unfused
     w = rollout_workload(ctx, device, args.tables, args.players, args.policy, args.steps, args.warmup, args.chunk,
                          args.reps, args.min_steps, args.samples, fused, args.coalesce)
     K, reps = w["K"], w["reps"]
+    dist_block = ctx.describe(device, w["n_local"])      # (collective: every rank takes part)
     ctx.barrier()
     if ctx.rank == 0:
         cfg_idx = baseline_config_index(args.tables, args.players, args.policy, ctx.world)
         out = {
-            "metric": "env-steps/sec (whole node) + showdown hand-evals/sec, 65 536 tables 6-max",
+            "metric": "env-steps/sec (whole node) + showdown hand-evals/sec, %s tables %d-max" % ("{:,}".format(args.tables).replace(",", " "), args.players),
             "value": w["total_steps"] / w["seconds"], "unit": "env-steps/s", "n_gpus": ctx.world, "steps": K,
             "warmup": args.warmup, "ms_per_step": w["seconds"] / (K * reps) * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
@@ -707,7 +921,7 @@ def main():
                                    % (args.tables, ctx.world, args.players, args.policy,
                                       "BASELINE configs[%d]" % cfg_idx if cfg_idx is not None else "not a BASELINE config"),
                        "tables_per_gpu": args.tables, "num_players": args.players, "policy": args.policy,
-                       "kernel": kernel_description(w), "launch_stats": w["stats"], "launch_stats_before_timed_region": w["stats_warm"],
+                       "kernel": kernel_description(w), "kernel_short": kernel_short(w, args.players), "launch_stats": w["stats"], "launch_stats_before_timed_region": w["stats_warm"],
                        "parallelism": "env-parallel, %d shard(s), no collective on the step path" % ctx.world},
             "hand_evals_per_s": w["hand_evals_per_s"], "hands_per_s": w["hands_per_s"], "games_per_s": w["games_per_s"],
             "roofline": rollout_roofline(w, ctx.world),
@@ -721,7 +935,11 @@ def main():
                 out["extra_workloads"] = [{"name": "extra_workloads", "error": "%s: %s" % (type(e).__name__, e)}]
         if not args.no_cpu_baseline and ctx.world == 1:
             out["cpu_baseline"] = cpu_baseline(args.players, policy)
-        print(json.dumps(out))
+        if dist_block is not None:
+            out["dist"] = dist_block
+        with open(DETAIL_FILE, "w") as f:      # everything: notes, per-sample arrays, the full roofline block of every leg
+            json.dump(out, f, indent=1)
+        print(json.dumps(out) if args.full_line else compact_line(out))   # ONE line of < 4 KB (the driver keeps the last ~8 KB of stdout)
     ctx.close()
 
 

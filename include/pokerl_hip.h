@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define PK_ABI_VERSION 4
+#define PK_ABI_VERSION 5
 #define PK_MIN_PLAYERS 2
 #define PK_MAX_PLAYERS 16 /* the reference takes any num_players (game.py:246; the deck allows 23).  Up to 16 the numpy routines it
                              calls are restated exactly: np.sum's eight-lane pairwise blocks (one up to 15 seats, two at 16) and
@@ -128,12 +128,22 @@ int pk_num_players(const pk_handle *h);
 
 /* Game.reset(dealer=...), pokerl/game.py:397-412, on tables with mask[t] != 0 (mask NULL = all tables). */
 int pk_reset(pk_handle *h, const uint8_t *mask, int dealer);
+/* Same with a DEVICE mask, asynchronous on the handle's stream: tables with (mask_d[t] & mask_bits) != 0 are reset (mask_d NULL = all
+ * tables).  mask_bits picks the bits of a mask byte that count, so that the flags pk_step_d wrote can serve as the mask directly:
+ * pk_reset_d(h, flags_d, PK_FLAG_GAME_OVER, 0) is the `if game_over: game.reset()` of a device-resident rollout loop
+ * (examples/random_game.py:8-12) without a host round trip; 0xFF = any non-zero byte. */
+int pk_reset_d(pk_handle *h, const uint8_t *mask_d, int mask_bits, int dealer);
 
 /* Game.step(action), pokerl/game.py:621-700, one action per table.
  * flags[T] (PK_FLAG_*), terr[T] (PK_TERR_*, may be NULL).  Returns PK_E_TABLE if any terr != 0. */
 int pk_step(pk_handle *h, const int32_t *actions, uint8_t *flags, uint8_t *terr);
 /* Same, device-resident I/O (inputs already in HBM; asynchronous on the handle's stream). */
 int pk_step_d(pk_handle *h, const int32_t *actions_d, uint8_t *flags_d, uint8_t *terr_d);
+/* pk_step_d with the `if game_over: game.reset()` of a rollout loop (examples/random_game.py:8-12) in the SAME launch: a table whose
+ * step ends its game (or runs into PK_TERR_HAND_CAP, which the reference would never leave) is Game.reset(dealer = 0) on the spot, exactly
+ * as pk_rollout's auto_reset does; flags_d[t] still reports PK_FLAG_GAME_OVER and terr_d[t] the error bits of the step that ended it.
+ * Saves the pk_reset_d launch of the loop (a launch costs ~4 us of a ~25 us step at 65 536 tables). */
+int pk_step_auto_d(pk_handle *h, const int32_t *actions_d, uint8_t *flags_d, uint8_t *terr_d);
 
 /* Game.get_valid_actions(player), pokerl/game.py:339-383: out[T][7] one-hot bytes.  player < 0: each table's active
  * player (the reference's `player=None`); 0 <= player < N: that seat on every table. */

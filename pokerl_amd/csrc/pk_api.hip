@@ -560,20 +560,38 @@ int pk_reset(pk_handle *h, const uint8_t *mask, int dealer) {
     int rc = upload_mask(h, mask, &dmask);
     if (rc) return rc;
     int d = ((dealer % h->N) + h->N) % h->N;
-    DISPATCH_N(h, k_reset, table_grid(h), h->S, h->hot, dmask, d);
+    DISPATCH_N(h, k_reset, table_grid(h), h->S, h->hot, dmask, 0xff, d);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return PK_OK;
 }
 
-int pk_step_d(pk_handle *h, const int32_t *actions_d, uint8_t *flags_d, uint8_t *terr_d) {
-    if (!h || !actions_d || !flags_d) return h ? h->fail(PK_E_INVALID_ARG, "pk_step_d: NULL buffer") : PK_E_INVALID_ARG;
+int pk_reset_d(pk_handle *h, const uint8_t *mask_d, int mask_bits, int dealer) {
+    if (!h) return PK_E_INVALID_ARG;
+    if (mask_d && !(mask_bits & 0xff)) return h->fail(PK_E_INVALID_ARG, "pk_reset_d: mask_bits selects no bit of a mask byte");
     ON_DEVICE(h);
     FLUSH(h);
-    const StepKernArgs ka{(const State *)h->d_S, h->hot, actions_d, flags_d, terr_d, scaled_park(h, 28)};
+    int d = ((dealer % h->N) + h->N) % h->N;
+    DISPATCH_N(h, k_reset, table_grid(h), h->S, h->hot, mask_d, mask_bits & 0xff, d);
+    HIPCHK(h, hipGetLastError());
+    return PK_OK;
+}
+
+static int launch_step(pk_handle *h, const int32_t *actions_d, uint8_t *flags_d, uint8_t *terr_d, int auto_reset) {
+    ON_DEVICE(h);
+    FLUSH(h);
+    const StepKernArgs ka{(const State *)h->d_S, h->hot, actions_d, flags_d, terr_d, scaled_park(h, 28), auto_reset ? 1 : 0};
     DISPATCH_N(h, k_step, table_grid(h), ka);
     HIPCHK(h, hipGetLastError());
     return PK_OK;
+}
+int pk_step_d(pk_handle *h, const int32_t *actions_d, uint8_t *flags_d, uint8_t *terr_d) {
+    if (!h || !actions_d || !flags_d) return h ? h->fail(PK_E_INVALID_ARG, "pk_step_d: NULL buffer") : PK_E_INVALID_ARG;
+    return launch_step(h, actions_d, flags_d, terr_d, 0);
+}
+int pk_step_auto_d(pk_handle *h, const int32_t *actions_d, uint8_t *flags_d, uint8_t *terr_d) {
+    if (!h || !actions_d || !flags_d) return h ? h->fail(PK_E_INVALID_ARG, "pk_step_auto_d: NULL buffer") : PK_E_INVALID_ARG;
+    return launch_step(h, actions_d, flags_d, terr_d, 1);
 }
 
 static int any_terr(const uint8_t *terr, int T) {

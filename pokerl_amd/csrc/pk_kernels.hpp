@@ -46,10 +46,10 @@ __global__ void __launch_bounds__(256) k_sum_counters(unsigned long long *slots,
 #endif
 
 template <int N>
-__global__ void __launch_bounds__(PK_TABLE_BLOCK) k_reset(State S, Hot H, const uint8_t *mask, int dealer) {  // Game.reset, game.py:397-412
+__global__ void __launch_bounds__(PK_TABLE_BLOCK) k_reset(State S, Hot H, const uint8_t *mask, int mask_bits, int dealer) {  // Game.reset, game.py:397-412
     int t = blockIdx.x * H.tpb + threadIdx.x;
     if ((int)threadIdx.x >= H.tpb || t >= S.T) return;
-    if (mask && !mask[t]) return;
+    if (mask && !(mask[t] & mask_bits)) return;       // (pk_reset: any non-zero byte; pk_reset_d: the caller's bits, e.g. PK_FLAG_GAME_OVER of pk_step_d's flags)
     Table<N> tb;
     tb.load(S, t);
     tb.reset_state(H, dealer);
@@ -107,7 +107,7 @@ __global__ void __launch_bounds__(PK_TABLE_BLOCK) k_pick(State S, Hot H, int pol
 // would run empty).
 // k_step's formal parameter = the layout of its kernarg segment: the two output pointers are read through the kernarg
 // segment pointer after the loop (see EnvArgs below for why).
-struct StepKernArgs { const State *Sp; Hot H; const int32_t *actions; uint8_t *flags, *terr; int park; };
+struct StepKernArgs { const State *Sp; Hot H; const int32_t *actions; uint8_t *flags, *terr; int park, auto_reset; };
 template <int N, bool ONE_PASS, int POLICY, int PASSES = 0>
 __device__ __forceinline__ void rollout_body(const State *__restrict__ Sp, const Hot &H, int K, int auto_reset, int park, int slack, int clear_terr,
                                              const int32_t *actions = nullptr, const StepKernArgs *ext = nullptr) {
@@ -218,7 +218,7 @@ __device__ __forceinline__ void rollout_body(const State *__restrict__ Sp, const
                 as_global(S.mid)[t] = 0;
                 as_global(S.valid)[t] = (uint8_t)tb.valid_mask(high_bet);
             }
-            const uint8_t te = ext_ok_l ? (uint8_t)tb.terr : (uint8_t)PK_TERR_INVALID_ACTION;
+            const uint8_t te = ext_ok_l ? (uint8_t)(tb.terr | tb.seen) : (uint8_t)PK_TERR_INVALID_ACTION;   // (seen: the error bits of a table pk_step_auto_d reset on the spot)
             flags_out[t] = ext_ok_l ? (uint8_t)tb.flags : (uint8_t)0;              // :649-651: no mutation
             as_global(S.terr)[t] = te;
             if (terr_out) terr_out[t] = te;
@@ -260,7 +260,7 @@ template <int N>
 __global__ void __launch_bounds__(PK_TABLE_BLOCK, PK_WAVES_PER_SIMD_N(N)) k_step(StepKernArgs) {
     const StepKernArgs *ka = (const StepKernArgs *)__builtin_amdgcn_kernarg_segment_ptr();
     const Hot H = ka->H;
-    rollout_body<N, false, PK_POLICY_EXTERNAL, 1>(ka->Sp, H, 0, 0, ka->park, PK_WAVE, 1, ka->actions, ka);
+    rollout_body<N, false, PK_POLICY_EXTERNAL, 1>(ka->Sp, H, 0, ka->auto_reset, ka->park, PK_WAVE, 1, ka->actions, ka);
 }
 template <int N>
 __global__ void __launch_bounds__(PK_TABLE_BLOCK, PK_WAVES_PER_SIMD_N(N)) k_rollout_single(const State *__restrict__ Sp, Hot H, int K, int auto_reset, int park, int slack, int clear_terr) {
@@ -969,7 +969,7 @@ __global__ void k_eval7_prefix(int a, int b, int fast, uint32_t count, uint32_t 
 // explicit instantiations), in parallel; pk_api.hip declares them `extern template` and launches them.
 #define PK_ROLLOUT_SIG (const State *__restrict__, Hot, int, int, int, int, int)
 #define PK_TABLE_KERNELS(X, N)                                               \
-    X(N, k_reset, (State, Hot, const uint8_t *, int))                        \
+    X(N, k_reset, (State, Hot, const uint8_t *, int, int))                      \
     X(N, k_make_fresh, (Hot, Fresh *))                                       \
     X(N, k_pick, (State, Hot, int, int32_t *))                               \
     X(N, k_rollout, PK_ROLLOUT_SIG)                                          \

@@ -101,6 +101,35 @@ class VecGame:
             return out
         return out + (terr,)
 
+    # ---- device-resident forms (a learner on the same GPU: no host round trip; asynchronous on the handle's stream)
+    @staticmethod
+    def _dptr(p):
+        """A device pointer as c_void_p: an int (tensor.data_ptr()), a c_void_p, or an object with .ptr (hipmem.DeviceBuffer)."""
+        if p is None:
+            return None
+        if hasattr(p, 'ptr'):
+            p = p.ptr
+        return p if isinstance(p, C.c_void_p) else C.c_void_p(int(p))
+
+    def step_d(self, actions_d, flags_d, terr_d=None, auto_reset=False):
+        """`Game.step` (game.py:621-700) on DEVICE buffers (pk_step_d): actions_d i32[T] in, flags_d u8[T] (PK_FLAG_* bits =
+        the reference's (game_over, hand_over, turn_over)) and terr_d u8[T] (optional) out.  A table whose action is not
+        valid is left untouched and gets PK_TERR_INVALID_ACTION (game.py:649-651); nothing is raised -- the caller reads
+        terr_d.  Asynchronous: order it with your stream through set_stream / wait_event / record_event.
+        auto_reset=True (pk_step_auto_d): a table whose step ends its game is `Game.reset()` in the same launch (flags_d still says
+        game_over) -- the rollout loop of examples/random_game.py:8-12 without a separate reset launch."""
+        fn = self._lib.pk_step_auto_d if auto_reset else self._lib.pk_step_d
+        L.check(fn(self._h, self._dptr(actions_d), self._dptr(flags_d), self._dptr(terr_d)), self._h)
+
+    def pick_actions_d(self, actions_d, policy=0):
+        """The action the in-kernel agent `policy` takes on every table -> actions_d i32[T] (pk_pick_actions_d)."""
+        L.check(self._lib.pk_pick_actions_d(self._h, int(policy), self._dptr(actions_d)), self._h)
+
+    def reset_d(self, mask_d=None, mask_bits=0xff, dealer=0):
+        """`Game.reset` on the tables with (mask_d[t] & mask_bits) != 0 (pk_reset_d; mask_d None = all): with step_d's flags_d
+        and mask_bits = FLAG_GAME_OVER this is `if game_over: game.reset()` of examples/random_game.py:8-12 on the device."""
+        L.check(self._lib.pk_reset_d(self._h, self._dptr(mask_d), int(mask_bits), int(dealer)), self._h)
+
     def check_actions(self, actions, table_offset=0):
         """Game.step's precondition (game.py:648-651) for the whole batch, checked on the device (pk_check_actions): raises
         the reference's ValueError naming the first offending table; nothing is mutated."""

@@ -463,6 +463,60 @@ def test_device_pointer_step(HB, O):
         hip.hipFree(p)
 
 
+def test_device_resident_game_loop(HB, O):
+    """The rollout loop of examples/random_game.py:8-12 with every buffer in HBM, through the host mirror: VecGame.pick_actions_d +
+    step_d + reset_d(flags, GAME_OVER) (pk_pick_actions_d / pk_step_d / pk_reset_d: the step's own flags are the reset mask), and
+    step_d(auto_reset=True) (pk_step_auto_d: the reset inside the step's launch) -- both against the oracle's step + reset, every
+    state byte, at full-width waves with a ragged tail and at a small batch."""
+    import pokerl_amd
+    from pokerl_amd import _lib as L
+    from pokerl_amd.hipmem import DeviceBuffer
+    for T, N, steps in ((65536 + 19, 6, 60), (1500, 9, 260), (4096, 2, 200)):
+        hb = HB(T, N, seed=977)
+        hb2 = HB(T, N, seed=977)
+        g, g2 = hb.g, hb2.g
+        o = O.OracleGame(T, N, seed=977)
+        o.reset(); g.reset(); g2.reset()
+        act, flags, terr = DeviceBuffer(T * 4), DeviceBuffer(T), DeviceBuffer(T)
+        act2, flags2, terr2 = DeviceBuffer(T * 4), DeviceBuffer(T), DeviceBuffer(T)
+        resets = 0
+        for s in range(steps):
+            a = o.pick_actions(0)
+            fo, eo = o.step(a)
+            over = ((fo & 1) | ((eo & 4) >> 2)).astype(np.uint8)      # game over, or a step the reference would never leave
+            g.pick_actions_d(act, 0)
+            g.step_d(act, flags, terr)
+            g.sync()                                                  # (the handle's stream is non-blocking: hipMemcpy does not wait for it)
+            assert np.array_equal(act.download(np.int32, T), a), s
+            fl, te = flags.download(np.uint8, T), terr.download(np.uint8, T)
+            assert np.array_equal(fl, fo) and np.array_equal(te, eo), s
+            g.reset_d(flags, L.FLAG_GAME_OVER)                        # HAND_OVER / TURN_OVER bits alone must not reset a table
+            if (eo & 4).any():
+                g.reset_d(terr, L.TERR_HAND_CAP)
+            g2.pick_actions_d(act2, 0)
+            g2.step_d(act2, flags2, terr2, auto_reset=True)
+            g2.sync()
+            fl2, te2 = flags2.download(np.uint8, T), terr2.download(np.uint8, T)
+            assert np.array_equal(fl2 & 6, fo & 6) and np.array_equal(fl2 & 1, over) and np.array_equal(te2, eo), s
+            if over.any():
+                o.reset(mask=over)
+                resets += int(over.sum())
+            if s % 20 == 19 or s == steps - 1:
+                assert_same(o.snapshot(), hb.snapshot(), "T=%d step %d (step_d + reset_d)" % (T, s))
+                assert_same(o.snapshot(), hb2.snapshot(), "T=%d step %d (step_d auto_reset)" % (T, s))
+        assert resets > 0 or T > 60000        # (the small batches run long enough for games to end)
+        g.reset_d()                           # mask None = every table
+        o.reset()
+        assert_same(o.snapshot(), hb.snapshot(), "reset_d(all)")
+        for b in (act, flags, terr, act2, flags2, terr2):
+            b.free()
+    lib = L.lib()
+    g = pokerl_amd.VecGame(64, num_players=3)
+    m = DeviceBuffer(64)
+    assert lib.pk_reset_d(g._h, m.ptr, 0, 0) == L.PK_E_INVALID_ARG              # a mask that selects no bit
+    assert lib.pk_step_auto_d(g._h, None, None, None) == L.PK_E_INVALID_ARG
+
+
 def test_bad_arguments_are_reported_not_fatal(HB):
     import ctypes as C
     import pokerl_amd
@@ -499,9 +553,14 @@ def test_bench_two_ranks_rehearsal(tmp_path):
     assert out.returncode == 0, out.stderr[-3000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     r = json.loads(line)
+    assert len(line) < 4096
     assert r["n_gpus"] == 2 and r["scaling"] == "weak" and r["steps"] == 256
-    assert r["value"] > 0 and abs(r["value"] - 2 * 8192 * 256 / (r["ms_per_step"] * 256 / 1e3)) / r["value"] < 1e-6
+    assert r["value"] > 0 and abs(r["value"] - 2 * 8192 * 256 / (r["ms_per_step"] * 256 / 1e3)) / r["value"] < 1e-3
     assert "cpu_baseline" not in r and r["roofline"]["frac"] > 0
+    # the `dist` block: the collective library saw both ranks, each with its shard (value = units of ALL ranks / MAX seconds, above)
+    d = r["dist"]
+    assert d["backend"] == "gloo" and d["world"] == 2 and d["devices"] == [0, 0] and d["tables_per_rank"] == [8192, 8192]
+    assert d["collectives_on_step_path"] == 0
 
 
 def test_device_resident_env_loop(HB, O):
@@ -691,26 +750,55 @@ def test_empty_and_minimal_inputs(HB, O):
 
 
 def test_bench_json_contract():
-    """`python bench.py` prints exactly ONE JSON line on stdout with every field the driver's contract names."""
+    """`python bench.py` prints exactly ONE JSON line on stdout -- under 4 KB, so that it fits the tail of stdout the driver keeps --
+    with every field the driver's contract names; everything else (notes, per-sample arrays, the full roofline block of every leg) is
+    in bench_detail.json next to bench.py."""
     import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, PK_BENCH_CPU_BUDGET="1", PK_BENCH_EVAL_LOG2="22")
+    detail_path = os.path.join(root, "bench_detail.json")
+    if os.path.exists(detail_path):
+        os.remove(detail_path)
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "256", "--warmup", "64"],
                          capture_output=True, text=True, env=env, timeout=600, cwd=root)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, lines
-    r = json.loads(lines[0])
+    assert len(lines[0]) < 4096, len(lines[0])
+    c = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "evaluator", "extra_workloads", "detail"):
+        assert k in c, k
+    assert c["metric"] == "env-steps/sec (whole node) + showdown hand-evals/sec, 65 536 tables 6-max"      # BASELINE.json's metric
+    assert c["n_gpus"] == 1 and c["steps"] == 256 and c["warmup"] == 64 and c["higher_is_better"] is True
+    assert c["scaling"] == "weak" and c["vs_baseline"] is None and c["dtype"] == "f64" and c["data"] == "synthetic"
+    assert "workload" in c["config"] and "model" not in c["config"] and "BASELINE configs[2]" in c["config"]["workload"]
+    assert c["config"]["kernel"].startswith("k_rollout<6>") and "dist" not in c
+    assert abs(c["value"] - 65536 * 256 / (c["ms_per_step"] * 256 / 1e3)) / c["value"] < 1e-3     # (five significant digits in the line)
+    crf = c["roofline"]
+    assert crf["bound"] == "valu-issue" and crf["unit"] == "wave-instr/s" and 0.0 < crf["frac"] <= 0.5 and crf["traffic"] > 0
+    assert abs(crf["frac"] - crf["achieved"] / crf["peak"]) < 1e-4 and crf["source"].endswith("_summary.json") and crf["hbm_algorithmic"]["frac"] > 0
+    assert c["cpu_baseline"]["kind"] == "port" and c["cpu_baseline"]["cores"] == 1 and c["cpu_baseline"]["value"] > 0 and c["cpu_baseline"]["sample"]
+    assert c["evaluator"]["hand_evals_per_s"] > 0 and 0.0 < c["evaluator"]["frac"] <= 1.0
+    cx = c["extra_workloads"]
+    assert len(cx) == 9 and all(len(x["name"]) <= 40 for x in cx)
+    for x in cx:
+        assert set(x) >= {"name", "value", "unit", "kernel_ms", "bound", "frac", "hbm_frac"} and x["value"] > 0 and 0.0 < x["frac"] <= 1.0, x
+    assert [x["name"].split()[0] for x in cx] == ["cfg1", "cfg4", "cfg2", "Game.step", "Game.step", "Game.step", "env.step", "env.step", "env.step"]
+    assert cx[3]["bound"] == cx[4]["bound"] == cx[5]["bound"] == "hbm" and cx[3]["unit"] == "env-steps/s" and cx[4]["value"] >= cx[3]["value"] * 0.95
+    assert cx[5]["frac"] > cx[4]["frac"]                  # a batch that fills the chip is bound by its bytes, 65 536 tables by the slowest table's chain
+    assert abs(cx[1]["hand_evals_per_s"] / cx[1]["value"] - 1.0) < 1e-3       # configs[4]: one in-game evaluation per env-step
+
+    # ---- the detail file: what the line held up to round 4
+    assert c["detail"] == "bench_detail.json"
+    r = json.load(open(detail_path))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in r, k
-    assert r["n_gpus"] == 1 and r["steps"] == 256 and r["warmup"] == 64 and r["higher_is_better"] is True
-    assert r["scaling"] == "weak" and r["vs_baseline"] is None and r["dtype"] == "f64" and r["data"] == "synthetic"
-    assert "workload" in r["config"] and "model" not in r["config"] and "BASELINE configs[2]" in r["config"]["workload"]
-    assert abs(r["value"] - 65536 * 256 / (r["ms_per_step"] * 256 / 1e3)) / r["value"] < 1e-6
+    assert abs(r["value"] - 65536 * 256 / (r["ms_per_step"] * 256 / 1e3)) / r["value"] < 1e-6 and abs(r["value"] - c["value"]) / r["value"] < 1e-4
     assert r["reps"] == 2048 and r["samples"] == 7 and len(r["sample_seconds"]) == 7   # 2 048 blocks of 256 steps = 524 288 per sample
     rf = r["roofline"]
     # the binding roofline leads: VALU issue, from the committed rocprofv3 PMC summary of this workload x this run's launch time
@@ -736,12 +824,12 @@ def test_bench_json_contract():
     assert ev["roofline"]["bytes_per_eval"] == 12 and ev["hand_evals_per_s"] > 0 and 0.0 < ev["roofline"]["frac"] <= 1.0
     assert "HYBRID" in rf["note"] and "COMMITTED" in rf["note"]      # says where VALU-per-wave-step comes from
     assert cm["half_rate_share_source"] and 0.4 < cm["half_rate_share"] < 0.8
-    # the other single-GPU BASELINE configs and the PokerGameEnv path are driver-timed legs of the same line
+    # the other single-GPU BASELINE configs, Game.step with the caller's actions and the PokerGameEnv path are driver-timed legs
     xs = r["extra_workloads"]
-    assert len(xs) == 6 and [("configs[1]" in xs[0]["name"]), ("configs[4]" in xs[1]["name"])] == [True, True]
+    assert len(xs) == 9 and [("configs[1]" in xs[0]["name"]), ("configs[4]" in xs[1]["name"])] == [True, True]
     assert "one launch per call" in xs[2]["name"] and xs[2]["launch_stats"]["max"] == 20 and xs[2]["value"] < r["value"]
     for x in xs:
-        for k in ("name", "value", "unit", "kernel", "kernel_ms", "launches", "roofline"):
+        for k in ("name", "short", "value", "unit", "kernel", "kernel_ms", "launches", "roofline"):
             assert k in x, (x.get("name"), k)
         xr = x["roofline"]
         assert x["value"] > 0 and x["kernel_ms"] > 0 and x["launches"] > 0 and xr["bound"] in ("valu-issue", "hbm")
@@ -749,10 +837,14 @@ def test_bench_json_contract():
         assert abs(xr["frac"] - xr["achieved"] / xr["peak"]) < 1e-9
     # configs[4] is the showdown-heavy half of the metric: one in-game evaluation per env-step
     assert abs(xs[1]["hand_evals_per_s"] / xs[1]["value"] - 1.0) < 1e-3 and xs[0]["unit"] == xs[1]["unit"] == "env-steps/s"
-    for x in xs[3:]:                                               # PokerGameEnv legs: measured HBM traffic beside the VALU figure
+    for x in xs[3:6]:                                              # Game.step legs: the HBM roofline on SURVEY 8d's bytes + measured traffic
+        xr = x["roofline"]
+        assert x["unit"] == "env-steps/s" and "k_step" in x["kernel"] and xr["bound"] == "hbm" and x["tables_with_error_bits"] < 40
+        assert abs(xr["achieved"] - 478 * x["value"] / 1e9) / xr["achieved"] < 1e-6 and xr["traffic"] > 0.5 * 65536 * 478
+    for x in xs[6:]:                                               # PokerGameEnv legs: measured HBM traffic beside the VALU figure
         assert x["unit"] == "env.step/s" and x["kernel"].startswith("k_env_step") and 0.0 < x["roofline"]["hbm"]["frac"] <= 1.0
         assert x["roofline"]["traffic"] > 0 and 4.0 < x["game_steps_per_env_step"] < 8.0
-    assert xs[3]["ready_fraction_per_launch"] == 1.0 and 0.3 < xs[4]["ready_fraction_per_launch"] < 1.0
+    assert xs[6]["ready_fraction_per_launch"] == 1.0 and 0.3 < xs[7]["ready_fraction_per_launch"] < 1.0
 
 
 @pytest.mark.parametrize("N,policy", [(6, 0), (9, 1), (2, 0), (10, 0)])

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     L = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(L, name), name
-    assert _lib.lib().pk_abi_version() == _lib.ABI_VERSION == 4
+    assert _lib.lib().pk_abi_version() == _lib.ABI_VERSION == 5
 
 
 def test_no_device_fails_loudly():
@@ -164,6 +164,33 @@ if rank == 0:
                           cfg=bench.baseline_config_index(65536, 6, "random", world))))
 ctx.close()
 '''
+
+
+def test_bench_line_is_compact():
+    """bench.py's stdout line must fit the ~8 KB tail of stdout the driver keeps (round 4's 20.9 KB line was never parsed): the full
+    result of that very run (profiles/r04_bench_driver.json) goes through compact_line() and comes out under 4 KB with every contract
+    key, `roofline` and `cpu_baseline`; what is dropped stays in the detail file."""
+    import json
+    import bench
+    full = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_driver.json")))
+    assert len(json.dumps(full)) > 20000
+    full["dist"] = {"backend": "nccl", "world": 8, "devices": list(range(8)), "tables_per_rank": [65536] * 8, "collectives_on_step_path": 0}
+    full["extra_workloads"].append({"name": "a leg that failed", "error": "RuntimeError: " + "x" * 500})
+    text = bench.compact_line(full)
+    assert len(text) < bench.LINE_LIMIT == 4096 and "\n" not in text
+    c = json.loads(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline", "evaluator", "extra_workloads", "dist", "detail"):
+        assert k in c, k
+    assert abs(c["value"] - full["value"]) / full["value"] < 1e-4 and c["config"]["workload"] == full["config"]["workload"]
+    rf = c["roofline"]
+    assert set(rf) == {"bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms", "steps_per_launch", "source", "hbm_algorithmic"}
+    assert rf["bound"] == "valu-issue" and abs(rf["frac"] - full["roofline"]["frac"]) < 1e-4 and list(rf["hbm_algorithmic"]) == ["frac"]
+    assert c["cpu_baseline"]["cores"] == 1 and c["cpu_baseline"]["all_cores"]["cores"] == 16 and c["cpu_baseline"]["kind"] == "port"
+    assert len(c["extra_workloads"]) == 7 and all(len(x["name"]) <= 40 for x in c["extra_workloads"])
+    assert c["extra_workloads"][-1]["error"].startswith("RuntimeError") and len(c["extra_workloads"][-1]["error"]) <= 80
+    assert c["extra_workloads"][3]["bound"] == "valu-issue" and 0 < c["extra_workloads"][3]["hbm_frac"] < 1      # env leg: measured HBM beside VALU
+    assert c["dist"]["world"] == 8
 
 
 def test_bench_aggregation_gloo_world2(tmp_path):

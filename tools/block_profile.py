@@ -14,21 +14,24 @@ from pokerl_amd import _lib as L  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 6
 policy = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-T, K = 65536, 512
+T, K = int(os.environ.get("PK_BP_T", "65536")), int(os.environ.get("PK_BP_K", "512"))
+FUSED = os.environ.get("PK_BP_FUSED", "1") != "0"   # 0: K single-step launches (k_rollout_single: the state round-trips HBM every step)
 g = pokerl_amd.VecGame(T, num_players=N)
 g.reset()
-g.rollout(K, policy)
+g.rollout(K, policy, True, FUSED)
 lib = L.lib()
 lib.pk_prof_read.argtypes = [C.c_void_p, C.c_void_p]
 buf = np.zeros(16, np.uint64)
 lib.pk_prof_read(g._h, L.ptr(buf))
 launches = 4
-ms, c = g.time_rollout(K, policy, True, True, launches)
+ms, c = g.time_rollout(K, policy, True, FUSED, launches)
+if not FUSED:
+    ms *= K     # time_rollout reports per LAUNCH; below everything is per block of K steps
 lib.pk_prof_read(g._h, L.ptr(buf))
 names = ["action+valid", "cursor", "end_pre", "eval", "sidepot", "setup", "deal", "other"]
-waves = T // 64
+waves = max(1, (T + 63) // 64) if T >= 65536 else 1024
 tot = float(buf[:8].sum())
-print("N=%d policy=%d  %.3f ms/launch  %.2f G env-steps/s (diagnostic build; read shares, not time)" % (N, policy, ms, T * K / ms / 1e6))
+print("N=%d T=%d %s policy=%d  %.3f ms/launch  %.2f G env-steps/s (diagnostic build; read shares, not time)" % (N, T, "fused" if FUSED else "single-step launches", policy, ms, T * K / ms / 1e6))
 for i, n in enumerate(names):
     print("  %-14s %6.1f %%   %8.0f cycles/wave-step" % (n, 100 * buf[i] / tot, buf[i] / waves / launches / K))
 print("  cursor passes/step %.2f  end_blocks/step %.2f  eval passes/step %.2f  sidepot iters/step %.2f" % tuple(

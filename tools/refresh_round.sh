@@ -21,14 +21,15 @@ tools/profile_eval7.sh ${R}_eval7
 fi
 if [ "$WHAT" != "profiles" ]; then
 cd $ROOT
-python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${R}_bench_driver.json 2> gpurun_out/${R}_bench_driver.err
-python bench.py --no-extra > gpurun_out/${R}_bench_65536x6.json 2>/dev/null
-python bench.py --gpus 1 --steps 20 --warmup 5 --coalesce 0 --no-cpu-baseline --no-evaluator --no-extra > gpurun_out/${R}_bench_driver_nocoalesce.json 2>/dev/null
-python bench.py --players 9 --policy allin --no-cpu-baseline --no-evaluator --no-extra > gpurun_out/${R}_bench_65536x9_allin.json 2>/dev/null
-python bench.py --tables 4096 --players 2 --no-cpu-baseline --no-evaluator --no-extra > gpurun_out/${R}_bench_4096x2.json 2>/dev/null
-python bench.py --tables 1048576 --no-cpu-baseline --no-evaluator --no-extra --samples 3 --min-steps 8192 > gpurun_out/${R}_bench_1048576x6.json 2>/dev/null
-python bench.py --unfused --steps 512 --warmup 64 --no-cpu-baseline --no-evaluator --samples 3 > gpurun_out/${R}_bench_65536x6_unfused.json 2>/dev/null
-for n in 10 12 13 15 16; do python bench.py --players $n --no-cpu-baseline --no-evaluator --no-extra --samples 3 --min-steps 131072 > gpurun_out/${R}_bench_65536x$n.json 2>/dev/null; done
+python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${R}_bench_driver_line.json 2> gpurun_out/${R}_bench_driver.err   # the driver's command: the compact line ...
+cp bench_detail.json gpurun_out/${R}_bench_driver.json                                                                      # ... and everything behind it
+python bench.py --full-line --no-extra > gpurun_out/${R}_bench_65536x6.json 2>/dev/null
+python bench.py --full-line --gpus 1 --steps 20 --warmup 5 --coalesce 0 --no-cpu-baseline --no-evaluator --no-extra > gpurun_out/${R}_bench_driver_nocoalesce.json 2>/dev/null
+python bench.py --full-line --players 9 --policy allin --no-cpu-baseline --no-evaluator --no-extra > gpurun_out/${R}_bench_65536x9_allin.json 2>/dev/null
+python bench.py --full-line --tables 4096 --players 2 --no-cpu-baseline --no-evaluator --no-extra > gpurun_out/${R}_bench_4096x2.json 2>/dev/null
+python bench.py --full-line --tables 1048576 --no-cpu-baseline --no-evaluator --no-extra --samples 3 --min-steps 8192 > gpurun_out/${R}_bench_1048576x6.json 2>/dev/null
+python bench.py --full-line --unfused --steps 512 --warmup 64 --no-cpu-baseline --no-evaluator --samples 3 > gpurun_out/${R}_bench_65536x6_unfused.json 2>/dev/null
+for n in 10 12 13 15 16; do python bench.py --full-line --players $n --no-cpu-baseline --no-evaluator --no-extra --samples 3 --min-steps 131072 > gpurun_out/${R}_bench_65536x$n.json 2>/dev/null; done
 python bench.py --mode env --steps 200 --warmup 20 2>/dev/null | tail -1 > gpurun_out/${R}_bench_env.json
 python bench.py --mode env --steps 200 --warmup 20 --env-batches 4 2>/dev/null | tail -1 > gpurun_out/${R}_bench_env_sync_batches4.json
 python bench.py --mode env --steps 2000 --warmup 200 --env-async 8 2>/dev/null | tail -1 > gpurun_out/${R}_bench_env_async8_batches1.json
@@ -36,6 +37,6 @@ python bench.py --mode env --steps 2000 --warmup 200 --env-async 8 --env-batches
 python bench.py --mode env --steps 2000 --warmup 200 --env-async 8 --tables 524288 --env-inner-batches 3 2>/dev/null | tail -1 > gpurun_out/${R}_bench_env_async8_inner3_524288.json
 python tools/launch_overhead.py > gpurun_out/${R}_launch_overhead.txt 2>&1
 python tools/measure_api.py > gpurun_out/${R}_measure_api.txt 2>&1
-for c in 128 256 512 1024 2048; do echo "coalesce $c: $(python bench.py --gpus 1 --steps 20 --warmup 5 --coalesce $c --no-cpu-baseline --no-evaluator --no-extra --samples 3 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('%.2f G  %s' % (r['value']/1e9, r['config']['launch_stats']))")"; done > gpurun_out/${R}_coalesce_sweep.txt 2>&1
+for c in 128 256 512 1024 2048; do echo "coalesce $c: $(python bench.py --full-line --gpus 1 --steps 20 --warmup 5 --coalesce $c --no-cpu-baseline --no-evaluator --no-extra --samples 3 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('%.2f G  %s' % (r['value']/1e9, r['config']['launch_stats']))")"; done > gpurun_out/${R}_coalesce_sweep.txt 2>&1
 fi
 echo refreshed $R $WHAT

@@ -26,6 +26,7 @@ PY
 done
 [ -d gpurun_out/prof_${R}_eval7 ] && python tools/summarize_eval7.py ${R}_eval7 | tail -3
 for f in launch_overhead coalesce_sweep measure_api; do [ -f gpurun_out/${R}_$f.txt ] && cp gpurun_out/${R}_$f.txt profiles/${R}_$f.txt; done
+[ -s gpurun_out/${R}_bench_driver_line.json ] && tail -1 gpurun_out/${R}_bench_driver_line.json > profiles/${R}_bench_driver_line.json && wc -c profiles/${R}_bench_driver_line.json
 for f in driver driver_nocoalesce 65536x6 65536x9_allin 4096x2 1048576x6 65536x6_unfused 65536x10 65536x12 65536x13 65536x15 65536x16 env env_sync_batches4 env_async8_batches1 env_async8_batches4 env_async8_inner3_524288; do
   [ -s gpurun_out/${R}_bench_$f.json ] || continue
   tail -1 gpurun_out/${R}_bench_$f.json > profiles/${R}_bench_$f.json

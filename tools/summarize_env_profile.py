@@ -55,6 +55,14 @@ summary = {
 summary["waves_per_simd_launched"] = waves / 1024.0
 summary["waves_per_simd_resident"] = min(waves / 1024.0, float(max(1, min(8, 512 // max(1, 2 * vgpr)))))
 counters = {}
+# The counters of one dispatch accumulate over rocprofv3's bracket around it -- the dispatch plus the packets that start and stop the
+# counters -- which is a few microseconds LONGER than the kernel's own start/end timestamps (round 4 divided GRBM_GUI_ACTIVE by the sum of
+# those timestamps and got an "effective clock" of 2.46 / 2.87 / 2.74 GHz: above the 2.4 GHz the chip runs at, by the share of the bracket
+# in a 30 us launch).  So: (1) show that the PMC passes SERIALISE the dispatches (no launch of the pass starts before the previous one has
+# ended: a dispatch's counters hold that dispatch's events only, whatever the un-profiled run overlaps -- instruction and byte counts per
+# launch are exact and need no window at all); (2) take the clock over the pass's own accumulation window, first start to last end of
+# its kernels: busy cycles / elapsed time, <= the true clock by construction.
+serial = {}
 for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
     if not os.path.isdir(d):
         continue
@@ -62,7 +70,11 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
     if not files:
         continue
     ptr = glob.glob(os.path.join(d, "*", "*_kernel_trace.csv"))
-    pass_ns = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(ptr[0])) if kname in r["Kernel_Name"]) if ptr else 0
+    krows = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(open(ptr[0])) if kname in r["Kernel_Name"])) if ptr else []
+    pass_ns = sum(e - b for b, e in krows)
+    span_ns = (krows[-1][1] - krows[0][0]) if krows else 0
+    overlaps = sum(1 for i in range(1, len(krows)) if krows[i][0] < krows[i - 1][1])
+    serial[os.path.basename(d)] = {"launches": len(krows), "overlapping_launches": overlaps, "kernel_ns_sum": pass_ns, "span_ns": span_ns}
     agg, cnt = collections.defaultdict(float), collections.defaultdict(int)
     for r in csv.DictReader(open(files[0])):
         if kname in r["Kernel_Name"]:
@@ -70,8 +82,14 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
             cnt[r["Counter_Name"]] += 1
     for k, v in agg.items():
         counters[k] = v / cnt[k]                        # per mean launch of THAT pass
-        if k == "GRBM_GUI_ACTIVE" and pass_ns:          # summed over the 8 XCDs: clock of that pass
-            summary["effective_clock_GHz"] = v / 8.0 / pass_ns
+        if k == "GRBM_GUI_ACTIVE" and span_ns:          # summed over the 8 XCDs
+            summary["effective_clock_GHz"] = v / 8.0 / span_ns
+            summary["effective_clock_note"] = ("GRBM_GUI_ACTIVE / 8 XCDs / (first start .. last end of the pass's kernels): busy cycles over the pass's own "
+                                               "accumulation window; per sum of kernel timestamps it would read %.2f GHz (the counter bracket of a dispatch is "
+                                               "longer than the kernel)" % (v / 8.0 / max(1, pass_ns)))
+            summary["counter_bracket_us_per_launch"] = (v / 8.0 / 2.4 - pass_ns) / max(1, len(krows)) / 1e3
+summary["pmc_passes"] = serial
+summary["pmc_dispatches_serialised"] = all(v["overlapping_launches"] == 0 for v in serial.values())
 summary["pmc_per_launch"] = counters
 if "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
     summary["hbm_traffic_bytes_per_launch"] = (2.0 * counters["FETCH_SIZE"] + counters["WRITE_SIZE"]) * 1024.0

@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""Distils gpurun_out/prof_<tag>/ (rocprofv3 kernel trace + separate PMC passes of ONE `bench.py --mode step` command, made by
+tools/profile_step.sh) into profiles/<tag>_kernel_stats.csv + profiles/<tag>_summary.json: per kernel of the Game.step loop
+(k_pick, k_step, k_reset) the average launch duration and the per-launch counters, and per LOOP ITERATION (one launch of each) the HBM
+traffic by the guide's recipe (separate --pmc passes; FETCH_SIZE doubled on gfx950) -- bench.py's Game.step legs quote
+`hbm_traffic_bytes_per_step` as `roofline.traffic`.     usage: tools/summarize_step_profile.py <tag>"""
+import collections
+import csv
+import glob
+import json
+import os
+import re
+import shutil
+import sys
+
+tag = sys.argv[1]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, "gpurun_out", "prof_" + tag)
+dst = os.path.join(root, "profiles")
+KERNELS = ("k_pick<", "k_step<", "k_reset<", "k_step_bet<", "k_step_end<")
+
+
+def bench_line(log):
+    for line in reversed(open(log).read().splitlines()):
+        if line.startswith("{") and '"metric"' in line:
+            return json.loads(line)
+    return None
+
+
+def short(name):
+    for k in KERNELS:
+        if k in name:
+            return k[:-1]
+    return None
+
+
+line = bench_line(os.path.join(src, "trace.log"))
+stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
+shutil.copy(stats, os.path.join(dst, tag + "_kernel_stats.csv"))
+trace = glob.glob(os.path.join(src, "trace", "*", "*_kernel_trace.csv"))[0]
+per = collections.defaultdict(list)
+first = {}
+for r in csv.DictReader(open(trace)):
+    k = short(r["Kernel_Name"])
+    if k:
+        per[k].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        first.setdefault(k, r)
+m = re.search(r"(\d+) x (\d+)", line["name"])
+summary = {"tag": tag, "workload": {"tables": int(m.group(1)), "players": int(m.group(2)), "replay": "replayed" in line["name"],
+                                    "command": json.load(open(os.path.join(src, "workload.json")))["command"]},
+           "bench_line_of_the_traced_run": {k: line[k] for k in ("value", "kernel_ms", "launches", "device_ms", "ms_per_step")},
+           "kernels": {}}
+for k, d in per.items():
+    d.sort()
+    r = first[k]
+    summary["kernels"][k] = {"launches": len(d), "avg_ms": sum(d) / len(d) / 1e6, "median_ms": d[len(d) // 2] / 1e6, "min_ms": d[0] / 1e6, "max_ms": d[-1] / 1e6,
+                             "vgpr": int(r["VGPR_Count"]), "agpr": int(r["Accum_VGPR_Count"]), "sgpr": int(r["SGPR_Count"]),
+                             "lds_bytes": int(r["LDS_Block_Size"]), "scratch_bytes": int(r["Scratch_Size"]),
+                             "grid": int(r["Grid_Size_X"]), "workgroup": int(r["Workgroup_Size_X"])}
+summary["k_step_avg_ms"] = sum(summary["kernels"][k]["avg_ms"] for k in summary["kernels"] if k.startswith("k_step"))
+summary["kernel_ms_per_step_sum"] = sum(v["avg_ms"] for v in summary["kernels"].values())
+# PMC passes: per kernel, the mean per launch; a loop iteration = one launch of each kernel of the loop
+for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
+    if not os.path.isdir(d):
+        continue
+    files = glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))
+    if not files:
+        continue
+    agg, cnt = collections.defaultdict(float), collections.defaultdict(int)
+    for r in csv.DictReader(open(files[0])):
+        k = short(r["Kernel_Name"])
+        if k:
+            agg[(k, r["Counter_Name"])] += float(r["Counter_Value"])
+            cnt[(k, r["Counter_Name"])] += 1
+    for (k, c), v in agg.items():
+        summary["kernels"].setdefault(k, {}).setdefault("pmc_per_launch", {})[c] = v / cnt[(k, c)]
+tot = 0.0
+for k, v in summary["kernels"].items():
+    p = v.get("pmc_per_launch", {})
+    if "FETCH_SIZE" in p and "WRITE_SIZE" in p:
+        v["hbm_traffic_bytes_per_launch"] = (2.0 * p["FETCH_SIZE"] + p["WRITE_SIZE"]) * 1024.0
+        tot += v["hbm_traffic_bytes_per_launch"]
+    if p.get("SQ_ACTIVE_INST_VALU") and "SQ_THREAD_CYCLES_VALU" in p:
+        v["lanes_active"] = p["SQ_THREAD_CYCLES_VALU"] / (64.0 * p["SQ_ACTIVE_INST_VALU"])
+    if p.get("SQ_WAVES"):
+        v["valu_insts_per_wave"] = p.get("SQ_INSTS_VALU", 0.0) / p["SQ_WAVES"]
+summary["hbm_traffic_bytes_per_step"] = tot
+summary["hbm_traffic_note"] = "(2*FETCH_SIZE + WRITE_SIZE) KiB per mean launch, summed over the kernels of one loop iteration: FETCH_SIZE doubled per the guide's gfx950 correction (an upper estimate)"
+T, N = summary["workload"]["tables"], summary["workload"]["players"]
+summary["algorithmic_bytes_per_step"] = (2 * (35 * N + 21) + 16) * T
+summary["traffic_over_algorithmic"] = tot / summary["algorithmic_bytes_per_step"] if tot else None
+if summary["k_step_avg_ms"]:
+    summary["k_step_hbm_frac_algorithmic"] = summary["algorithmic_bytes_per_step"] / (summary["k_step_avg_ms"] * 1e-3) / 8e12
+json.dump(summary, open(os.path.join(dst, tag + "_summary.json"), "w"), indent=1)
+print(json.dumps(summary, indent=1))
