@@ -172,8 +172,9 @@ int pk_get_hand_ranks(pk_handle *h, uint8_t *rank, uint32_t *kick);
 
 /* pokerl.judger.eval_hand (pokerl/judger.py:7-99) on M hands.  cards[M][7] Card.value bytes (unused slots ignored),
  * ncards[M] in 0..7 (NULL = all 7).  rank[M], kick[M] (packed kickers, judger.py:101-109), nkick[M] (may be NULL).
- * Multiset semantics: duplicate cards are legal, as in the reference's own tests (those hands, and hands of fewer than three
- * cards, take the reference's sort-and-scan; 3..7 DISTINCT cards a bitmask evaluator that equals it on every subset of the deck). */
+ * Multiset semantics: duplicate cards are legal, as in the reference's own tests (those hands, hands of fewer than three cards and
+ * hands with a byte that is no card -- suit > 3 or rank nibble > 12 -- take the reference's sort-and-scan; 3..7 DISTINCT cards a
+ * table-driven evaluator that equals it on every subset of the deck: tools/host_sim `evalntab`, GPU digest fast = 4). */
 int pk_eval_hands(int device, const uint8_t *cards, const uint8_t *ncards, size_t m, uint8_t *rank, uint32_t *kick,
                   uint8_t *nkick);
 /* Same op on device-resident buffers, asynchronous on `stream` (a hipStream_t; NULL = the default stream): the
@@ -200,8 +201,9 @@ int pk_time_eval7_d(int device, const uint64_t *hands_d, size_t m, uint32_t *out
  * canonical deck indices (pokerl/cards.py:77 order) are (a, b), in lexicographic order; out holds C(51-b, 5) words.
  * fast == 1: the 7-distinct-card evaluator the showdown kernels use; fast == 0: the general one behind pk_eval_hands;
  * fast == 2: the table-driven 7-distinct-card evaluator of pk_eval7_d (cards of hand i rotated by i inside the packed word);
- * fast == 3: the evaluator pk_eval_hands(_d) applies (a bitmask fast path for 3..7 distinct cards, the reference's scan for hands
- * that repeat a card or hold fewer than three). */
+ * fast == 3: the register evaluator that backed pk_eval_hands(_d) up to ABI 4 and still does under PK_EVAL_HANDS_TAB=0 (a bitmask fast path
+ * for 3..7 distinct cards, the reference's scan for hands that repeat a card or hold fewer than three);
+ * fast == 4: the table path pk_eval_hands(_d) takes (eval_tab_n, cards rotated as for fast == 2). */
 int pk_eval7_prefix(int device, int a, int b, int fast, uint32_t *out, size_t *count_out);
 
 /* Actions the in-kernel agent `policy` would take now (one per table) -- lets a host loop reproduce rollouts. */

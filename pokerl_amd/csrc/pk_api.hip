@@ -1232,6 +1232,23 @@ static void *scratch(int device, size_t bytes) {  // caller holds g_scratch_mu a
     return s.p;
 }
 
+static const uint32_t *eval7_table(int device);
+// pk_eval_hands(_d)'s launch: the table path (k_eval_hands_tab); the register evaluator if the table could not be allocated or
+// env PK_EVAL_HANDS_TAB=0 (A/B knob).  tab: eval7_table(device), fetched by the caller BEFORE it takes g_scratch_mu.
+static void launch_eval_hands(const uint32_t *tab, const uint8_t *cards_d, const uint8_t *ncards_d, size_t m, uint8_t *rank_d, uint32_t *kick_d,
+                              uint8_t *nkick_d, hipStream_t stream) {
+    static const bool use_tab = !(getenv("PK_EVAL_HANDS_TAB") && atoi(getenv("PK_EVAL_HANDS_TAB")) == 0);
+    if (tab && use_tab) {
+        static const int grid_max = getenv("PK_EVAL_HANDS_GRID") ? atoi(getenv("PK_EVAL_HANDS_GRID")) : 256 * 8;
+        const size_t chunks = (m + EVAL_TAB_BLOCK - 1) / EVAL_TAB_BLOCK;      // every workgroup copies the 32 KB table: no more of them than have hands
+        const unsigned grid = (unsigned)(chunks < (size_t)grid_max ? chunks : (size_t)grid_max);   // four resident per CU (LDS), two rounds; grid-stride over the rest
+        if (ncards_d) hipLaunchKernelGGL(k_eval_hands_tab<true>, dim3(grid), dim3(EVAL_TAB_BLOCK), 0, stream, cards_d, ncards_d, m, rank_d, kick_d, nkick_d, tab);
+        else hipLaunchKernelGGL(k_eval_hands_tab<false>, dim3(grid), dim3(EVAL_TAB_BLOCK), 0, stream, cards_d, ncards_d, m, rank_d, kick_d, nkick_d, tab);
+    } else {
+        hipLaunchKernelGGL(k_eval_hands, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, stream, cards_d, ncards_d, m, rank_d, kick_d, nkick_d);
+    }
+}
+
 int pk_eval_hands_d(int device, const uint8_t *cards_d, const uint8_t *ncards_d, size_t m, uint8_t *rank_d, uint32_t *kick_d,
                     uint8_t *nkick_d, void *stream) {
     if (!cards_d || !rank_d || !kick_d) { g_err = "pk_eval_hands_d: NULL buffer"; return PK_E_INVALID_ARG; }
@@ -1240,7 +1257,7 @@ int pk_eval_hands_d(int device, const uint8_t *cards_d, const uint8_t *ncards_d,
     DeviceGuard guard(device);
     if (!guard.ok) { g_err = "hipSetDevice failed"; return PK_E_HIP; }
     if (m == 0) return PK_OK;
-    hipLaunchKernelGGL(k_eval_hands, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, (hipStream_t)stream, cards_d, ncards_d, m, rank_d, kick_d, nkick_d);
+    launch_eval_hands(eval7_table(device), cards_d, ncards_d, m, rank_d, kick_d, nkick_d, (hipStream_t)stream);
     if (hipGetLastError() != hipSuccess) { g_err = "pk_eval_hands_d: launch failed"; return PK_E_HIP; }
     return PK_OK;
 }
@@ -1255,6 +1272,7 @@ int pk_eval_hands(int device, const uint8_t *cards, const uint8_t *ncards, size_
     if (!guard.ok) { g_err = "hipSetDevice failed"; return PK_E_HIP; }
     if (m == 0) return PK_OK;
     tmp_handle th;
+    const uint32_t *tab = eval7_table(device);   // (takes g_scratch_mu itself)
     std::lock_guard<std::mutex> lock(g_scratch_mu);
     size_t off_n = m * 7, off_r = off_n + m, off_nk = off_r + m, off_k = (off_nk + m + 3) & ~(size_t)3, total = off_k + m * 4;
     uint8_t *d = (uint8_t *)scratch(device, total);
@@ -1262,8 +1280,7 @@ int pk_eval_hands(int device, const uint8_t *cards, const uint8_t *ncards, size_
     hipError_t e = hipMemcpyAsync(d, cards, m * 7, hipMemcpyHostToDevice, 0);
     if (e == hipSuccess && ncards) e = hipMemcpyAsync(d + off_n, ncards, m, hipMemcpyHostToDevice, 0);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_eval_hands, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, 0, d, ncards ? d + off_n : nullptr, m,
-                           d + off_r, (uint32_t *)(d + off_k), d + off_nk);
+        launch_eval_hands(tab, d, ncards ? d + off_n : nullptr, m, d + off_r, (uint32_t *)(d + off_k), d + off_nk, 0);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(rank, d + off_r, m, hipMemcpyDeviceToHost, 0);
@@ -1402,8 +1419,8 @@ int pk_eval7_prefix(int device, int a, int b, int fast, uint32_t *out, size_t *c
     if (count_out) *count_out = count;
     if (!count) return PK_OK;
     tmp_handle th;
-    const uint32_t *tab = fast == 2 ? eval7_table(device) : nullptr;   // (takes g_scratch_mu itself)
-    if (fast == 2 && !tab) { g_err = "pk_eval7_prefix: out of device memory"; return PK_E_OOM; }
+    const uint32_t *tab = (fast == 2 || fast == 4) ? eval7_table(device) : nullptr;   // (takes g_scratch_mu itself)
+    if ((fast == 2 || fast == 4) && !tab) { g_err = "pk_eval7_prefix: out of device memory"; return PK_E_OOM; }
     std::lock_guard<std::mutex> lock(g_scratch_mu);
     uint32_t *d = (uint32_t *)scratch(device, count * 4);
     if (!d) { g_err = "pk_eval7_prefix: out of device memory"; return PK_E_OOM; }

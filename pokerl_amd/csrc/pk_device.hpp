@@ -429,12 +429,10 @@ __device__ __forceinline__ uint32_t eval_distinct_n(const uint32_t (&c)[7], int 
     return (cat << 20) | kick;
 }
 // pk_eval_hands' evaluator: the fast path above for 3..7 distinct cards, the literal scan otherwise (0..2 cards: its first lines)
+__device__ __forceinline__ bool distinct_valid_cards(const uint32_t (&c)[7], int n);
 __device__ __forceinline__ uint32_t eval_hand_any(const uint32_t (&c)[7], int n, int &nk) {
-    uint64_t bits = 0;
-#pragma unroll
-    for (int i = 0; i < 7; ++i) bits |= (i < n) ? (1ull << (c[i] & 63)) : 0ull;
-    if (n >= 3 && __popcll(bits) == n) return eval_distinct_n(c, n, nk);
-    return eval_hand(c, n, nk);
+    if (distinct_valid_cards(c, n)) return eval_distinct_n(c, n, nk);   // (a byte that is no card -- suit > 3, rank nibble 13..15 -- would alias
+    return eval_hand(c, n, nk);                                          //  onto a real card in the bitmask: such hands take the scan)
 }
 
 // ---------------------------------------------------------------------------------------------- table-driven evaluator
@@ -535,6 +533,113 @@ __device__ __forceinline__ uint32_t eval7_tab_back(const Eval7Front &f, const ui
 __device__ __forceinline__ uint32_t eval7_tab(uint32_t lo, uint32_t hi, const uint32_t *T) {
     const Eval7Front f = eval7_tab_front(lo, hi, T);
     return eval7_tab_back(f, T);
+}
+
+// eval7_tab generalised to n = 3 .. 7 DISTINCT cards with len(kickers): the table path of pk_eval_hands(_d) (the partial-hand rank feature
+// of examples/q_learning.py:29-33).  What changes with fewer cards is what eval_distinct_n states: `islice(others, count)` yields what is there
+// (judger.py:91-99), so the tail takes min(nm, ranks left) nibbles and the whole kicker word moves down by the nibbles that are missing;
+// len(kickers) = the leading kickers of the category + that tail.  Equal to eval_hand on EVERY 3-, 4-, 5-, 6- and 7-card subset of the deck
+// (value and count: tools/host_sim `evalntab`).
+// Input: `bits` = OR of (4 << Card.value) over the hand's cards (four 16-bit suit lanes of rank masks shifted left by two, as in
+// eval7_tab_front).
+template <bool SEVEN = false>   // SEVEN: the caller knows the hand holds 7 cards -- every tail is complete (what eval7_tab assumes)
+__device__ __forceinline__ uint32_t eval_tab_bits(uint64_t bits, const uint32_t *T, int &nk) {
+    Eval7Front f;
+    {
+        const uint32_t w01 = (uint32_t)bits, w23 = (uint32_t)(bits >> 32);
+        const uint32_t sa = w01 & 0xffffu, sb = w01 >> 16, sc = w23 & 0xffffu, sd = w23 >> 16;
+        f.um = sa | sb | sc | sd;
+        const uint32_t s1 = sa ^ sb, c1 = sa & sb, s2 = sc ^ sd, c2 = sc & sd;
+        const uint32_t bit0 = s1 ^ s2, t = c1 ^ c2 ^ (s1 & s2);
+        f.quads = c1 & c2; f.pairs = t & ~bit0; f.trips = t & bit0;
+        const uint32_t ka = ((uint32_t)__popc(sa) << 15) | sa, kb = ((uint32_t)__popc(sb) << 15) | sb;
+        const uint32_t kc = ((uint32_t)__popc(sc) << 15) | sc, kd = ((uint32_t)__popc(sd) << 15) | sd;
+        const uint32_t gk = max(max(ka, kb), max(kc, kd));
+        f.has_flush = gk >= (5u << 15);
+        const uint32_t lp = sa ? sa : (sb ? sb : (sc ? sc : sd));
+        f.gm = f.has_flush ? (gk & 0x7fffu) : lp;
+        f.e_um = eval7_tab_at(T, f.um); f.e_gm = eval7_tab_at(T, f.gm); f.e_p = eval7_tab_at(T, f.pairs);
+        f.e_t = eval7_tab_at(T, f.trips); f.e_q = eval7_tab_at(T, f.quads);
+    }
+    const uint32_t p1 = (f.e_p >> 16) & 15u, p12 = (f.e_p >> 12) & 0xffu, p2 = p12 & 15u, p3 = (f.e_p >> 8) & 15u;
+    const uint32_t t1 = (f.e_t >> 16) & 15u, t2 = (f.e_t >> 12) & 15u, q1 = (f.e_q >> 16) & 15u;
+    const uint32_t st = (f.e_um >> 20) & 15u;
+    uint32_t W = 1u << 24;                                                                     // (the candidates of eval7_tab_back)
+    const uint32_t w_p = p2 ? ((3u << 24) | (4u << 20) | (p12 << 4)) : ((2u << 24) | (2u << 20) | (p1 << 12));
+    W = max(W, p1 ? w_p : 0u);
+    const uint32_t x2 = t2 ? t2 : p1;
+    const uint32_t w_t = (x2 ? ((7u << 24) | (5u << 20) | x2) : ((4u << 24) | (3u << 20))) | (t1 << (x2 ? 4u : 8u));
+    W = max(W, t1 ? w_t : 0u);
+    W = max(W, st ? ((5u << 24) | (5u << 20) | st) : 0u);
+    W = max(W, f.has_flush ? ((6u << 24) | (5u << 20) | (f.e_gm & 0xfffffu)) : 0u);
+    W = max(W, q1 ? ((8u << 24) | (4u << 20) | (q1 << 4)) : 0u);
+    W = max(W, ((f.e_gm >> 24) & 15u) >= 5u ? ((9u << 24) | (5u << 20) | ((f.e_gm >> 28) + 1u)) : 0u);
+    const uint32_t taken2 = f.pairs & ~((4u << p3) & ~4u);
+    const uint32_t taken = q1 ? f.quads : (t1 ? f.trips : taken2);
+    const uint32_t rest = f.um & ~taken;
+    const uint32_t shift = (W >> 20) & 7u, cat = W >> 24;
+    const uint32_t nm0 = 5u - shift, left = SEVEN ? 5u : (uint32_t)__popc(rest);
+    const uint32_t nm = SEVEN ? nm0 : min(nm0, left);                                          // islice yields what is there
+    const uint32_t tail = (eval7_tab_at(T, rest) & 0xfffffu) >> (shift << 2);
+    const uint32_t kick = ((W & 0xfffffu) | tail) >> ((nm0 - nm) << 2);
+    // len(kickers): the leading kickers per category (HIGH 0, PAIR 1, TWO_PAIR 2, TRIS 1, STRAIGHT 1, FLUSH 5, FULL 2, POKER 1, SF 1) + the tail
+    nk = (int)(((0x1125112100ull >> (cat << 2)) & 15u) + nm);
+    uint32_t v = ((10u - cat) << 20) | kick;
+    const bool low4 = (f.e_gm >> 24) == 0x34u;                                                 // judger.py:83-88, if / elif
+    const bool wheel_sf = low4 && (f.gm & 4u);
+    const bool wheel_st = !low4 && st == 0 && (f.e_um >> 24) == 0x34u && (f.um & 4u);
+    v = wheel_st ? (((uint32_t)HR_STRAIGHT << 20) | 4u) : v;
+    v = wheel_sf ? (((uint32_t)HR_SF << 20) | 4u) : v;
+    nk = (wheel_st || wheel_sf) ? 1 : nk;
+    return v;
+}
+// Front end on the PACKED hand (card i = byte i of w, n = 3 .. 7 cards; bytes from n on are ignored): the suit-lane bit set of
+// eval_tab_bits and, with it, whether the hand may take the table at all -- every used byte a real card (suit < 4: byte < 0x40; rank0 < 13)
+// and no card twice.  Unused bytes are replaced by a copy of card 0, which sets no new bit.  A rank nibble of 13 lands on bit 15 of its suit
+// lane, 14 / 15 on bits 0 / 1 of the next lane (masks are shifted by two, so those bits are otherwise never set) or beyond bit 63, where it
+// is lost and the popcount test fails.
+template <bool SEVEN = false>
+__device__ __forceinline__ bool tab_bits_of(uint64_t w, int n, uint64_t &bits) {
+    uint32_t lo = (uint32_t)w, hi = (uint32_t)(w >> 32) & 0x00ffffffu;
+    if (!SEVEN) {   // bytes n .. 6 := card 0 (a bit-field select per half: mask = the used bytes)
+        const uint32_t r4 = rep4(lo), ulo = n >= 4 ? 0xffffffffu : ((1u << ((8 * n) & 31)) - 1u);
+        const uint32_t uhi = n <= 4 ? 0u : ((1u << ((8 * (n - 4)) & 31)) - 1u);
+        lo = (lo & ulo) | (r4 & ~ulo); hi = ((hi & uhi) | (r4 & ~uhi)) & 0x00ffffffu;
+    }
+    bits = (4ull << (lo & 63)) | (4ull << ((lo >> 8) & 63)) | (4ull << ((lo >> 16) & 63)) | (4ull << ((lo >> 24) & 63)) |
+           (4ull << (hi & 63)) | (4ull << ((hi >> 8) & 63)) | (4ull << ((hi >> 16) & 63));
+    const bool cards_ok = ((lo & 0xc0c0c0c0u) | (hi & 0x00c0c0c0u)) == 0 && (((uint32_t)bits | (uint32_t)(bits >> 32)) & 0x80038003u) == 0;
+    return (SEVEN || n >= 3) && cards_ok && __popcll(bits) == (SEVEN ? 7 : n);
+}
+// judger.eval_hand's first lines for hands of 0, 1, 2 cards (judger.py:30-35), on the packed hand: what the scan returns for them
+__device__ __forceinline__ uint32_t eval_small(uint64_t w, int n, int &nk) {
+    uint32_t r0 = (uint32_t)w & 0xf, r1 = (uint32_t)(w >> 8) & 0xf;
+    r0 = r0 ? r0 : 13u; r1 = r1 ? r1 : 13u;                                       // cards.py:14
+    const uint32_t hi = r0 > r1 ? r0 : r1, lo = r0 > r1 ? r1 : r0;
+    const bool pair = n == 2 && r0 == r1;
+    nk = n == 0 ? 0 : ((n == 1 || pair) ? 1 : 2);
+    const uint32_t v2 = pair ? (((uint32_t)HR_PAIR << 20) | r0) : (((uint32_t)HR_HIGH << 20) | (hi << 4) | lo);
+    return n == 0 ? NONE_V : (n == 1 ? (((uint32_t)HR_HIGH << 20) | r0) : v2);
+}
+__device__ __forceinline__ uint32_t eval_tab_n(const uint32_t (&c)[7], int n, const uint32_t *T, int &nk) {   // (array form: tests, k_eval7_prefix)
+    uint64_t bits = 0;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) bits |= (i < n) ? (4ull << (c[i] & 63)) : 0ull;
+    return eval_tab_bits(bits, T, nk);
+}
+// Which hands may take a bitmask / table evaluator: 3..7 cards, every used byte a real card (suit < 4: byte < 0x40; rank0 < 13), no card
+// twice.  Anything else -- the reference's own tests feed eval_hand repeated cards -- takes the literal scan (its reading of a byte that is
+// no card: suit = bits 4..5, rank nibble as it is -- what pk_eval_hands returned for such bytes before the bitmask paths existed).
+__device__ __forceinline__ bool distinct_valid_cards(const uint32_t (&c)[7], int n) {
+    uint64_t bits = 0;
+    bool ok = n >= 3;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        const bool used = i < n;
+        ok = ok && (!used || (c[i] < 0x40u && (c[i] & 15u) < 13u));
+        bits |= used ? (1ull << (c[i] & 63)) : 0ull;
+    }
+    return ok && __popcll(bits) == n;
 }
 
 // ---------------------------------------------------------------------------------------------- the table

@@ -842,6 +842,54 @@ __global__ void k_eval_hands(const uint8_t *cards, const uint8_t *ncards, size_t
     kick[i] = v & 0xFFFFF;
     if (nkick) nkick[i] = (uint8_t)nk;
 }
+// The same op on the TABLE path (eval_tab_bits: ~two thirds of the instructions of the register evaluator, checks included):
+// EVAL_TAB_BLOCK-thread workgroups with the 32 KB rank-mask table of the streaming evaluator in LDS, grid-stride, one hand per lane per
+// iteration, nothing shared between lanes after the table copy (no barrier in the loop; eight waves per SIMD hide the lookups).  A hand's
+// seven card bytes start at ANY byte offset: ONE unaligned 8-byte load per hand (gfx950 runs in unaligned-access mode; the eighth byte
+// belongs to the next hand and is ignored -- the LAST hand of the buffer is read byte by byte instead, so nothing past cards[7m) is
+// touched), the next iteration's load in flight while this one is evaluated.  3..7 distinct real cards: the table; 0..2 cards: the
+// reference's first lines as selects (eval_small); a repeated card or a byte that is no card: the literal scan, executed by a wave only if
+// one of its lanes needs it.  HAS_N == false: ncards == NULL, every hand holds seven cards.
+// (Tried: two hands per lane per iteration as in the streaming kernel, 16-byte loads and paired stores -- no faster on seven-card hands,
+// the kernel is bound by VALU issue, not by latency or memory instructions, and slower on mixed batches, where one short hand sends its
+// partner down the slow branch too: profiles/r05_eval_hands_bench.txt.)
+#define EVAL_TAB_BLOCK 512
+template <bool HAS_N>
+__global__ void __launch_bounds__(EVAL_TAB_BLOCK, 8) k_eval_hands_tab(const uint8_t *__restrict__ cards, const uint8_t *__restrict__ ncards, size_t m,
+                                                                      uint8_t *__restrict__ rank, uint32_t *__restrict__ kick, uint8_t *__restrict__ nkick,
+                                                                      const uint32_t *__restrict__ tab) {
+    __shared__ uint32_t T[EVAL7_TAB_WORDS];
+    for (int i = threadIdx.x; i < EVAL7_TAB_WORDS / 4; i += EVAL_TAB_BLOCK) reinterpret_cast<uint4 *>(T)[i] = reinterpret_cast<const uint4 *>(tab)[i];
+    __syncthreads();
+    const size_t stride = (size_t)gridDim.x * EVAL_TAB_BLOCK;
+    auto fetch = [&](size_t i, uint64_t &w, int &n) {
+        if (i + 1 < m) __builtin_memcpy(&w, cards + 7 * i, 8);            // global_load_dwordx2 at a byte address
+        else { w = 0; for (int j = 0; j < 7; ++j) w |= (uint64_t)cards[7 * i + j] << (8 * j); }
+        n = HAS_N ? ncards[i] : 7;
+    };
+    size_t i = (size_t)blockIdx.x * EVAL_TAB_BLOCK + threadIdx.x;
+    uint64_t w = 0; int n = 0;
+    if (i < m) fetch(i, w, n);
+    for (; i < m; i += stride) {
+        uint64_t wn = 0; int nn = 0;
+        if (i + stride < m) fetch(i + stride, wn, nn);
+        n = n > 7 ? 7 : n;                                                  // (u8: never negative)
+        int nk = 0;
+        uint32_t v;
+        uint64_t bits;
+        if (tab_bits_of<!HAS_N>(w, n, bits)) v = eval_tab_bits<!HAS_N>(bits, T, nk);
+        else if (HAS_N && n < 3) v = eval_small(w, n, nk);
+        else {
+            const uint32_t lo = (uint32_t)w, hi = (uint32_t)(w >> 32);
+            const uint32_t c[7] = {lo & 0xff, (lo >> 8) & 0xff, (lo >> 16) & 0xff, lo >> 24, hi & 0xff, (hi >> 8) & 0xff, (hi >> 16) & 0xff};
+            v = eval_hand(c, n, nk);
+        }
+        rank[i] = (uint8_t)(v >> 20);
+        kick[i] = v & 0xFFFFF;
+        if (nkick) nkick[i] = (uint8_t)nk;
+        w = wn; n = nn;
+    }
+}
 // pokerl.judger.compare_rankings batched: one list of n rankings per lane (judger.py:111-158)
 __global__ void k_compare(const uint8_t *rank, const uint32_t *kick, int n, size_t m, uint8_t *onehot) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -958,7 +1006,11 @@ __global__ void k_eval7_prefix(int a, int b, int fast, uint32_t count, uint32_t 
         uint32_t r[7];
         for (int j = 0; j < 7; ++j) r[j] = h[(j + i) % 7];
         out[i] = eval7_tab(r[0] | (r[1] << 8) | (r[2] << 16) | (r[3] << 24), r[4] | (r[5] << 8) | (r[6] << 16) | 0xAB000000u, tab);
-    } else if (fast == 3) out[i] = eval_hand_any(h, 7, nk);   // pk_eval_hands' dispatch (its fast path: eval_distinct_n)
+    } else if (fast == 4) {                                  // the table path of pk_eval_hands(_d), cards rotated likewise
+        uint32_t r[7];
+        for (int j = 0; j < 7; ++j) r[j] = h[(j + i) % 7];
+        out[i] = eval_tab_n(r, 7, tab, nk);
+    } else if (fast == 3) out[i] = eval_hand_any(h, 7, nk);   // pk_eval_hands' register dispatch (its fast path: eval_distinct_n)
     else out[i] = fast ? eval7_distinct(h) : eval_hand(h, 7, nk);
 }
 

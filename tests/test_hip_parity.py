@@ -75,8 +75,8 @@ def test_golden_judger_vectors(HB):
         assert [[r, k] for r, k in out[2]] == case["rankings"]
 
 
-@pytest.mark.parametrize("fast", [1, 0, 2, 3], ids=["showdown_evaluator", "general_evaluator", "table_evaluator_of_the_streaming_kernel",
-                                                   "eval_hands_dispatch_fast_path"])
+@pytest.mark.parametrize("fast", [1, 0, 2, 3, 4], ids=["showdown_evaluator", "general_evaluator", "table_evaluator_of_the_streaming_kernel",
+                                                      "eval_hands_dispatch_fast_path", "eval_hands_table_path"])
 def test_eval7_exhaustive_digest(HB, fast):
     """All C(52,7) = 133 784 560 hands on the GPU against the digest computed from the imported reference, for both
     device evaluators (the bitmask one the showdown kernels use, the general multiset one of pk_eval_hands, and the
@@ -729,6 +729,32 @@ def test_streaming_evaluator(HB, O):
     ro, ko, no = O.eval_hands(np.ascontiguousarray(part), nc)
     rg, kg, ng = judger.eval_hands(part, nc)
     assert np.array_equal(ro, rg) and np.array_equal(ko, kg) and np.array_equal(no, ng)
+    # the TABLE path (k_eval_hands_tab: one unaligned 8-byte load per hand, the buffer's last hand byte by byte) at odd sizes, with the
+    # card bytes starting at byte offset 0 and 1 of the allocation (canary bytes around them)
+    import ctypes as C
+    for m2 in (1, 2, 511, 512, 513, 1023, 4097, 300000 - 1):
+        d_c, d_n, d_r, d_k, d_nk = DeviceBuffer(m2 * 7 + 8), DeviceBuffer(m2), DeviceBuffer(m2), DeviceBuffer(m2 * 4), DeviceBuffer(m2)
+        for off in (0, 1):
+            d_c.upload(np.concatenate([np.full(off, 0xEE, np.uint8), part[:m2].reshape(-1), np.full(8 - off, 0xEE, np.uint8)]))
+            d_n.upload(nc[:m2])
+            judger.eval_hands_d(C.c_void_p(d_c.ptr.value + off), d_n.ptr, m2, d_r.ptr, d_k.ptr, d_nk.ptr)
+            C.CDLL("libamdhip64.so").hipDeviceSynchronize()
+            assert np.array_equal(d_r.download(np.uint8, m2), ro[:m2]) and np.array_equal(d_k.download(np.uint32, m2), ko[:m2]), (m2, off)
+            assert np.array_equal(d_nk.download(np.uint8, m2), no[:m2]), (m2, off)
+        for b in (d_c, d_n, d_r, d_k, d_nk):
+            b.free()
+    # bytes that are no card (suit > 3, rank nibble 13..15) must not reach a bitmask / table evaluator, where they would alias onto real
+    # cards: such hands go to the scan wherever the bytes start
+    odd = cards[:2048].copy()
+    odd[::3, 2] |= 0x40; odd[1::3, 4] = (odd[1::3, 4] & 0xf0) | 0x0d; odd[2::3, 0] = 0xff
+    d_c, d_r, d_k, d_nk = DeviceBuffer(2048 * 7 + 8), DeviceBuffer(2048), DeviceBuffer(2048 * 4), DeviceBuffer(2048)
+    got = []
+    for off in (0, 1):
+        d_c.upload(np.concatenate([np.zeros(off, np.uint8), odd.reshape(-1), np.zeros(8 - off, np.uint8)]))
+        judger.eval_hands_d(C.c_void_p(d_c.ptr.value + off), None, 2048, d_r.ptr, d_k.ptr, d_nk.ptr)
+        C.CDLL("libamdhip64.so").hipDeviceSynchronize()
+        got.append((d_r.download(np.uint8, 2048), d_k.download(np.uint32, 2048), d_nk.download(np.uint8, 2048)))
+    assert all(np.array_equal(a, b) for a, b in zip(*got))
 
 
 def test_empty_and_minimal_inputs(HB, O):

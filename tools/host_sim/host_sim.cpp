@@ -161,7 +161,7 @@ static int fuzz(int rounds, int T, int K) {
 
 // eval_distinct_n (the fast path of pk_eval_hands) against eval_hand (the literal scan) on EVERY n-card subset of the deck,
 // n = 3 .. 7 (7: 133 784 560 hands; pass a smaller max n for a quick run), cards in a rotated order so that positions vary
-static int check_evaln(int nmax) {
+static int check_evaln(int nmax, const uint32_t *tab = nullptr) {   // tab: check eval_tab_n (the table path of pk_eval_hands) instead
     auto canon = [](int k) { return (uint32_t)(((k % 4) << 4) | (k / 4)); };
     long long bad = 0, total = 0;
     for (int n = 3; n <= nmax; ++n) {
@@ -172,7 +172,19 @@ static int check_evaln(int nmax) {
             uint32_t c[7] = {0, 0, 0, 0, 0, 0, 0};
             for (int i = 0; i < n; ++i) c[(i + (int)(cnt % 7)) % n] = canon(idx[i]);
             int nk0 = -1, nk1 = -1;
-            const uint32_t v0 = eval_hand(c, n, nk0), v1 = eval_hand_any(c, n, nk1);
+            uint32_t v1;
+            const uint32_t v0 = eval_hand(c, n, nk0);
+            if (tab) {                                          // the packed front end of k_eval_hands_tab (garbage in the unused bytes)
+                uint64_t w = 0xABull << 56, bits = 0;
+                for (int i = 0; i < 7; ++i) w |= (uint64_t)(i < n ? c[i] : (uint32_t)(0x5Au + 37u * (uint32_t)cnt + (uint32_t)i) & 0xffu) << (8 * i);
+                if (!tab_bits_of(w, n, bits)) { printf("tab_bits_of refuses a valid hand\n"); ++bad; }
+                v1 = eval_tab_bits(bits, tab, nk1);
+                if (n == 7) {                                   // the ncards == NULL instantiation of the kernel
+                    uint64_t b7; int nk7 = -1;
+                    if (!tab_bits_of<true>(w, 7, b7) || eval_tab_bits<true>(b7, tab, nk7) != v1 || nk7 != nk1) { printf("SEVEN variant differs\n"); ++bad; }
+                }
+                if (!distinct_valid_cards(c, n)) { printf("distinct_valid_cards refuses a valid hand\n"); ++bad; }
+            } else v1 = eval_hand_any(c, n, nk1);
             if (v0 != v1 || nk0 != nk1) {
                 if (bad < 5) printf("MISMATCH n=%d hand %lld: scan %08x nk %d, fast %08x nk %d\n", n, cnt, v0, nk0, v1, nk1);
                 ++bad;
@@ -192,12 +204,62 @@ static int check_evaln(int nmax) {
     int a, b;
     if (eval_hand(d, 7, a) != eval_hand_any(d, 7, b) || a != b) { printf("MISMATCH on a hand with a repeated card\n"); ++bad; }
     for (int n = 0; n <= 2; ++n) if (eval_hand(d, n, a) != eval_hand_any(d, n, b) || a != b) { printf("MISMATCH n=%d\n", n); ++bad; }
+    // ... and so must a byte that is no card (suit > 3 or rank nibble 13..15: it would alias onto a real card in the bitmask)
+    const uint32_t odd[4][7] = {{0x4c, 0x0c, 0x1c, 0x2c, 0x3c, 0x01, 0x02}, {0x0d, 0x00, 0x1c, 0x2c, 0x3c, 0x01, 0x02},
+                                {0x0f, 0x1f, 0x2f, 0x3f, 0x01, 0x02, 0x03}, {0x80, 0x00, 0x10, 0x20, 0x30, 0x05, 0x06}};
+    for (int k = 0; k < 4; ++k)
+        for (int n = 3; n <= 7; ++n) {
+            if (distinct_valid_cards(odd[k], n)) { printf("distinct_valid_cards accepts a malformed byte (case %d, n %d)\n", k, n); ++bad; }
+            uint64_t w = 0, bits;
+            for (int i = 0; i < 7; ++i) w |= (uint64_t)odd[k][i] << (8 * i);
+            if (tab_bits_of(w, n, bits)) { printf("tab_bits_of accepts a malformed byte (case %d, n %d)\n", k, n); ++bad; }
+            if (eval_hand(odd[k], n, a) != eval_hand_any(odd[k], n, b) || a != b) { printf("MISMATCH on a malformed byte (case %d, n %d)\n", k, n); ++bad; }
+        }
+    // eval_small = the scan on every 0-, 1-, 2-card hand over all byte values
+    for (int n = 0; n <= 2; ++n)
+        for (uint32_t x = 0; x < 256; ++x)
+            for (uint32_t y = 0; y < 256; ++y) {
+                const uint32_t c2[7] = {x, y, 0x77, 0, 0, 0, 0};
+                int ka = -1, kb = -1;
+                if (eval_hand(c2, n, ka) != eval_small((uint64_t)x | ((uint64_t)y << 8) | 0x770000ull, n, kb) || ka != kb) {
+                    if (bad < 5) printf("eval_small differs: n %d bytes %02x %02x\n", n, x, y);
+                    ++bad;
+                }
+            }
+    // tab_bits_of: EVERY byte value in EVERY position of a few valid hands, n = 3..7: accepted iff it is a real card no other used position holds
+    {
+        const uint32_t base[3][7] = {{0x00, 0x11, 0x22, 0x33, 0x04, 0x15, 0x26}, {0x3c, 0x2c, 0x1c, 0x0c, 0x0b, 0x1b, 0x2b}, {0x30, 0x31, 0x32, 0x33, 0x34, 0x35, 0x3c}};
+        for (int k = 0; k < 3; ++k)
+            for (int n = 3; n <= 7; ++n)
+                for (int pos = 0; pos < 7; ++pos)
+                    for (uint32_t byte = 0; byte < 256; ++byte) {
+                        uint32_t c[7];
+                        for (int i = 0; i < 7; ++i) c[i] = base[k][i];
+                        c[pos] = byte;
+                        uint64_t w = 0, bits;
+                        for (int i = 0; i < 7; ++i) w |= (uint64_t)c[i] << (8 * i);
+                        bool want = true;                       // (a byte outside the hand does not matter)
+                        for (int i = 0; i < n; ++i) {
+                            want = want && c[i] < 0x40 && (c[i] & 15) < 13;
+                            for (int j = 0; j < i; ++j) want = want && c[i] != c[j];
+                        }
+                        if (tab_bits_of(w, n, bits) != want || distinct_valid_cards(c, n) != want || (n == 7 && tab_bits_of<true>(w, 7, bits) != want)) {
+                            if (bad < 5) printf("tab_bits_of / distinct_valid_cards wrong: hand %d n %d pos %d byte %02x\n", k, n, pos, byte);
+                            ++bad;
+                        }
+                    }
+    }
     printf("evaln: %lld hands, %lld mismatching\n", total, bad);
     return bad != 0;
 }
 
 int main(int argc, char **argv) {
     if (argc > 1 && !strcmp(argv[1], "evaln")) return check_evaln(argc > 2 ? atoi(argv[2]) : 7);
+    if (argc > 1 && !strcmp(argv[1], "evalntab")) {
+        std::vector<uint32_t> tab(EVAL7_TAB_WORDS);
+        for (int m = 0; m < EVAL7_TAB_WORDS; ++m) tab[m] = eval7_tab_entry((uint32_t)m);
+        return check_evaln(argc > 2 ? atoi(argv[2]) : 7, tab.data());
+    }
     if (argc > 1 && !strcmp(argv[1], "eval7")) return check_eval7();
     if (argc > 1 && !strcmp(argv[1], "eval7tab")) {
         std::vector<uint32_t> tab(EVAL7_TAB_WORDS);
