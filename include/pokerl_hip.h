@@ -298,6 +298,9 @@ int pk_env_step_fused_d(pk_handle *h, const int32_t *actions_d, int seat0_policy
 /* The compact row (PK_OBS_PACKED_BYTES) from the PokerGameEnv kernels: once a device buffer is set here, every
  * pk_env_step_fused_d / _async_d / _multi_d call writes the packed row of each table it delivers into it (beside the f64 row
  * if obs_d is given too), from registers.  NULL switches it off.  8-byte aligned, [T][PK_OBS_PACKED_BYTES(N)]. */
+/* Exactly those three write it (pk_env_step_d, pk_env_step / _begin and pk_env_reset_d do not: after a reset the rows are those of the last
+ * step -- refresh them with pk_get_obs_packed_d).  The handle keeps the RAW pointer: call pk_set_env_obs_packed(h, NULL) before freeing the
+ * buffer.  PK_E_BUSY while env steps are in flight. */
 int pk_set_env_obs_packed(pk_handle *h, uint8_t *obs_packed_d);
 int pk_get_obs_packed_d(pk_handle *h, int player, uint8_t *out_d);
 
@@ -307,8 +310,11 @@ int pk_get_obs_packed_d(pk_handle *h, int player, uint8_t *out_d);
  * f64 observation rows (obs) and / or the packed ones (obs_packed); pk_env_step_end waits for them.  With buffers from
  * pk_host_alloc nothing in `begin` blocks and the copies run at PCIe line rate, so the caller's own work -- or the step of
  * ANOTHER handle -- overlaps with them.  Per-table errors are in terr[] after `end` (which does not scan them).  The handle
- * must not be used between the two calls, and EVERY buffer -- actions[] included, which a pinned upload reads when the copy
- * engine gets to it, not when `begin` returns -- must stay valid and untouched until `end` has returned. */
+ * must not be used between the two calls -- every entry point that reads or changes tables, a second pk_env_step_begin included, returns
+ * PK_E_BUSY until pk_env_step_end (pk_sync only waits); pk_env_step_end without a begin is PK_E_INVALID_ARG -- and EVERY buffer --
+ * actions[] included, which a pinned upload reads when the copy engine gets to it, not when `begin` returns -- must stay valid and
+ * untouched until `end` has returned.  Invalid actions are NOT an error of either call: such a table is left untouched and terr[t] says
+ * PK_TERR_INVALID_ACTION -- read terr[] after `end`. */
 int pk_env_step_begin(pk_handle *h, const int32_t *actions, int opp_policy, int auto_reset, double *reward, uint8_t *done,
                       uint8_t *hand, uint8_t *terr, double *obs, uint8_t *obs_packed);
 int pk_env_step_end(pk_handle *h);
@@ -402,6 +408,12 @@ int pk_wait_event(pk_handle *h, void *event);
 int pk_record_event(pk_handle *h, void *event);
 /* Completes deferred rollout steps and waits until everything requested so far has finished. */
 int pk_sync(pk_handle *h);
+/* Streams are recycled through a per-device pool when handles are destroyed (a process that opens and closes handles keeps its hardware
+ * queues); the sub-batch streams of pk_set_env_batches are created at the HIGHEST stream priority (env PK_ENV_STREAM_PRIO=0: normal), so a
+ * learner's normal-priority kernels on the same GPU yield to the env ranges while those run.  pk_stream_pool_drain destroys the pooled (idle)
+ * streams of `device` (-1: all devices) and returns how many -- call it before hipDeviceReset, which would leave stale handles in the pool
+ * (pk_create drops a pool whose streams no longer work and retries), or to give the queues back. */
+int pk_stream_pool_drain(int device);
 /* Runs `reps` back-to-back fused rollouts of k_steps each (never coalesced) plus the flush of what they deferred and
  * returns the device time of all of it divided by `reps`, in milliseconds (events on the handle's stream): the time one
  * launch's k_steps of work take, the flush shared among the launches.  Diagnostic (tools/); bench.py's roofline leg

@@ -62,6 +62,7 @@ struct pk_handle {
     // PokerGameEnv.steps left in flight by pk_env_step_async_d (State::env_ctx): every other entry point that touches
     // table state refuses to run until a draining call (max_passes <= 0) has completed them.
     bool env_pending = false;
+    bool host_step = false;   // between pk_env_step_begin and pk_env_step_end: the caller's host buffers are the targets of queued copies
     hipStream_t stream = nullptr, own_stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     State S{};
@@ -230,7 +231,10 @@ static int launch_coalesced(pk_handle *h, int policy, int auto_reset) {
     h->ev_idx ^= 1;
     return PK_OK;
 }
+static inline bool in_flight(const pk_handle *h) { return h->env_pending || h->host_step; }
 static int flush(pk_handle *h) {
+    if (h->host_step)
+        return h->fail(PK_E_BUSY, "a pk_env_step_begin is waiting for its pk_env_step_end: the copies into the caller's buffers are still queued");
     if (h->env_pending)
         return h->fail(PK_E_BUSY, "PokerGameEnv steps are in flight (pk_env_step_async_d / pk_env_step_multi_d): drain them with max_passes = 0 "
                                   "(pk_env_end_multi_d where seats are played by the caller) first");
@@ -290,6 +294,25 @@ static void stream_release(int device, hipStream_t s, bool sub_batch = false) { 
     } else (void)hipStreamDestroy(s);
 }
 
+// Destroys the pooled (idle) streams of a device; -1: of every device.  For a host application that resets the device (hipDeviceReset
+// invalidates every stream, pooled ones included) or wants its hardware queues back.  Streams of live handles are not in the pool.
+static int drain_stream_pool(int device) {
+    std::lock_guard<std::mutex> lock(g_stream_mu);
+    int n = 0;
+    for (int d = 0; d < PK_MAX_DEVICES; ++d) {
+        if (device >= 0 && d != device) continue;
+        for (int cls = 0; cls < 2; ++cls) {
+            auto &pool = g_stream_pool[d][cls];
+            if (pool.empty()) continue;
+            DeviceGuard guard(d);
+            for (hipStream_t s : pool) { if (guard.ok) (void)hipStreamDestroy(s); ++n; }
+            (void)hipGetLastError();      // (a stream the application's device reset already killed: nothing left to destroy)
+            pool.clear();
+        }
+    }
+    return n;
+}
+
 static int check_device_any() {
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -304,10 +327,13 @@ static EnvKernArgs env_args(const pk_handle *h, const int32_t *actions_d, int se
     ka.Sp = (const State *)h->d_S; ka.H = h->hot_env;
     ka.A.actions = actions_d; ka.A.seat0_policy = seat0_policy; ka.A.seatpol = seatpol; ka.A.auto_reset = auto_reset;
     ka.A.reward = reward_d; ka.A.done = done_d; ka.A.hand = hand_d; ka.A.terr = terr_d; ka.A.obs = obs_d;
-    ka.A.obs_packed = h->env_obs_packed;   // pk_set_env_obs_packed: the compact row beside (or instead of) the f64 one
+    ka.A.obs_packed = nullptr;             // (pk_set_env_obs_packed's buffer: set by the three entry points the header names, see with_packed)
     ka.A.park = env_park(h); ka.A.t0 = 0; ka.A.tend = h->T;
     return ka;
 }
+
+// pk_set_env_obs_packed: pk_env_step_fused_d / _async_d / _multi_d write the compact row of every table they deliver
+static inline EnvKernArgs with_packed(const pk_handle *h, EnvKernArgs ka) { ka.A.obs_packed = h->env_obs_packed; return ka; }
 
 extern "C" {
 
@@ -378,7 +404,10 @@ int pk_create(pk_handle **out, int device, int num_tables, int num_players, cons
     auto bail = [&](int code) { g_err = h->err; pk_destroy(h); return code; };
     DeviceGuard guard(device);
     if (!guard.ok) return bail(h->fail(PK_E_HIP, "hipSetDevice"));
-    if (stream_acquire(device, &h->own_stream) != hipSuccess) return bail(h->fail(PK_E_HIP, "hipStreamCreate"));
+    if (stream_acquire(device, &h->own_stream) != hipSuccess) {
+        (void)hipGetLastError(); drain_stream_pool(device);      // e.g. after the application reset the device: pooled handles are stale
+        if (stream_acquire(device, &h->own_stream) != hipSuccess) return bail(h->fail(PK_E_HIP, "hipStreamCreate"));
+    }
     h->stream = h->own_stream;
     if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_ring[0], hipEventDisableTiming) != hipSuccess ||
@@ -485,6 +514,11 @@ int pk_destroy(pk_handle *h) {
     return PK_OK;
 }
 
+int pk_stream_pool_drain(int device) {
+    if (device < -1 || device >= PK_MAX_DEVICES) { g_err = "pk_stream_pool_drain: device index out of range (-1 = every device)"; return PK_E_INVALID_ARG; }
+    return drain_stream_pool(device);
+}
+
 int pk_num_tables(const pk_handle *h) { return h ? h->T : PK_E_INVALID_ARG; }
 int pk_num_players(const pk_handle *h) { return h ? h->N : PK_E_INVALID_ARG; }
 
@@ -495,7 +529,7 @@ int pk_get_stream(pk_handle *h, void **stream_out) {
     return PK_OK;
 }
 static int switch_stream(pk_handle *h, hipStream_t to) {
-    if (!h->env_pending) FLUSH(h);               // host-side accumulated / deferred rollout steps belong to the old stream
+    if (!in_flight(h)) FLUSH(h);                 // host-side accumulated / deferred rollout steps belong to the old stream
     HIPCHK(h, hipStreamSynchronize(h->stream));  // nothing of ours may still be running on the stream we leave
     h->stream = to;
     h->ev_used[0] = h->ev_used[1] = false;
@@ -521,14 +555,14 @@ int pk_wait_event(pk_handle *h, void *event) {
     ON_DEVICE(h);
     // rollout steps the host still holds back (coalescing) were requested BEFORE this wait: launch them now, so that they do not
     // queue up behind the caller's event (and overlap with whatever the caller does until it records it)
-    if (!h->env_pending && h->acc > 0) { int rc = launch_coalesced(h, h->pend_policy, h->pend_auto); if (rc) return rc; }
+    if (!in_flight(h) && h->acc > 0) { int rc = launch_coalesced(h, h->pend_policy, h->pend_auto); if (rc) return rc; }
     HIPCHK(h, hipStreamWaitEvent(h->stream, (hipEvent_t)event, 0));
     return PK_OK;
 }
 int pk_record_event(pk_handle *h, void *event) {
     if (!h || !event) return PK_E_INVALID_ARG;
     ON_DEVICE(h);
-    if (!h->env_pending) FLUSH(h);  // "everything requested so far" includes deferred rollout steps (env steps in flight stay so)
+    if (!in_flight(h)) FLUSH(h);    // "everything requested so far" includes deferred rollout steps (env steps in flight stay so)
     // ... and the launches of pk_env_step_async_d's sub-batches on the handle's internal streams (pk_set_env_batches)
     for (int b = 0; b < h->env_batches && h->env_batches > 1; ++b)
         if (h->env_launched[b]) HIPCHK(h, hipStreamWaitEvent(h->stream, h->env_done[b], 0));
@@ -756,7 +790,7 @@ int pk_get_obs_packed_d(pk_handle *h, int player, uint8_t *out_d) {
 
 int pk_set_env_obs_packed(pk_handle *h, uint8_t *obs_packed_d) {
     if (!h || ((uintptr_t)obs_packed_d & 7)) return h ? h->fail(PK_E_INVALID_ARG, "pk_set_env_obs_packed: the buffer must be 8-byte aligned") : PK_E_INVALID_ARG;
-    if (h->env_pending) return h->fail(PK_E_BUSY, "pk_set_env_obs_packed: PokerGameEnv steps are in flight");
+    if (in_flight(h)) return h->fail(PK_E_BUSY, "pk_set_env_obs_packed: PokerGameEnv steps are in flight");
     h->env_obs_packed = obs_packed_d;
     return PK_OK;
 }
@@ -835,7 +869,7 @@ int pk_env_step_fused_d(pk_handle *h, const int32_t *actions_d, int seat0_policy
         return h ? h->fail(PK_E_INVALID_ARG, "pk_env_step_fused_d: bad argument") : PK_E_INVALID_ARG;
     ON_DEVICE(h);
     FLUSH(h);
-    const EnvKernArgs ka = env_args(h, actions_d, actions_d ? -1 : seat0_policy, uniform_seats(opp_policy), auto_reset ? 1 : 0, reward_d, done_d, hand_d, terr_d, obs_d);
+    const EnvKernArgs ka = with_packed(h, env_args(h, actions_d, actions_d ? -1 : seat0_policy, uniform_seats(opp_policy), auto_reset ? 1 : 0, reward_d, done_d, hand_d, terr_d, obs_d));
     DISPATCH_N(h, k_env_step, env_grid(h), ka);
     HIPCHK(h, hipGetLastError());
     return PK_OK;
@@ -856,7 +890,7 @@ int pk_env_step_async_d(pk_handle *h, const int32_t *actions_d, int seat0_policy
     if (rc) return rc;
     const int mp = max_passes > 0 ? max_passes : 0;
     if (h->env_batches <= 1) {
-        EnvKernArgs ka = env_args(h, actions_d, actions_d ? -1 : seat0_policy, uniform_seats(opp_policy), au, reward_d, done_d, hand_d, terr_d, obs_d);
+        EnvKernArgs ka = with_packed(h, env_args(h, actions_d, actions_d ? -1 : seat0_policy, uniform_seats(opp_policy), au, reward_d, done_d, hand_d, terr_d, obs_d));
         ka.A.ready = ready_d; ka.A.max_passes = mp;
         DISPATCH_N(h, k_env_step_async, env_grid(h), ka);
         HIPCHK(h, hipGetLastError());
@@ -873,7 +907,7 @@ int pk_env_step_async_d(pk_handle *h, const int32_t *actions_d, int seat0_policy
         auto launch_range = [&](int b, int passes) -> int {
             const int t0 = b * h->env_range, tend = (t0 + h->env_range < h->T) ? t0 + h->env_range : h->T;
             if (caller_busy) HIPCHK(h, hipStreamWaitEvent(h->env_streams[b], h->env_in, 0));
-            EnvKernArgs ka = env_args(h, actions_d, actions_d ? -1 : seat0_policy, uniform_seats(opp_policy), au, reward_d, done_d, hand_d, terr_d, obs_d);
+            EnvKernArgs ka = with_packed(h, env_args(h, actions_d, actions_d ? -1 : seat0_policy, uniform_seats(opp_policy), au, reward_d, done_d, hand_d, terr_d, obs_d));
             ka.A.ready = ready_d; ka.A.max_passes = passes; ka.A.t0 = t0; ka.A.tend = tend;
             DISPATCH_N_ON(h, h->env_streams[b], k_env_step_async, (tend - t0 + h->env_tpb - 1) / h->env_tpb, ka);
             HIPCHK(h, hipGetLastError());
@@ -967,7 +1001,7 @@ int pk_env_step_multi_d(pk_handle *h, const int32_t *actions_d, const uint8_t *r
     rc = flush_rollout(h);
     if (rc) return rc;
     const int pol0 = PK_SEAT_POLICY(seat_policies, 0);
-    EnvKernArgs ka = env_args(h, actions_d, pol0 == PK_POLICY_EXTERNAL ? -1 : pol0, seat_policies, au, reward_d, done_d, hand_d, terr_d, obs_d);
+    EnvKernArgs ka = with_packed(h, env_args(h, actions_d, pol0 == PK_POLICY_EXTERNAL ? -1 : pol0, seat_policies, au, reward_d, done_d, hand_d, terr_d, obs_d));
     ka.A.ready = ready_d; ka.A.max_passes = max_passes > 0 ? max_passes : 0; ka.A.reset_req = reset_d; ka.A.who = who_d;
     DISPATCH_N(h, k_env_step_multi, env_grid(h), ka);
     HIPCHK(h, hipGetLastError());
@@ -1174,12 +1208,15 @@ int pk_env_step_begin(pk_handle *h, const int32_t *actions, int opp_policy, int 
     HIPCHK(h, hipMemcpyAsync(terr, h->d_terr, T, hipMemcpyDeviceToHost, h->stream));
     if (obs) HIPCHK(h, hipMemcpyAsync(obs, h->d_export, T * D * 8, hipMemcpyDeviceToHost, h->stream));
     if (obs_packed) HIPCHK(h, hipMemcpyAsync(obs_packed, h->d_obs_packed, T * PB, hipMemcpyDeviceToHost, h->stream));
+    h->host_step = true;      // until pk_env_step_end: every entry point that reads or changes tables (another begin included) is PK_E_BUSY
     return PK_OK;
 }
 
 int pk_env_step_end(pk_handle *h) {
     if (!h) return PK_E_INVALID_ARG;
     ON_DEVICE(h);
+    if (!h->host_step) return h->fail(PK_E_INVALID_ARG, "pk_env_step_end: no pk_env_step_begin is waiting for it");
+    h->host_step = false;     // (whatever the wait below returns, nothing is queued into the caller's buffers any more once it has)
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return PK_OK;
 }
@@ -1200,7 +1237,7 @@ int pk_prof_read(pk_handle *h, unsigned long long *out) {
 int pk_sync(pk_handle *h) {
     if (!h) return PK_E_INVALID_ARG;
     ON_DEVICE(h);
-    if (!h->env_pending) FLUSH(h);   // env steps in flight stay in flight: only wait for the launches made so far
+    if (!in_flight(h)) FLUSH(h);     // env steps in flight stay in flight: only wait for the launches made so far
     HIPCHK(h, hipStreamSynchronize(h->stream));
     for (int b = 0; b < h->env_batches && h->env_batches > 1; ++b) HIPCHK(h, hipStreamSynchronize(h->env_streams[b]));
     return PK_OK;

@@ -18,6 +18,7 @@ class VecPokerGameEnv:
         that every opponent plays."""
         self.game = VecGame(num_tables, **game_config)  # game_env.py:16
         self.player_agent = 0                           # game_env.py:18
+        self._pin, self._sent, self._in_flight = {}, None, False    # send() / recv(): pinned arrays, what send() asked for, a send awaits its recv
         self.set_agents(agents)
 
     def set_agents(self, agents):
@@ -153,7 +154,12 @@ class VecPokerGameEnv:
         launches the step and queues the copies of reward / done / hand / terr and of the observation rows -- obs='packed'
         (state_view.packed_dtype rows, 168 B per table at six seats), 'dense' (f64 [T, PK_OBS_DIM], 280 B) or None -- into
         PINNED arrays this env keeps and reuses (so nothing here blocks, and another env's send / the caller's own work
-        overlaps with the copies).  recv() completes it.  Needs ONE in-kernel policy for all opponents."""
+        overlaps with the copies).  recv() completes it.  Needs ONE in-kernel policy for all opponents.
+        Between send() and recv() the env must not be used: a second send(), step(), reset() or a getter raises (PK_E_BUSY in the
+        library; here a RuntimeError before anything is touched), because the views an earlier recv() handed out are being written.
+        Invalid actions: strict=True checks them first and raises the reference's ValueError before any table is mutated (as step()
+        does); with the default strict=False a table whose action is invalid is left UNSTEPPED and recv()'s terr[t] says
+        PK_TERR_INVALID_ACTION (1) -- the caller must look at terr (step_pipelined does not)."""
         from .hipmem import pinned_empty
         from .state_view import packed_dtype
         g = self.game
@@ -161,8 +167,10 @@ class VecPokerGameEnv:
             raise ValueError('send / recv need ONE in-kernel policy for all opponents; per-seat / host agents: step()')
         if obs not in ('packed', 'dense', None):
             raise ValueError("obs: 'packed', 'dense' or None")
+        if self._in_flight:
+            raise RuntimeError('send(): the previous send() has not been completed by recv()')
         T, n = g.num_tables, g.num_players
-        if not getattr(self, '_pin', None):
+        if not self._pin:
             self._pin = dict(act=pinned_empty(T, np.int32), rew=pinned_empty(T, np.float64), done=pinned_empty(T, np.uint8),
                              hand=pinned_empty(T, np.uint8), terr=pinned_empty(T, np.uint8))
         b = self._pin
@@ -178,12 +186,16 @@ class VecPokerGameEnv:
                                          L.ptr(b['done'].array), L.ptr(b['hand'].array), L.ptr(b['terr'].array),
                                          L.ptr(b['dense'].array) if obs == 'dense' else None,
                                          L.ptr(b['packed'].array) if obs == 'packed' else None), g._h)
-        self._sent = obs
+        self._sent, self._in_flight = obs, True
 
     def recv(self):
         """Second half: waits for the copies send() queued and returns (obs, reward, done, hand, terr) -- VIEWS of the env's
-        pinned arrays, overwritten by the next send(); copy what must outlive it.  obs is None / packed rows / dense rows."""
+        pinned arrays, overwritten by the next send(); copy what must outlive it.  obs is None / packed rows / dense rows.
+        terr[t] != 0: that table's step did not happen as asked (1 = invalid action, table untouched; see send())."""
+        if not self._in_flight:
+            raise RuntimeError('recv() without a send()')
         g, b = self.game, self._pin
+        self._in_flight = False
         L.check(g._lib.pk_env_step_end(g._h), g._h)
         obs = None if self._sent is None else b[self._sent].array
         return obs, b['rew'].array, b['done'].array.view(np.bool_), b['hand'].array.view(np.bool_), b['terr'].array
@@ -349,11 +361,16 @@ class VecPokerGameEnvPool:
             raise L.PokerlHipError('table error bits %s' % np.unique(cat[4]))
         return cat[:4]
 
-    def step_pipelined(self, actions, obs='packed', auto_reset=False):
+    def step_pipelined(self, actions, obs='packed', auto_reset=False, strict=True):
         """The host-array fast path over the pool: send() on every batch, then recv() on every batch -- batch b+1's launch
         and the other devices' work overlap with batch b's device-to-host copies.  Returns one (obs, reward, done, hand,
-        terr) tuple of pinned VIEWS per batch (see VecPokerGameEnv.recv): no concatenation, no copy."""
+        terr) tuple of pinned VIEWS per batch (see VecPokerGameEnv.recv): no concatenation, no copy.
+        strict=True (the default, as step()): every batch's actions are checked first and the reference's ValueError is raised before
+        any table of any batch is mutated; strict=False: a table whose action is invalid is left unstepped and its terr is 1."""
         a = np.ascontiguousarray(np.broadcast_to(np.asarray(actions), (self.num_tables,)))
+        if strict:
+            for e, s in zip(self.envs, self.slices):
+                e.check_actions(a[s], table_offset=s.start)
         for e, s in zip(self.envs, self.slices):
             e.send(a[s], obs=obs, auto_reset=auto_reset)
         return [e.recv() for e in self.envs]

@@ -539,10 +539,37 @@ def test_packed_rows_from_the_env_kernels_and_the_pinned_host_path(O):
         assert not terr_b.any()
     # dense rows through the pinned path, and the getter into a caller-supplied pinned array
     acts = g.pick_actions(0)
+    with pytest.raises(RuntimeError):
+        eb.recv()                                                     # no send() awaits it
+    assert lib.pk_env_step_end(eb.game._h) == L.PK_E_INVALID_ARG
     eb.send(acts, obs='dense', auto_reset=True)
+    # between the two halves the handle is busy: the copies into the caller's (pinned) arrays are queued
+    with pytest.raises(RuntimeError):
+        eb.send(acts)
+    hb = eb.game._h
+    assert lib.pk_get_i32(hb, 0, L.ptr(np.zeros(T, np.int32))) == L.PK_E_BUSY and lib.pk_reset(hb, None, 0) == L.PK_E_BUSY
+    assert lib.pk_env_step_begin(hb, L.ptr(acts), 0, 1, L.ptr(np.zeros(T)), L.ptr(np.zeros(T, np.uint8)), L.ptr(np.zeros(T, np.uint8)),
+                                 L.ptr(np.zeros(T, np.uint8)), None, None) == L.PK_E_BUSY
+    assert lib.pk_sync(hb) == L.PK_OK                                 # (only waits)
     obs_b = eb.recv()[0]
     pin = pokerl_amd.pinned_empty((T, D), np.float64)
     assert eb.game.observations_of(None, out=pin.array) is pin.array and pin.array.tobytes() == obs_b.tobytes()
+    # an invalid action is not an error of send / recv: that table is left unstepped and terr says so (strict=True raises first)
+    bad = eb.game.pick_actions(0); bad[5] = 9
+    with pytest.raises(ValueError, match=r"table 5\)"):
+        eb.send(bad, obs=None, strict=True)
+    before = eb.game.step_serial
+    eb.send(bad, obs=None)
+    terr_b = eb.recv()[4]
+    assert terr_b[5] == L.TERR_INVALID_ACTION and not np.delete(terr_b, 5).any()
+    after = eb.game.step_serial
+    assert after[5] == before[5] and (np.delete(after, 5) > np.delete(before, 5)).all()
+    # the packed rows come from pk_env_step_fused_d / _async_d / _multi_d only: pk_env_step_d leaves the caller's buffer alone
+    bufs['packed'].upload(np.full(T * dt.itemsize, 0xA5, np.uint8))
+    bufs['act'].upload(g.pick_actions(0))
+    L.check(lib.pk_env_step_d(g._h, bufs['act'].ptr, 0, bufs['rew'].ptr, bufs['done'].ptr, bufs['hand'].ptr, bufs['terr'].ptr), g._h)
+    g.sync()
+    assert (bufs['packed'].download(np.uint8, T * dt.itemsize) == 0xA5).all()
     L.check(lib.pk_set_env_obs_packed(g._h, None), g._h)
     pin.free(); ea.close(); eb.close()
     for b in bufs.values():
