@@ -128,11 +128,14 @@ VALU_PEAK_WAVE_INSTS_PER_S = 256 * 4 * 2.4e9 / 2.0   # 256 CUs x 4 SIMDs, one wa
 #   (guides/MI355X_MICROARCH.md: "v_fma_f32 (wave64) 2 cyc (SIMD-32); one wave alone: 4")
 
 
-# Cycles per wave-instruction measured by tools/microbench/valu_rates.hip on MI355X (profiles/r03_valu_rates.txt; round 2's
-# subset: r02_valu_rates.txt), by waves per SIMD: (the plain VOP2 ALU kinds -- v_add / v_sub / v_and / v_or / v_xor, independent
+# Cycles per wave-instruction measured by tools/microbench/valu_rates.hip on MI355X (profiles/r05_valu_rates.txt, re-run in round 5:
+# the same figures as r03_valu_rates.txt to the second digit), by waves per SIMD: (the plain VOP2 ALU kinds -- v_add / v_sub / v_and / v_or / v_xor, independent
 # stream; everything else the step machine is made of -- every f64 op, shifts, v_bfe, v_bcnt, v_ffbh, multiplies, v_perm,
 # v_max, the three-operand forms v_or3 / v_lshl_or / v_max3 / v_lshl_add_u64, v_cndmask on an SGPR mask -- which all issue
-# at half rate).  A lone wave issues ~one instruction per 5 cycles whatever its kind; three waves per SIMD are interpolated
+# at half rate).  A lone wave issues ~one instruction per 5 cycles whatever its kind -- REAL cycles: the probe at the end of the
+# microbenchmark reads the shader-clock counter against the 100 MHz one (2 397 MHz, 4.75 ticks per instruction of an independent v_add_u32
+# stream); the guide's "one wave alone: 4" is the pipeline time of a wave64 instruction, the rest is the issue gap a lone wave cannot
+# fill (SQ_ACTIVE_INST_ANY = 79 % of the wave cycles in k_rollout).  Three waves per SIMD are interpolated
 # (towards the four-wave figures: with the two-wave ones the 1 M-table run exceeded its own ceiling by 1 %).
 ISSUE_CYCLES = {1: (5.0, 5.0), 2: (2.7, 4.5), 3: (2.5, 4.3), 4: (2.45, 4.3)}
 HALF_RATE_SHARE = 0.60   # fallback only (round 3's hand estimate): half_rate_share() below reads the figure GENERATED from
@@ -408,7 +411,7 @@ def env_roofline(res):
                          "valu_wave_insts_per_launch": per_launch, "lanes_active": d.get("lanes_active"),
                          "waves_per_simd": resident, "wait_any_frac": d.get("wait_any_frac_of_wave_cycles"),
                          "ceiling_mix": {"peak": ceil_rate, "frac_of_ceiling": rate / ceil_rate, "cycles_per_instruction": ceil_cyc,
-                                         "half_rate_share": half_rate_share()[0], "source": "profiles/r03_valu_rates.txt + " + half_rate_share()[1]},
+                                         "half_rate_share": half_rate_share()[0], "source": "profiles/r05_valu_rates.txt + " + half_rate_share()[1]},
                          "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE, KiB)",
                          "hbm": {"bound": "hbm (measured traffic)", "achieved": (traffic or 0.0) * res["launches"] / (res["device_ms"] * 1e-3) / 1e9,
                                  "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -579,7 +582,7 @@ def rollout_roofline(w, world):
                          "lanes_active": lanes, "waves_per_simd": resident, "waves_per_simd_launched": waves / 1024.0,
                          "wait_any_frac": d.get("wait_any_frac_of_wave_cycles"), "source": src,
                          "ceiling_mix": {"peak": ceil_rate, "frac_of_ceiling": valu_rate / ceil_rate,
-                                         "cycles_per_instruction": ceil_cyc, "source": "profiles/r03_valu_rates.txt",
+                                         "cycles_per_instruction": ceil_cyc, "source": "profiles/r05_valu_rates.txt",
                                          "half_rate_share": half_rate_share()[0], "half_rate_share_source": half_rate_share()[1],
                                          "note": "what this instruction mix can issue at this occupancy: measured cycles per "
                                                  "wave-instruction of the plain and of the half-rate kinds, weighted by their "
@@ -707,7 +710,7 @@ def step_line(res, name):
     prof = step_profile_summary(T, N)
     if prof:
         d, src = prof
-        mine = [k for k in d.get("kernels", {}) if not (res["replay"] and k == "k_pick") and not (res["fused_reset"] and k == "k_reset")]   # the kernels of THIS leg's loop iteration
+        mine = [k for k in d.get("loop_kernels", d.get("kernels", {})) if not (res["replay"] and k == "k_pick") and not (res["fused_reset"] and k == "k_reset")]   # the kernels of THIS leg's loop iteration
         roof.update({"traffic": sum(d["kernels"][k].get("hbm_traffic_bytes_per_launch", 0.0) for k in mine), "source": src,
                      "k_step_ms_rocprof": d.get("k_step_avg_ms"), "kernels_in_traffic": mine,
                      "traffic_unit": "HBM bytes per loop iteration (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE, KiB), summed over its kernels"})

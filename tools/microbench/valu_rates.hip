@@ -102,6 +102,23 @@ __global__ void __launch_bounds__(256) k64(int iters, double *sink) {
     sink[blockIdx.x * blockDim.x + threadIdx.x] = r;
 }
 
+// What a "cycle" above is worth: the rows divide elapsed TIME by the 2.4 GHz nominal clock.  This kernel reads the shader-clock counter
+// (s_memtime) and the constant 100 MHz counter (s_memrealtime) around the same independent v_add_u32 stream, one wave per SIMD: the
+// ratio is the clock the SIMDs really ran at, and counter ticks / instructions = issue cost in REAL shader cycles.
+__global__ void __launch_bounds__(256) k_clock(int iters, unsigned long long *out, unsigned *sink) {
+    unsigned x[8], b = threadIdx.x | 1;
+    for (int i = 0; i < 8; ++i) x[i] = threadIdx.x + i;
+    const unsigned long long c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; ++it) {
+        REP8(AddU32::dep(x[0], b); AddU32::dep(x[1], b); AddU32::dep(x[2], b); AddU32::dep(x[3], b); AddU32::dep(x[4], b); AddU32::dep(x[5], b); AddU32::dep(x[6], b); AddU32::dep(x[7], b);)
+    }
+    const unsigned long long c1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
+    unsigned r = 0;
+    for (int i = 0; i < 8; ++i) r ^= x[i];
+    sink[blockIdx.x * blockDim.x + threadIdx.x] = r;
+    if (threadIdx.x == 0) { out[2 * blockIdx.x] = c1 - c0; out[2 * blockIdx.x + 1] = r1 - r0; }
+}
+
 template <typename K, typename S>
 static void row(const char *label, K kern, S *sink, int ilp) {
     const int iters = 4000;
@@ -133,5 +150,22 @@ int main() {
     R32(AddU32) R32(XorB32) R32(AndB32) R32(Cndmask) R32(CndmaskSgpr) R32(CmpCnd) R32(CmpCndS) R32(LshlRev) R32(Bcnt) R32(MulU24) R32(MulLo) R32(MulHi)
     R32(Bfe) R32(Perm) R32(Or3) R32(Max3) R32(MaxU32) R32(Bitop3) R32(LshlOr) R32(Ffbh)
     R64(AddF64) R64(MulF64) R64(FmaF64) R64(CmpF64) R64(Mad64) R64(Lshl64) R64(LshlAdd64) R64(MaxF64)
+    {   // the real clock, and the lone wave's issue cost in real shader cycles
+        unsigned long long *d, h[512];
+        (void)hipMalloc(&d, sizeof(h));
+        const int iters = 20000;
+        for (int wps : {1}) {   // (one wave per SIMD: with more, a wave's own elapsed ticks no longer say what the SIMD issued)
+            hipLaunchKernelGGL(k_clock, dim3(256 * wps), dim3(256), 0, 0, iters, d, s32);
+            hipLaunchKernelGGL(k_clock, dim3(256 * wps), dim3(256), 0, 0, iters, d, s32);
+            (void)hipDeviceSynchronize();
+            (void)hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+            double ticks = 0, real = 0;
+            for (int i = 0; i < 256; ++i) { ticks += (double)h[2 * i]; real += (double)h[2 * i + 1]; }
+            const double mhz = ticks / real * 100.0;
+            printf("clock probe, %d wave(s) per SIMD, independent v_add_u32 stream: shader-clock counter / 100 MHz counter = %.0f MHz;  %.2f counter ticks per "
+                   "wave-instruction (%.2f ns -> %.2f cycles at the nominal 2.4 GHz)\n", wps, mhz, ticks / 256 / ((double)iters * 64 * wps),
+                   real / 256 * 10.0 / ((double)iters * 64 * wps), real / 256 * 10.0 * 2.4 / ((double)iters * 64 * wps));
+        }
+    }
     return 0;
 }

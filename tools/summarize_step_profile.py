@@ -58,7 +58,7 @@ for k, d in per.items():
                              "lds_bytes": int(r["LDS_Block_Size"]), "scratch_bytes": int(r["Scratch_Size"]),
                              "grid": int(r["Grid_Size_X"]), "workgroup": int(r["Workgroup_Size_X"])}
 summary["k_step_avg_ms"] = sum(summary["kernels"][k]["avg_ms"] for k in summary["kernels"] if k.startswith("k_step"))
-summary["kernel_ms_per_step_sum"] = sum(v["avg_ms"] for v in summary["kernels"].values())
+summary["kernel_ms_per_step_sum"] = sum(v["avg_ms"] for v in summary["kernels"].values() if v["launches"] * 2 >= max(x["launches"] for x in summary["kernels"].values()))
 # PMC passes: per kernel, the mean per launch; a loop iteration = one launch of each kernel of the loop
 for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
     if not os.path.isdir(d):
@@ -75,11 +75,14 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
     for (k, c), v in agg.items():
         summary["kernels"].setdefault(k, {}).setdefault("pmc_per_launch", {})[c] = v / cnt[(k, c)]
 tot = 0.0
+most = max(v.get("launches", 0) for v in summary["kernels"].values())
+summary["loop_kernels"] = [k for k, v in summary["kernels"].items() if v.get("launches", 0) * 2 >= most]   # (not the one k_reset of the set-up)
 for k, v in summary["kernels"].items():
     p = v.get("pmc_per_launch", {})
     if "FETCH_SIZE" in p and "WRITE_SIZE" in p:
         v["hbm_traffic_bytes_per_launch"] = (2.0 * p["FETCH_SIZE"] + p["WRITE_SIZE"]) * 1024.0
-        tot += v["hbm_traffic_bytes_per_launch"]
+        if k in summary["loop_kernels"]:
+            tot += v["hbm_traffic_bytes_per_launch"]
     if p.get("SQ_ACTIVE_INST_VALU") and "SQ_THREAD_CYCLES_VALU" in p:
         v["lanes_active"] = p["SQ_THREAD_CYCLES_VALU"] / (64.0 * p["SQ_ACTIVE_INST_VALU"])
     if p.get("SQ_WAVES"):
