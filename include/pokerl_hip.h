@@ -39,7 +39,7 @@ extern "C" {
                              calls are restated exactly: np.sum's eight-lane pairwise blocks (one up to 15 seats, two at 16) and
                              np.argsort's stable insertion sort (the pinned numpy sorts up to 17 elements that way); from 18 seats on
                              argsort's order among EQUAL bets -- which decides side pots -- is no longer a rule the reference pins,
-                             and a 17th seat does not fit the 16 nibbles of a policy word: DESIGN.md section 9.  13 ... 16 seats
+                             and a 17th seat does not fit the 16 nibbles of a policy word: DESIGN.md section 8, docs/history.md section 9.  13 ... 16 seats
                              run kernels that keep part of the table in AGPRs at one wave per SIMD (no scratch memory). */
 #define PK_MAX_ENV_BATCHES 8 /* pk_set_env_batches */
 #define PK_MAX_DEVICES 64 /* the handle-less judger calls keep one scratch arena per device index below this */
@@ -346,7 +346,7 @@ int pk_env_step_async_d(pk_handle *h, const int32_t *actions_d, int seat0_policy
  *   - LAUNCHES one range (round robin), reading actions_d only inside it, and
  *   - DELIVERS the range launched longest ago: the call WAITS ON THE HOST for that launch (made B - 1 calls ago, so done or
  *     nearly so; ABI 3 queued a device-side wait on the handle's stream instead, whose barrier packet could stall another range's
- *     hardware queue -- DESIGN.md section 5), and pk_env_last_range reports [begin, end): ready_d / reward_d / ... / obs_d are
+ *     hardware queue -- docs/history.md section 5), and pk_env_last_range reports [begin, end): ready_d / reward_d / ... / obs_d are
  *     COMPLETE inside that range when the call returns (and untouched outside).  The launch itself is ordered after the work the
  *     caller queued on the handle's stream (an event pair) unless that stream is idle, in which case nothing needs ordering.
  *     fresh != 0: that range has not been launched yet since pk_set_env_batches / the last drain -- nothing was written, every

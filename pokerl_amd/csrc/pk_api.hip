@@ -260,7 +260,7 @@ static int export_to_host(pk_handle *h, void *out, size_t bytes, F launch) {
 
 // Streams are RECYCLED through a per-device pool instead of being destroyed with their handle: a process that opens and closes
 // handles (bench.py's legs, a test suite) keeps working on the same few streams -- and therefore on the same hardware queues --
-// instead of walking through HIP's stream-to-queue assignment (see the sub-batch notes below and DESIGN.md section 5).
+// instead of walking through HIP's stream-to-queue assignment (see the sub-batch notes below and docs/history.md section 5).
 static std::mutex g_stream_mu;
 static std::vector<hipStream_t> g_stream_pool[PK_MAX_DEVICES][2];   // [device][0: normal priority, 1: the sub-batch streams]
 // The internal streams of pk_set_env_batches are created with the HIGHEST stream priority: HIP keeps separate hardware queues per
@@ -356,7 +356,7 @@ int pk_create(pk_handle **out, int device, int num_tables, int num_players, cons
         g_err = "pk_create: need num_tables >= 1 and " PK_STR(PK_MIN_PLAYERS) " <= num_players <= " PK_STR(PK_MAX_PLAYERS)
                 " (the reference takes any num_players, game.py:246; a 17th seat does not fit the 16 nibbles of a policy word, and from 18 seats on "
                 "numpy's argsort of the bets, game.py:495, is no longer a stable insertion sort, so the side-pot order among equal bets is not a "
-                "rule the reference pins: DESIGN.md section 9)";
+                "rule the reference pins: DESIGN.md section 8, docs/history.md section 9)";
         return PK_E_INVALID_ARG;
     }
     if (!seat_count_built(num_players)) { g_err = "pk_create: this development build of the library holds one seat count only (PK_ONLY_SEATS)"; return PK_E_INVALID_ARG; }

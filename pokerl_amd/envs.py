@@ -294,7 +294,7 @@ class VecPokerGameEnvPool:
 
     Why: a bounded launch of pk_env_step_async_d ends with a tail (the last waves run alone), and launches of one handle are
     serialised on its stream, so ONE batch of 65 536 tables delivers 0.88 G env.step/s while FOUR such batches whose
-    launches overlap deliver 2.7 G -- a learner works on the batch whose launch has finished while the
+    launches overlap deliver 3.6 G (docs/history.md section 5) -- a learner works on the batch whose launch has finished while the
     others run.  Tables keep their GLOBAL ids (table_id_base), so the pool's tables play exactly the trajectories of one
     handle holding all of them (RNG spec: streams are keyed by the global table id).
 

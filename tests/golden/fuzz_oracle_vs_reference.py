@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Fuzz the CPU oracle against the REAL reference on random odd configurations (build container only: imports
 /root/reference through make_golden's injection harness; nothing is written).  A configuration on which the reference
-itself never returns (Game.step spins) is skipped after a time-out.
+itself never returns (Game.step spins, docs/history.md section 2) is skipped after a time-out.
 
     PYTHONDONTWRITEBYTECODE=1 python tests/golden/fuzz_oracle_vs_reference.py [rounds] [min_seats max_seats]
 (seats default 2..10: the generator sequence of the recorded runs; `200 11 15` fuzzes the wide tables)

@@ -200,7 +200,7 @@ def view_record(game):
 
 # --------------------------------------------------------------------------- Game trajectories
 class _HandCapProbe:
-    """The cap rule ("Steps that never return", rule (b)): a Game.step that rolls more than `cap` hands
+    """The cap rule (docs/history.md section 2, "Steps that never return", rule (b)): a Game.step that rolls more than `cap` hands
     is ended by the product right after its (cap+1)-th setup_hand() with PK_TERR_HAND_CAP, although the reference -- on the
     configuration pinned here -- does return, thousands of hands later.  This probe wraps the reference game's setup_hand
     (called as self.setup_hand() by end_hand, game.py:539) and snapshots the table right after that call: what the product

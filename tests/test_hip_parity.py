@@ -415,7 +415,7 @@ def test_both_rollout_kernels_vs_oracle(HB, O, monkeypatch, occ3):
 
 def test_hand_cap_rule(HB, O):
     """start_credits = 0: every seat is re-dealt all-in with no chips for ever -- the reference's Game.step would never
-    return.  step() reports PK_TERR_HAND_CAP; a rollout with auto_reset treats it as a finished game."""
+    return (docs/history.md section 2).  step() reports PK_TERR_HAND_CAP; a rollout with auto_reset treats it as a finished game."""
     T, N = 256, 3
     o = O.OracleGame(T, N, 0, 2, 1)
     h = HB(T, N, 0, 2, 1)

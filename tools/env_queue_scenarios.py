@@ -2,7 +2,7 @@
 """Diagnostic (GPU box): does the sub-batched PokerGameEnv.step (pk_set_env_batches, bench.py's extra leg) run at the same rate
 whatever the PROCESS did before?  Round 4 found it did not -- 3.6 G env.step/s in a fresh process, 2.6 G after one hipMemcpy, 1.5 G
 after another PokerGameEnv handle had been used: barrier packets of the cross-stream waits stalling hardware queues that share a
-pipe -- and this is the script that pinned it down.  Each scenario runs in a process of its own.
+pipe (docs/history.md section 5) -- and this is the script that pinned it down.  Each scenario runs in a process of its own.
 usage: python tools/env_queue_scenarios.py [scenario ...]     (no argument: all of them, one child process each)"""
 import os
 import subprocess
