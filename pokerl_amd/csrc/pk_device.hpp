@@ -661,6 +661,13 @@ enum : int { LS_DONE = 0, LS_SCAN = 1, LS_POT = 2, LS_END = 3 };
 #ifndef PK_WAVE
 #define PK_WAVE 64  // lanes per wavefront on gfx950 (tools/host_sim builds this header with 1)
 #endif
+// Decks a lone dealing table computes at once, on as many lanes, for the hands its step may roll on (end_block<false>'s deal stock)
+#define PK_STOCK (PK_WAVE >= 4 ? 4 : 1)
+#if PK_WAVE >= 16
+__device__ __forceinline__ uint32_t lane_read(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane); }   // lane: wave-uniform
+__device__ __forceinline__ uint64_t lane_read64(uint64_t v, int lane) { return (uint64_t)lane_read((uint32_t)v, lane) | ((uint64_t)lane_read((uint32_t)(v >> 32), lane) << 32); }
+__device__ __forceinline__ bool wave_uniform(bool b) { return __builtin_amdgcn_readfirstlane((int)b) != 0; }   // b holds the same value in every lane
+#endif
 
 // Diagnostic build only (-DPK_PROFILE, libpokerl_hip_prof.so; never the shipped library): per-wave cycle stamps
 // (s_memtime) around the blocks of the step machine, summed into State::prof.  Shares, not run times, are read from it.
@@ -700,6 +707,9 @@ struct Lds {  // per workgroup (= one wavefront); ~10 KB at N = 10
                                // (keeps global stores, and the vmcnt waits they drag along, out of the step loop)
     Fresh fresh;               // workgroup copy of *Hot::fresh (Table::stage_fresh), read with broadcast ds_reads
     alignas(16) uint8_t nth[128][8];   // nth[mask][k] = k-th (0-based) set bit of a 7-bit valid-action mask (stage_nth)
+    // (last, so that the layout above is what the kernels without single-table tails were tuned with)
+    uint32_t lone[(5 + 2 * N + 3) / 4];              // the deck words of a wave's ONE arriving table (end_block<false>), read by byte
+    uint32_t stock[PK_STOCK][(5 + 2 * N + 3) / 4];   // decks dealt ahead for ONE table of the wave (end_block<false>: a lone dealing table's step may roll on)
 };
 
 struct ActionRng {  // one Philox block serves EIGHT consecutive steps of a table: 16-bit draws (RNG spec)
@@ -861,16 +871,21 @@ struct Table {
     // counters since load
     uint32_t evals, games, hands, seen;
     bool showed;  // lds.show holds a showdown of this launch
+    bool pay_dirty;   // an end_hand of this launch has rewritten payoffs (load<false> / store<false>)
+    uint32_t stock_lane; uint64_t stock_serial;   // wave-uniform: lds.stock holds the decks of hand serials stock_serial .. +PK_STOCK-1 of lane stock_lane's table
     PK_PROF(Prof prof;)
 
-    template <typename ST>   // State, or a State in address space 1 (`*as_global(Sp)`)
+    // PAYOFFS == false (the single-step kernels, whose launch time is the bytes they move): Game.payoffs is not read -- the step machine
+    // only ever WRITES it (end_hand zeroes it first, game.py:468) -- and store<false> writes it back only where a hand ended (pay_dirty).
+    template <bool PAYOFFS = true, typename ST>   // ST: State, or a State in address space 1 (`*as_global(Sp)`)
     __device__ __forceinline__ void load(const ST &S, int t) {
         const auto g_credits = as_global(S.credits), g_bets = as_global(S.bets), g_pending = as_global(S.pending), g_payoffs = as_global(S.payoffs);
         const size_t T = (size_t)S.T;
         PK_FOR(p, N)
             credits[p] = g_credits[(size_t)p * T + t]; bets[p] = g_bets[(size_t)p * T + t];
-            pending[p] = g_pending[(size_t)p * T + t]; payoffs[p] = g_payoffs[(size_t)p * T + t];
+            pending[p] = g_pending[(size_t)p * T + t]; payoffs[p] = PAYOFFS ? g_payoffs[(size_t)p * T + t] : 0.0;
          PK_END
+        pay_dirty = false;
         min_raise = as_global(S.min_raise)[t];
         uint64_t ss = as_global(S.seat_states)[t];
         st_active = (uint32_t)ss & 0xffff; st_called = (uint32_t)(ss >> 16) & 0xffff;
@@ -888,6 +903,7 @@ struct Table {
         PK_FOR(p, N) pot_wb[p] = 0.0; pot_hv[p] = NONE_V; PK_END
         pot_todo = 0; pot_npw = 0;
         evals = 0; games = 0; hands = 0; seen = 0; showed = false;
+        stock_lane = ~0u; stock_serial = 0;
     }
     // A lane with no table (t >= T) still walks the wave-uniform control flow: give it inert, well-defined state.
     __device__ __forceinline__ void blank() {
@@ -898,17 +914,20 @@ struct Table {
         PK_FOR(p, N) pot_wb[p] = 0.0; pot_hv[p] = NONE_V; PK_END
         pot_todo = 0; pot_npw = 0;
         idle();
-        evals = 0; games = 0; hands = 0; seen = 0; showed = false;
+        evals = 0; games = 0; hands = 0; seen = 0; showed = false; pay_dirty = false;
+        stock_lane = ~0u; stock_serial = 0;
     }
     __device__ __forceinline__ void idle() { lstate = LS_DONE; current = 0; hands_this_step = 0; flags = 0; terr = 0; stepped = 0; foldout = false; }
-    template <typename ST>
+    template <bool PAYOFFS = true, typename ST>
     __device__ __forceinline__ void store(const ST &S, int t) const {
         const auto g_credits = as_global(S.credits), g_bets = as_global(S.bets), g_pending = as_global(S.pending), g_payoffs = as_global(S.payoffs);
         const size_t T = (size_t)S.T;
         PK_FOR(p, N)
             g_credits[(size_t)p * T + t] = credits[p]; g_bets[(size_t)p * T + t] = bets[p];
-            g_pending[(size_t)p * T + t] = pending[p]; g_payoffs[(size_t)p * T + t] = payoffs[p];
+            g_pending[(size_t)p * T + t] = pending[p];
+            if (PAYOFFS) g_payoffs[(size_t)p * T + t] = payoffs[p];
          PK_END
+        if (!PAYOFFS && pay_dirty) { PK_FOR(p, N) g_payoffs[(size_t)p * T + t] = payoffs[p]; PK_END }
         as_global(S.min_raise)[t] = min_raise;
         as_global(S.seat_states)[t] = (uint64_t)st_active | ((uint64_t)st_called << 16) | ((uint64_t)st_allin << 32) | ((uint64_t)st_broken << 48);
         const uint32_t inflight = ((uint32_t)current << 20) | ((uint32_t)lstate << 24) | ((uint32_t)foldout << 26) | (stepped << 27) | (flags << 28);
@@ -956,6 +975,11 @@ struct Table {
 
     // Deck of this hand (RNG spec: DESIGN.md, "RNG specification") -> cards[]; replaces random.shuffle(self.deck), game.py:424.
     __device__ __forceinline__ void deal(const Hot &S, uint32_t table_id) {
+        deal_cards(S, table_id, hand_serial, cards);
+        hand_serial += 1;
+    }
+    // The deck of (table_id, hand_serial) as packed Card.value words: a pure function of its arguments (any lane may compute any table's)
+    __device__ __forceinline__ static void deal_cards(const Hot &S, uint32_t table_id, uint64_t hand_serial, uint32_t (&cards)[W]) {
         uint32_t c[K];
         constexpr int NB = (K + 17) / 18;
         PK_FOR(b, NB)
@@ -973,7 +997,6 @@ struct Table {
                 PK_END
             PK_END
         PK_END
-        hand_serial += 1;
         // Lehmer decode ("c_i-th card not yet dealt") without arrays: packed bytes (bit 7 kept set), processed from the
         // last draw to the first; for each earlier-processed (later-drawn) byte b: b += (b >= c_i).  A word operation costs
         // four instructions whatever the number of live bytes in it, so a LAST word that holds a single card (K = 4k + 1:
@@ -1162,17 +1185,23 @@ struct Table {
     // every batch size (21.9 vs 23.4 G at 65 536 x 6, 34.5 vs 37.0 G at 1 M x 6), faster where a launch ends with a few lanes
     // per wave anyway, so that every further end_block call serves one or two tables: the single-step kernels (k_step,
     // k_rollout_single: +3.9 %), the synchronous PokerGameEnv.step (+3.1 %) and k_env_reset.
-    template <bool ONE_PASS = true>
+    // LONE (only with !ONE_PASS): the two single-table paths below -- a lone arriving table's showdown without the queue, a lone dealing
+    // table's decks four at a time.  For the kernels whose launches end in a tail of single tables: k_step / k_rollout_single (+7 %: a
+    // step that rolls hand after hand), k_env_step / k_env_reset (+1 %); NOT the bounded asynchronous env launches (-3 %: their
+    // end_blocks serve one or two tables that rarely deal twice within a launch) -- profiles/r05_ab_lone.txt.
+    template <bool ONE_PASS = true, bool LONE = !ONE_PASS>
     __device__ __forceinline__ void end_block(const Hot &S, int t, uint32_t table_id, Lds<N> &lds, bool auto_reset) {
+        static_assert(!(ONE_PASS && LONE), "the lone-table paths belong to the kernels that run the whole side-pot loop per call");
         const bool e = lstate == LS_END;
         const bool resumed = ONE_PASS && lstate == LS_POT;
         PK_PROF(prof.lap(PF_OTHER); prof.count(PF_N_END);)
 #ifdef PK_PROFILE_COUNTS
         if (e) { const unsigned long long act = __ballot(1); if ((int)(threadIdx.x & 63) == __ffsll((long long)act) - 1) atomicAdd(&S.prof[PF_N_END_LANES], (unsigned long long)__popcll(act)); }
 #endif
-        bool sd = false, nowin = false;
+        bool sd = false, nowin = false, need_deal = false;
         uint32_t showdown = 0;
         if (e) {
+            pay_dirty = true;
             PK_FOR(p, N)                                          // :457-461, :468
                 bets[p] = bets[p] + pending[p]; credits[p] = credits[p] - pending[p];
                 pending[p] = 0.0; payoffs[p] = 0.0;
@@ -1194,15 +1223,50 @@ struct Table {
             pot_npw = sd ? npw : pot_npw;
         }
         PK_PROF(prof.lap(PF_END_PRE);)
-        // ---- showdown hands of all arriving lanes -> LDS queue -> one hand per lane (game.py:488-489)
         const int lane = threadIdx.x & 63;
+        // ---- ONE arriving lane (the kernels whose launches end in a tail of single tables: a step that rolls hand after hand, a busted
+        //      seat 0 waiting for the end of its game): no queue, no barrier -- the lane's cards travel by v_readlane, lane p evaluates
+        //      seat p's hand, the rankings travel back the same way.  Same function on the same cards as the queue below.
+        bool lone = false;
+#if PK_WAVE >= 16 && !defined(PK_NO_LONE)   // (PK_NO_LONE: A/B builds without the lone-table paths)
+        if constexpr (LONE) {
+            const unsigned long long eb = __ballot(e);
+            lone = __popcll(eb) == 1;                                              // wave-uniform
+            if (lone) {
+                const int sl = __ffsll((long long)eb) - 1;
+                const uint32_t sm = lane_read(showdown, sl);
+                if (sm) {
+                    // the lane's deck words go through ONE row of LDS: lane p picks seat p's hole cards out of it by byte address (as
+                    // a select chain over readlane'd words the compiler spilled the words to scratch memory and indexed them there)
+                    if (e) { PK_FOR(w, W) lds.lone[w] = cards[w]; PK_END }
+                    __syncthreads();
+                    const int q = lane < N ? lane : 0;
+                    const uint8_t *lb = reinterpret_cast<const uint8_t *>(lds.lone);
+                    const uint32_t c0 = lds.lone[0];
+                    const uint32_t h[7] = {c0 & 0xff, (c0 >> 8) & 0xff, (c0 >> 16) & 0xff, c0 >> 24, lb[4],
+                                           lb[5 + 2 * q], lb[6 + 2 * q]};               // hand = deck[:5] + hole cards (:394-395)
+                    const uint32_t v = eval7_distinct(h);
+                    uint32_t res[N];
+                    PK_FOR(p, N) res[p] = lane_read(v, p); PK_END
+                    if (sd) { PK_FOR(p, N) pot_hv[p] = ((showdown >> p) & 1) ? res[p] : NONE_V; PK_END }
+                    evals += __popc(showdown);
+                } else if (sd) {
+                    PK_FOR(p, N) pot_hv[p] = NONE_V; PK_END
+                }
+            }
+        }
+#endif
+        // ---- showdown hands of all arriving lanes -> LDS queue -> one hand per lane (game.py:488-489)
         uint32_t total = 0, my_base[N];
+        if (!lone) {
         PK_FOR(p, N)
             unsigned long long bal = __ballot((showdown >> p) & 1);
             my_base[p] = total + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
             total += (uint32_t)__popcll(bal);
          PK_END
-        if (total) {  // wave-uniform
+        }
+        if (lone) {
+        } else if (total) {  // wave-uniform
             PK_FOR(p, N)                                                           // hand = deck[:5] + hole cards (:394-395)
                 const uint32_t slot = ((showdown >> p) & 1) ? my_base[p] : (uint32_t)(64 * N + lane);   // no branch per seat
                 lds.item[slot][0] = cards[0];
@@ -1313,8 +1377,34 @@ struct Table {
                     load_fresh(lds.fresh);
                 }
                 PK_PROF(prof.lap(PF_SETUP);)
-                deal(S, table_id);                                                 // :424
+                if constexpr (ONE_PASS) deal(S, table_id);                         // :424
+                else need_deal = true;                                             // (dealt below, outside the divergent branch)
             }
+        }
+        if constexpr (!ONE_PASS) {
+            // :424 for the kernels with single-table tails.  ONE table deals: PK_STOCK decks at once -- hand serials hs .. hs+3 on four
+            // lanes, the price of one -- kept in LDS for the hands this table's step may roll on (each further hand of the tail then
+            // takes its deck from the stock: a deal is a third of a lone end_block).  A deck is a pure function of (table id, hand
+            // serial), so a stocked deck IS the deck the table would have dealt.
+#if PK_WAVE >= 16 && !defined(PK_NO_LONE)
+            const unsigned long long db = LONE ? __ballot(need_deal) : 0ull;
+            if (LONE && __popcll(db) == 1) {
+                const int dl = __ffsll((long long)db) - 1;
+                const uint32_t tid = lane_read(table_id, dl);
+                const uint64_t hs = lane_read64(hand_serial, dl);
+                uint32_t idx = (uint32_t)(hs - stock_serial);
+                if (!wave_uniform(stock_lane == (uint32_t)dl && hs - stock_serial < (uint64_t)PK_STOCK)) {
+                    uint32_t c[W];
+                    deal_cards(S, tid, hs + (uint64_t)(lane & (PK_STOCK - 1)), c);
+                    __syncthreads();                                               // (earlier reads of the stock are done)
+                    if (lane < PK_STOCK) { PK_FOR(w, W) lds.stock[lane][w] = c[w]; PK_END }
+                    __syncthreads();
+                    stock_lane = (uint32_t)dl; stock_serial = hs; idx = 0;
+                }
+                if (need_deal) { PK_FOR(w, W) cards[w] = lds.stock[idx][w]; PK_END hand_serial += 1; }
+            } else
+#endif
+            if (need_deal) deal(S, table_id);
         }
         PK_PROF(prof.lap(PF_DEAL);)
     }
@@ -1326,7 +1416,7 @@ struct Table {
             cursor();
             PK_PROF(prof.lap(PF_CURSOR); prof.count(PF_N_CURSOR);)
             if (!__any(parked())) break;
-            end_block(S, t, table_id, lds, auto_reset);
+            end_block<false>(S, t, table_id, lds, auto_reset);   // (k_step's form: the whole side-pot loop per call, the lone-table paths)
         }
         PK_PROF(prof.lap(PF_OTHER);)
         finish_step();

@@ -123,7 +123,8 @@ __device__ __forceinline__ void rollout_body(const State *__restrict__ Sp, const
     Table<N>::stage_fresh(lds, H.fresh);
     stage_nth(lds);
     constexpr bool EXTERNAL = POLICY == PK_POLICY_EXTERNAL;
-    if (live) { tb.load(S, t); tb.hands_this_step = (int)as_global(S.mid)[t]; owed = as_global(S.owed)[t] + (uint32_t)K; } else tb.blank();
+    constexpr bool PAY = PASSES != 1;        // the single-step kernels (k_step, k_rollout_single) move the payoffs only where a hand ended
+    if (live) { tb.template load<PAY>(S, t); tb.hands_this_step = (int)as_global(S.mid)[t]; owed = as_global(S.owed)[t] + (uint32_t)K; } else tb.blank();
     uint32_t steps = 0;
     bool alive = live;
     ActionRing ring;
@@ -213,7 +214,7 @@ __device__ __forceinline__ void rollout_body(const State *__restrict__ Sp, const
         if (late & 1u) {
             const auto flags_out = as_global(ext->flags), terr_out = as_global(ext->terr);
             if (ext_ok_l) {
-                tb.store(S, t);
+                tb.template store<PAY>(S, t);
                 tb.store_show(S.show, S.T, t, lds);
                 as_global(S.mid)[t] = 0;
                 as_global(S.valid)[t] = (uint8_t)tb.valid_mask(high_bet);
@@ -227,7 +228,7 @@ __device__ __forceinline__ void rollout_body(const State *__restrict__ Sp, const
         return;                                                                    // Game.step is not counted as rollout work
     }
     if (live) {
-        tb.store(S, t);
+        tb.template store<PAY>(S, t);
         tb.store_show(S.show, S.T, t, lds);
         as_global(S.owed)[t] = owed; as_global(S.mid)[t] = (uint32_t)tb.hands_this_step;
         as_global(S.valid)[t] = (uint8_t)tb.valid_mask(high_bet);
@@ -585,7 +586,7 @@ __device__ __forceinline__ void env_step_body() {
         if (last || (parked == 0 && runnable == 0)) break;
         passes += made;
         if (parked >= park || runnable == 0) {
-            tb.template end_block<false>(H, t, table_id, lds, false);   // synchronous: the side-pot loop runs to its end inside the call (the step's tail is a few lanes)
+            tb.template end_block<false, !ASYNC>(H, t, table_id, lds, false);   // the side-pot loop runs to its end inside the call (the step's tail is a few lanes); lone-table paths: synchronous only
             retire();
         }
     }

@@ -517,6 +517,25 @@ def test_device_resident_game_loop(HB, O):
     assert lib.pk_step_auto_d(g._h, None, None, None) == L.PK_E_INVALID_ARG
 
 
+def test_stream_pool_drain(HB):
+    """Handles recycle their streams through a per-device pool; pk_stream_pool_drain destroys the pooled (idle) ones -- what a host
+    application calls before hipDeviceReset or to give the hardware queues back -- and handles created afterwards work."""
+    import pokerl_amd
+    from pokerl_amd import _lib as L
+    lib = L.lib()
+    g = pokerl_amd.VecGame(256, num_players=3)
+    g.reset(); g.rollout(10, 0)
+    g.close()                                           # its stream goes to the pool
+    n = lib.pk_stream_pool_drain(0)
+    assert n >= 1
+    assert lib.pk_stream_pool_drain(0) == 0 and lib.pk_stream_pool_drain(-1) == 0
+    assert lib.pk_stream_pool_drain(1000) == L.PK_E_INVALID_ARG
+    g = pokerl_amd.VecGame(256, num_players=3)          # a fresh stream
+    g.reset()
+    assert g.rollout(5, 0)["steps"] == 256 * 5
+    g.close()
+
+
 def test_bad_arguments_are_reported_not_fatal(HB):
     import ctypes as C
     import pokerl_amd

@@ -60,7 +60,7 @@ static int run(int T, int K, int policy, uint64_t seed, Cfg cfg = default_cfg(),
         orc_rollout(o, 1, policy, 1, c4);
         for (int t = 0; t < T; ++t) {
             Table<N> &x = tb[t];
-            x.load(S, t);
+            if (k & 1) x.template load<false>(S, t); else x.load(S, t);          // (k_step: payoffs are written back only where a hand ended)
             double hb; uint32_t mask = x.valid_mask(hb);
             ActionRing ring;   // the LDS ring of k_rollout (one lane)
             uint32_t draw = policy == 0 ? ActionRing::half_of(ring.draw16(lds, H, cfg.base + (uint32_t)t, x.step_serial, true), x.step_serial) : 0;
@@ -74,7 +74,7 @@ static int run(int T, int K, int policy, uint64_t seed, Cfg cfg = default_cfg(),
                 }
                 x.finish_step();
             }
-            x.store(S, t);
+            if (k & 1) x.template store<false>(S, t); else x.store(S, t);
         }
         orc_get_f64(o, 0, oc.data()); orc_get_f64(o, 1, ob.data()); orc_get_f64(o, 2, op.data()); orc_get_f64(o, 3, oy.data());
         orc_get_states(o, ost.data()); orc_get_cursors(o, ocur.data());
