@@ -585,6 +585,9 @@ __device__ __forceinline__ void env_step_body() {
         const int runnable = closing ? 0 : __popcll(__ballot(phase != PH_END && tb.lstate == LS_DONE && !yielded));
         if (last || (parked == 0 && runnable == 0)) break;
         passes += made;
+        // (Serving a parked table at once while only 1 / 2 / 4 / 8 tables of the wave are still inside their env step, instead of waiting
+        //  for the others to park too: 0.2367 / 0.2375 / 0.2374 / 0.236 G against 0.2383 G -- the wait is free, the wave is busy with the
+        //  others' passes anyway, and merged end_blocks are fewer end_blocks.  docs/history.md section 12.)
         if (parked >= park || runnable == 0) {
             tb.template end_block<false, !ASYNC>(H, t, table_id, lds, false);   // the side-pot loop runs to its end inside the call (the step's tail is a few lanes); lone-table paths: synchronous only
             retire();
