@@ -23,9 +23,12 @@ hands.free()
 repeated = distinct.copy()
 sel = rng.random(m) < 0.35
 repeated[sel, 1] = repeated[sel, 0]                                   # 35 % of the hands repeat a card (the reference's tests do)
-for name, cards, ncards in (("7 distinct cards", distinct, None),
-                            ("2/5/6/7 distinct cards, mixed in the batch", distinct, rng.choice(np.array([2, 5, 6, 7], np.uint8), m)),
-                            ("7 cards, 35 % of the hands with a repeated card", repeated, None)):
+CASES = (("7 distinct cards", distinct, None),
+         ("2/5/6/7 distinct cards, mixed in the batch", distinct, rng.choice(np.array([2, 5, 6, 7], np.uint8), m)),
+         ("7 cards, 35 % of the hands with a repeated card", repeated, None))
+if os.environ.get("PK_EHB_CASE"):          # one case only (tools/profile_eval_hands.sh profiles them one by one)
+    CASES = (CASES[int(os.environ["PK_EHB_CASE"])],)
+for name, cards, ncards in CASES:
     d_c, d_n, d_r, d_k, d_nk = DeviceBuffer(m * 7), DeviceBuffer(m), DeviceBuffer(m), DeviceBuffer(m * 4), DeviceBuffer(m)
     d_c.upload(cards)
     if ncards is not None:

@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""One-off confidence run (GPU box): Game.step with the caller's actions on DEVICE buffers -- pk_pick_actions_d + pk_step_auto_d
+(the reset of a finished game inside the step's launch) and, on a twin handle, pk_step_d + pk_reset_d(flags, GAME_OVER) -- against
+the CPU oracle's step + reset over seeded odd configurations (every N, zero / fractional / oversized blinds, per-seat stacks
+0.5 .. 1e6, any table-id base and dealer, batches from 65 to 4 097 tables: full and nearly empty waves).  This is the path on which a
+step that rolls hand after hand is served by end_block's single-table paths (lone showdown, deck stock).
+usage: python tools/fuzz_step_d.py [configs] [seed]"""
+import os
+import random
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np  # noqa: E402
+import golden_util as GU  # noqa: E402
+from hip_backend import HipBackend as HB  # noqa: E402
+from oracle import loader as O  # noqa: E402
+from pokerl_amd import _lib as L  # noqa: E402
+from pokerl_amd.hipmem import DeviceBuffer  # noqa: E402
+
+n_cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 150
+rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 2027)
+stacks = [0.5, 1, 2, 3, 5, 10, 37.5, 100, 1000, 1e6]
+blinds = [0, 0.25, 0.5, 1, 2, 3, 7.5, 40]
+
+
+def same(a, b, where):
+    for k in GU.SNAP_FIELDS:
+        assert GU.bits_equal(a[k], b[k]), (where, k)
+
+
+steps = resets = 0
+for i in range(n_cfg):
+    N = 2 + i % 15
+    start = [rng.choice(stacks) for _ in range(N)] if rng.random() < 0.5 else rng.choice(stacks)
+    bb, sb = rng.choice(blinds), rng.choice(blinds)
+    policy = 1 if rng.random() < 0.25 else 0
+    seed, base, dealer = rng.getrandbits(63), rng.getrandbits(32) & 0xFFFFF000, rng.randrange(N)
+    T = rng.choice([65, 128, 300, 1000, 4097])
+    K = rng.choice([40, 90, 200])
+    probe = O.OracleGame(16, N, start, bb, sb, seed=seed, table_id_base=base)
+    probe.reset()
+    t_probe = time.time()
+    probe.rollout(K, policy, True)
+    if (time.time() - t_probe) * T / 16 > 20:        # blinds far above the stacks: steps that roll thousands of hands
+        T = 65
+    where = "cfg %d: T=%d N=%d start=%s bb=%s sb=%s policy=%d K=%d" % (i, T, N, start, bb, sb, policy, K)
+    o = O.OracleGame(T, N, start, bb, sb, seed=seed, table_id_base=base)
+    ha, hb = HB(T, N, start, bb, sb, seed=seed, table_id_base=base), HB(T, N, start, bb, sb, seed=seed, table_id_base=base)
+    o.reset(); ha.reset(); hb.reset()                 # (pk_step_auto_d resets with dealer 0, as Game.reset() does)
+    bufs = [DeviceBuffer(T * 4), DeviceBuffer(T), DeviceBuffer(T), DeviceBuffer(T * 4), DeviceBuffer(T), DeviceBuffer(T)]
+    act_a, fl_a, te_a, act_b, fl_b, te_b = bufs
+    for s in range(K):
+        a = o.pick_actions(policy)
+        fo, eo = o.step(a)
+        over = ((fo & 1) | ((eo & 4) >> 2)).astype(np.uint8)
+        ha.g.pick_actions_d(act_a, policy); ha.g.step_d(act_a, fl_a, te_a, auto_reset=True)
+        hb.g.pick_actions_d(act_b, policy); hb.g.step_d(act_b, fl_b, te_b)
+        ha.g.sync(); hb.g.sync()
+        assert np.array_equal(act_a.download(np.int32, T), a) and np.array_equal(act_b.download(np.int32, T), a), (where, s)
+        fa, ea = fl_a.download(np.uint8, T), te_a.download(np.uint8, T)
+        fb, eb = fl_b.download(np.uint8, T), te_b.download(np.uint8, T)
+        assert np.array_equal(fb, fo) and np.array_equal(eb, eo), (where, s)
+        assert np.array_equal(fa & 6, fo & 6) and np.array_equal(fa & 1, over) and np.array_equal(ea, eo), (where, s)
+        hb.g.reset_d(fl_b, L.FLAG_GAME_OVER)
+        if (eo & 4).any():
+            hb.g.reset_d(te_b, L.TERR_HAND_CAP)
+        if (eo & 2).any():                            # the reference's assertion (game.py:473): the table stays as it is; reset it everywhere
+            m = ((eo & 2) != 0).astype(np.uint8)
+            o.reset(mask=m); ha.reset(mask=m); hb.reset(mask=m)
+        if over.any():
+            o.reset(mask=over)
+            resets += int(over.sum())
+        if s % 40 == 39 or s == K - 1:
+            snap = o.snapshot()
+            same(snap, ha.snapshot(), where + " step %d (auto)" % s)
+            same(snap, hb.snapshot(), where + " step %d (step_d + reset_d)" % s)
+    steps += 2 * T * K
+    for b in bufs:
+        b.free()
+    ha.g.close(); hb.g.close()
+    if i % 25 == 24:
+        print("%d configurations bit-exact so far" % (i + 1), flush=True)
+print("fuzz: %d configurations, %d device-resident Game.steps, %d games reset inside a step's launch, all bit-exact vs the oracle" % (n_cfg, steps, resets))
