@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""The loop of the reference's examples/random_game.py with the CALLER's policy and every buffer in HBM: observation rows and valid
+masks are read on the device, a (toy) policy kernel would write actions_d, Game.step runs on the device buffers and finished games
+restart inside the step's launch (pk_step_auto_d).  Here the "policy" is the library's own in-kernel pick written to actions_d
+(pk_pick_actions_d) -- replace it with your network; a torch user passes tensor.data_ptr() instead of DeviceBuffer.
+
+    python examples/device_game_loop.py [tables=65536] [steps=2000]
+"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+import pokerl_amd  # noqa: E402
+from pokerl_amd import _lib as L  # noqa: E402
+from pokerl_amd.hipmem import DeviceBuffer  # noqa: E402
+
+T = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
+N = 6
+game = pokerl_amd.VecGame(T, num_players=N)
+game.reset()
+actions, flags, terr = DeviceBuffer(T * 4), DeviceBuffer(T), DeviceBuffer(T)
+obs = DeviceBuffer(T * (17 + 3 * N) * 8)                       # dense StateView rows of the player to act, if the policy wants them
+
+games = 0
+t0 = time.perf_counter()
+for s in range(steps):
+    # L.lib().pk_get_obs_d(game._h, -1, obs.ptr)               # <- what a network would read (asynchronous on the handle's stream)
+    game.pick_actions_d(actions, pokerl_amd.Policy.RANDOM)     # <- your policy kernel goes here: int32[T], valid for each active player
+    game.step_d(actions, flags, terr, auto_reset=True)         # Game.step on every table; a finished game is Game.reset() on the spot
+    if s % 500 == 499:                                         # looking at the flags is a host round trip: do it rarely
+        game.sync()
+        games += int((flags.download(np.uint8, T) & L.FLAG_GAME_OVER).sum())
+game.sync()
+dt = time.perf_counter() - t0
+assert not (terr.download(np.uint8, T) & L.TERR_INVALID_ACTION).any()
+print("%d tables x %d device-resident Game.steps in %.3f s = %.2f G steps/s (%.1f us per step of the whole batch); "
+      "%d games ended in the sampled steps; mean pot now %.2f" % (T, steps, dt, T * steps / dt / 1e9, dt / steps * 1e6, games, game.pot.mean()))
+for b in (actions, flags, terr, obs):
+    b.free()
+game.close()
