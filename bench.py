@@ -624,12 +624,14 @@ def _leg(out, name, fn):
 
 
 
-def step_workload(ctx, device, tables, players, steps=400, warmup=100, replay=False, fused_reset=True):
+def step_workload(ctx, device, tables, players, steps=400, warmup=100, replay=False, fused_reset=True, async_hands=0):
     """`Game.step` with CALLER-SUPPLIED actions on device buffers (reference pokerl/game.py:621-700) as the device-resident loop of
     examples/random_game.py:8-12: pick (pk_pick_actions_d) + step with the reset of a finished game in the same launch
     (pk_step_auto_d) -- two launches per step, the table state round-trips HBM in each; fused_reset=False: pk_step_d + pk_reset_d on
     the step's own flags, three launches.  replay: the actions a first pass recorded are replayed, so that the timed loop is the
-    step kernel alone.  HIP events on the handle's stream around the timed steps; the serials prove the steps were made."""
+    step kernel alone.  async_hands > 0: pk_step_async_d with that budget of hand ends per launch -- a table whose step rolls on through
+    further hands stays in flight and the loop acts on the tables that are ready; the value counts DELIVERED steps (ready flags of the timed
+    launches).  HIP events on the handle's stream around the timed steps; the serials prove the steps were made."""
     import ctypes as C
     import numpy as np
     import pokerl_amd
@@ -640,7 +642,9 @@ def step_workload(ctx, device, tables, players, steps=400, warmup=100, replay=Fa
     flags, terr = DeviceBuffer(T, device), DeviceBuffer(T, device)
     total = warmup + steps
     rec = DeviceBuffer(T * 4 * (total if replay else 1), device)
+    ready = DeviceBuffer(T * (steps + 1), device) if async_hands > 0 else None     # one slice per timed launch (slice 0: warm-up)
     ev0, ev1 = DeviceEvent(), DeviceEvent()
+    assert not (async_hands > 0 and (replay or not fused_reset)), "the asynchronous leg picks on the device and resets inside the launch"
 
     def act(s):
         return C.c_void_p(rec.ptr.value + (s * T * 4 if replay else 0))
@@ -649,16 +653,24 @@ def step_workload(ctx, device, tables, players, steps=400, warmup=100, replay=Fa
         for s in range(lo, hi):
             if pick:
                 g.pick_actions_d(act(s), 0)
+            if async_hands > 0:
+                g.step_async_d(act(s), flags, terr, C.c_void_p(ready.ptr.value + (s - warmup + 1 if s >= warmup else 0) * T), async_hands, True)
+                continue
             g.step_d(act(s), flags, terr, auto_reset=fused_reset)
             if not fused_reset:
                 g.reset_d(flags, L.FLAG_GAME_OVER)
+
+    def drain():
+        if async_hands > 0:
+            g.pick_actions_d(act(0), 0)
+            g.step_async_d(act(0), flags, terr, ready, 0, True)
 
     if replay:                       # record the action of every step, then start over on the same RNG streams
         g.reset(); loop(0, total, True); g.sync()
         g.set_serials(0, 0)
     g.reset()
     loop(0, warmup, not replay)
-    g.sync()
+    drain(); g.sync()
     s0 = int(g.step_serial.sum())
     ctx.barrier()
     g.record_event(ev0.handle)
@@ -668,17 +680,27 @@ def step_workload(ctx, device, tables, players, steps=400, warmup=100, replay=Fa
     g.sync(); ctx.barrier()
     dt = time.perf_counter() - t0
     dev_ms = DeviceEvent.elapsed_ms(ev0, ev1)
+    delivered = None
+    if async_hands > 0:     # delivered steps = the ready flags of the timed launches; then finish what is in flight so that the tables can be read
+        delivered = int(ready.download(np.uint8, T * steps, T).sum(dtype=np.int64))
+        drain(); g.sync()
     made = int(g.step_serial.sum()) - s0
     bad = int((terr.download(np.uint8, T) != 0).sum())
     g.close()
-    for b in (flags, terr, rec):
-        b.free()
-    assert made >= 0.999 * T * steps, (made, T * steps, bad)   # every table made every step (a PK_TERR_NO_WINNER step would not count)
-    return dict(tables=T, players=players, steps=steps, warmup=warmup, replay=replay, seconds=dt, device_ms=dev_ms, game_steps=made,
+    for b in (flags, terr, rec, ready):
+        if b is not None:
+            b.free()
+    if async_hands > 0:     # (every delivered step was made; the drain's pick + step adds up to one more per table)
+        assert 0.95 * T * steps <= delivered <= made <= delivered + 2 * T, (delivered, made, T * steps)
+    else:
+        assert made >= 0.999 * T * steps, (made, T * steps, bad)   # every table made every step (a PK_TERR_NO_WINNER step would not count)
+    return dict(tables=T, players=players, steps=steps, warmup=warmup, replay=replay, seconds=dt, device_ms=dev_ms,
+                game_steps=delivered if delivered is not None else made, async_hands=async_hands,
+                ready_fraction_per_launch=(delivered / float(T * steps)) if delivered is not None else 1.0,
                 tables_with_error_bits=bad, fused_reset=fused_reset, launches_per_step=(1 if replay else 2) + (0 if fused_reset else 1))
 
 
-def step_profile_summary(tables, players):
+def step_profile_summary(tables, players, bounded=False):
     """The committed rocprofv3 summary of the Game.step loop (profiles/rNN_step_*_summary.json: kernel trace + PMC passes of
     tools/profile_step.sh), latest round; None if none."""
     import glob
@@ -689,7 +711,7 @@ def step_profile_summary(tables, players):
         except Exception:
             continue
         w = d.get("workload", {})
-        if (w.get("tables"), w.get("players")) == (tables, players):
+        if (w.get("tables"), w.get("players"), bool(w.get("bounded", False))) == (tables, players, bool(bounded)):
             best = (d, os.path.basename(f))
     return best
 
@@ -703,21 +725,21 @@ def step_line(res, name):
     alg = b_step(N) * res["game_steps"] / res["steps"]           # algorithmic bytes of one step of the whole batch
     gbs = alg / (ms_step * 1e-3) / 1e9
     roof = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
-            "kernel": " + ".join(([] if res["replay"] else ["k_pick"]) + ["k_step"] + ([] if res["fused_reset"] else ["k_reset(masked)"])),
+            "kernel": " + ".join(([] if res["replay"] else ["k_pick"]) + ["k_step_async" if res.get("async_hands") else "k_step"] + ([] if res["fused_reset"] else ["k_reset(masked)"])),
             "kernel_ms": ms_step, "launches_timed": res["steps"] * res["launches_per_step"], "algorithmic_bytes_per_step": alg,
             "kernel_ms_source": "HIP events (pk_record_event) around the timed steps on the handle's stream / steps: ALL launches of one "
                                 "loop iteration, launch gaps included"}
-    prof = step_profile_summary(T, N)
+    prof = step_profile_summary(T, N, bool(res.get("async_hands")))
     if prof:
         d, src = prof
         mine = [k for k in d.get("loop_kernels", d.get("kernels", {})) if not (res["replay"] and k == "k_pick") and not (res["fused_reset"] and k == "k_reset")]   # the kernels of THIS leg's loop iteration
         roof.update({"traffic": sum(d["kernels"][k].get("hbm_traffic_bytes_per_launch", 0.0) for k in mine), "source": src,
-                     "k_step_ms_rocprof": d.get("k_step_avg_ms"), "kernels_in_traffic": mine,
+                     "k_step_ms_rocprof": d.get("k_step_avg_ms"), "k_step_ms_rocprof_min_median_max": d.get("k_step_min_median_max_ms"), "kernels_in_traffic": mine,
                      "traffic_unit": "HBM bytes per loop iteration (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE, KiB), summed over its kernels"})
     return {"name": name, "metric": "Game.step env-steps/s (caller-supplied actions, device-resident)", "value": rate, "unit": "env-steps/s",
             "ms_per_step": res["seconds"] / res["steps"] * 1e3, "kernel": roof["kernel"], "kernel_ms": ms_step,
             "launches": res["steps"] * res["launches_per_step"], "device_ms": res["device_ms"], "seconds": res["seconds"],
-            "tables_with_error_bits": res["tables_with_error_bits"], "roofline": roof}
+            "tables_with_error_bits": res["tables_with_error_bits"], "ready_fraction_per_launch": res.get("ready_fraction_per_launch", 1.0), "roofline": roof}
 
 
 # ---------------------------------------------------------------------------------------------- the ONE stdout line
@@ -837,6 +859,11 @@ def extra_workloads(ctx, device):
     _leg(out, "Game.step replay", lambda: step_line(step_workload(ctx, device, 65536, 6, steps=2000, warmup=200, replay=True),
                                                     "Game.step, pk_step_auto_d alone on pre-picked (replayed) actions, 65 536 x 6")
          | {"short": "Game.step step_auto_d replay 65536x6"})
+    # ... as bounded launches (pk_step_async_d): the few tables whose step rolls on through further hands stay in flight instead of
+    # holding the launch; the loop acts on the tables that are ready, the value counts delivered steps
+    _leg(out, "Game.step async", lambda: step_line(step_workload(ctx, device, 65536, 6, steps=2000, warmup=200, async_hands=1),
+                                                   "Game.step, bounded launches: pk_pick_actions_d + pk_step_async_d (one hand end per launch, reset inside), 65 536 x 6")
+         | {"short": "Game.step pick+step_async_d 65536x6"})
     # ... and at a batch that fills the chip: there the bytes, not the slowest table's serial chain, bound the launch
     _leg(out, "Game.step 1M", lambda: step_line(step_workload(ctx, device, 1048576, 6, steps=300, warmup=50, replay=True),
                                                 "Game.step, pk_step_auto_d alone on pre-picked (replayed) actions, 1 048 576 x 6")
@@ -869,6 +896,7 @@ def main():
     ap.add_argument("--mode", choices=["game", "env", "step"], default="game")
     ap.add_argument("--step-replay", action="store_true", help="--mode step: the step kernel alone on replayed (pre-picked) actions")
     ap.add_argument("--step-unfused-reset", action="store_true", help="--mode step: pk_step_d + pk_reset_d(flags) instead of pk_step_auto_d")
+    ap.add_argument("--step-async", type=int, default=0, metavar="HANDS", help="--mode step through pk_step_async_d with this budget of hand ends per launch")
     ap.add_argument("--env-batches", type=int, default=1, help="--mode env: independent batches in flight, one stream each")
     ap.add_argument("--env-async", type=int, default=0, metavar="PASSES",
                     help="--mode env through pk_env_step_async_d with this pass budget per launch (0: synchronous)")
@@ -897,9 +925,10 @@ def main():
         ctx.close()
         return
     if args.mode == "step":   # Game.step with caller-supplied actions as its own line (tools/profile_step.sh profiles this command)
-        res = step_workload(ctx, device, args.tables, args.players, args.steps, args.warmup, args.step_replay, not args.step_unfused_reset)
+        res = step_workload(ctx, device, args.tables, args.players, args.steps, args.warmup, args.step_replay, not args.step_unfused_reset, args.step_async)
         if ctx.rank == 0:
-            print(json.dumps(step_line(res, "Game.step device-resident loop, %d x %d%s" % (args.tables, args.players, ", replayed actions" if args.step_replay else ""))))
+            print(json.dumps(step_line(res, "Game.step device-resident loop, %d x %d%s%s" % (args.tables, args.players, ", replayed actions" if args.step_replay else "",
+                                                                                              ", bounded launches (%d hand end(s) each)" % args.step_async if args.step_async else ""))))
         ctx.close()
         return
     policy = 0 if args.policy == "random" else 1

@@ -144,6 +144,20 @@ int pk_step_d(pk_handle *h, const int32_t *actions_d, uint8_t *flags_d, uint8_t 
  * as pk_rollout's auto_reset does; flags_d[t] still reports PK_FLAG_GAME_OVER and terr_d[t] the error bits of the step that ended it.
  * Saves the pk_reset_d launch of the loop (a launch costs ~4 us of a ~25 us step at 65 536 tables). */
 int pk_step_auto_d(pk_handle *h, const int32_t *actions_d, uint8_t *flags_d, uint8_t *terr_d);
+/* Game.step as a BOUNDED launch, for callers that act on whichever tables are ready (the pk_env_step_async_d idea applied to Game.step).
+ * The reference's next_player loop plays whole hands in which nobody can act (pokerl/game.py:607-611), so ONE step can roll through
+ * several hands: about one table in 10 000 per step does -- but among 65 536 tables the slowest needs ~4 hands, each ~3 us of serial work,
+ * and a synchronous step launch (pk_step_d: ~20 us) lasts as long as that one table.  Here a launch serves at most max_hands end_hand
+ * rounds (1: every table's step up to its first hand end): a table whose step has returned gets ready_d[t] = 1 and its flags_d / terr_d
+ * written; a table whose step rolls on gets ready_d[t] = 0, its outputs are left untouched and the step stays IN FLIGHT on the device --
+ * the next call carries on with it and IGNORES actions_d[t].  An invalid action returns at once (ready, PK_TERR_INVALID_ACTION, table
+ * untouched).  auto_reset != 0: as pk_step_auto_d.  Per table the sequence of steps, flags and RNG draws is exactly the synchronous one;
+ * only the call that delivers them differs.  max_hands <= 0: run every step to its end (every table ready) -- which also ends the state in
+ * which every other entry point that reads or changes tables returns PK_E_BUSY (pk_sync only waits) -- EXCEPT the device-resident readers a
+ * caller needs to act on the ready tables: pk_pick_actions_d, pk_get_obs_d, pk_get_obs_packed_d, pk_get_valid_actions_d, pk_get_f64_d (their
+ * rows for a table in flight show that table in the middle of its step: ignore them).  auto_reset must not change while
+ * steps are in flight (PK_E_INVALID_ARG).  A step that has already rolled 16 hands is carried to its end whatever the budget. */
+int pk_step_async_d(pk_handle *h, const int32_t *actions_d, uint8_t *flags_d, uint8_t *terr_d, uint8_t *ready_d, int max_hands, int auto_reset);
 
 /* Game.get_valid_actions(player), pokerl/game.py:339-383: out[T][7] one-hot bytes.  player < 0: each table's active
  * player (the reference's `player=None`); 0 <= player < N: that seat on every table. */

@@ -31,7 +31,7 @@ SYMBOLS = ["pk_abi_version", "pk_device_count", "pk_last_error", "pk_create", "p
            "pk_pick_actions_d", "pk_flush", "pk_get_owed", "pk_env_step_fused_d", "pk_env_step_async_d", "pk_set_tuning", "pk_get_stream", "pk_set_stream", "pk_wait_event",
            "pk_record_event", "pk_use_own_stream", "pk_set_coalesce", "pk_get_launch_stats", "pk_env_step_multi_d", "pk_env_end_multi_d", "pk_get_f64_d", "pk_set_env_batches", "pk_env_last_range",
            "pk_get_obs_packed", "pk_get_obs_packed_d", "pk_set_env_obs_packed", "pk_host_alloc", "pk_host_free", "pk_check_actions",
-           "pk_env_step_begin", "pk_env_step_end", "pk_reset_d", "pk_step_auto_d", "pk_stream_pool_drain"]
+           "pk_env_step_begin", "pk_env_step_end", "pk_reset_d", "pk_step_auto_d", "pk_stream_pool_drain", "pk_step_async_d"]
 
 
 class PokerlHipError(RuntimeError):
@@ -65,6 +65,7 @@ def lib():
     L.pk_step.argtypes = [_vp, _vp, _vp, _vp]
     L.pk_step_d.argtypes = [_vp, _vp, _vp, _vp]
     L.pk_step_auto_d.argtypes = [_vp, _vp, _vp, _vp]
+    L.pk_step_async_d.argtypes = [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int]
     L.pk_get_valid_actions.argtypes = [_vp, C.c_int, _vp]
     L.pk_get_f64.argtypes = [_vp, C.c_int, _vp]
     L.pk_get_f64_d.argtypes = [_vp, C.c_int, _vp]

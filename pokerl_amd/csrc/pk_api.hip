@@ -62,6 +62,8 @@ struct pk_handle {
     // PokerGameEnv.steps left in flight by pk_env_step_async_d (State::env_ctx): every other entry point that touches
     // table state refuses to run until a draining call (max_passes <= 0) has completed them.
     bool env_pending = false;
+    bool step_pending = false;   // Game.steps left in flight by pk_step_async_d (their machine state is in the tables' cursor bits): as env_pending
+    int step_auto = 0;
     bool host_step = false;   // between pk_env_step_begin and pk_env_step_end: the caller's host buffers are the targets of queued copies
     hipStream_t stream = nullptr, own_stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -231,8 +233,10 @@ static int launch_coalesced(pk_handle *h, int policy, int auto_reset) {
     h->ev_idx ^= 1;
     return PK_OK;
 }
-static inline bool in_flight(const pk_handle *h) { return h->env_pending || h->host_step; }
+static inline bool in_flight(const pk_handle *h) { return h->env_pending || h->host_step || h->step_pending; }
 static int flush(pk_handle *h) {
+    if (h->step_pending)
+        return h->fail(PK_E_BUSY, "Game.steps are in flight (pk_step_async_d): drain them with max_hands = 0 first");
     if (h->host_step)
         return h->fail(PK_E_BUSY, "a pk_env_step_begin is waiting for its pk_env_step_end: the copies into the caller's buffers are still queued");
     if (h->env_pending)
@@ -244,6 +248,18 @@ static int flush(pk_handle *h) {
     do {                           \
         int rc_ = flush(h);        \
         if (rc_) return rc_;       \
+    } while (0)
+// The device-resident READERS (pk_pick_actions_d, pk_get_obs_d, pk_get_obs_packed_d, pk_get_valid_actions_d, pk_get_f64_d) also work while
+// Game.steps are in flight (pk_step_async_d): a caller needs them to act on the tables that are ready.  What they return for a table whose
+// step is still in flight is that table in the middle of its step -- ready_d says which rows to ignore.
+static int flush_reader(pk_handle *h) {
+    if (h->step_pending && !h->env_pending && !h->host_step) return PK_OK;
+    return flush(h);
+}
+#define FLUSH_READER(h)                \
+    do {                               \
+        int rc_ = flush_reader(h);     \
+        if (rc_) return rc_;           \
     } while (0)
 
 template <typename F>
@@ -614,7 +630,7 @@ int pk_reset_d(pk_handle *h, const uint8_t *mask_d, int mask_bits, int dealer) {
 static int launch_step(pk_handle *h, const int32_t *actions_d, uint8_t *flags_d, uint8_t *terr_d, int auto_reset) {
     ON_DEVICE(h);
     FLUSH(h);
-    const StepKernArgs ka{(const State *)h->d_S, h->hot, actions_d, flags_d, terr_d, scaled_park(h, 28), auto_reset ? 1 : 0};
+    const StepKernArgs ka{(const State *)h->d_S, h->hot, actions_d, flags_d, terr_d, scaled_park(h, 28), auto_reset ? 1 : 0, nullptr, 0};
     DISPATCH_N(h, k_step, table_grid(h), ka);
     HIPCHK(h, hipGetLastError());
     return PK_OK;
@@ -626,6 +642,21 @@ int pk_step_d(pk_handle *h, const int32_t *actions_d, uint8_t *flags_d, uint8_t 
 int pk_step_auto_d(pk_handle *h, const int32_t *actions_d, uint8_t *flags_d, uint8_t *terr_d) {
     if (!h || !actions_d || !flags_d) return h ? h->fail(PK_E_INVALID_ARG, "pk_step_auto_d: NULL buffer") : PK_E_INVALID_ARG;
     return launch_step(h, actions_d, flags_d, terr_d, 1);
+}
+int pk_step_async_d(pk_handle *h, const int32_t *actions_d, uint8_t *flags_d, uint8_t *terr_d, uint8_t *ready_d, int max_hands, int auto_reset) {
+    if (!h || !actions_d || !flags_d || !ready_d) return h ? h->fail(PK_E_INVALID_ARG, "pk_step_async_d: NULL buffer") : PK_E_INVALID_ARG;
+    ON_DEVICE(h);
+    if (h->step_pending) {
+        if ((auto_reset ? 1 : 0) != h->step_auto)   // steps in flight keep the reset rule they were started with
+            return h->fail(PK_E_INVALID_ARG, "pk_step_async_d: Game.steps are in flight with another auto_reset; drain them first (max_hands = 0)");
+        if (h->env_pending || h->host_step) return flush(h);
+    } else FLUSH(h);
+    const StepKernArgs ka{(const State *)h->d_S, h->hot, actions_d, flags_d, terr_d, scaled_park(h, 28), auto_reset ? 1 : 0, ready_d, max_hands > 0 ? max_hands : 0};
+    DISPATCH_N(h, k_step_async, table_grid(h), ka);
+    HIPCHK(h, hipGetLastError());
+    h->step_pending = max_hands > 0;
+    h->step_auto = auto_reset ? 1 : 0;
+    return PK_OK;
 }
 
 static int any_terr(const uint8_t *terr, int T) {
@@ -670,7 +701,7 @@ int pk_get_f64(pk_handle *h, int field, double *out) {
 int pk_get_f64_d(pk_handle *h, int field, double *out_d) {
     if (!h || !out_d || field < 0 || field > 3) return h ? h->fail(PK_E_INVALID_ARG, "pk_get_f64_d: bad argument") : PK_E_INVALID_ARG;
     ON_DEVICE(h);
-    FLUSH(h);
+    FLUSH_READER(h);
     const double *src = field == PK_F_CREDITS ? h->S.credits : field == PK_F_BETS ? h->S.bets : field == PK_F_PENDING_BETS ? h->S.pending : h->S.payoffs;
     size_t n = (size_t)h->T * h->N;
     hipLaunchKernelGGL(k_export_f64, dim3(flat_grid(n)), dim3(256), 0, h->stream, src, h->T, h->N, out_d);
@@ -765,7 +796,7 @@ int pk_get_obs(pk_handle *h, int player, double *out) {
 int pk_get_obs_d(pk_handle *h, int player, double *out_d) {
     if (!h || !out_d || bad_player(h, player)) return h ? h->fail(PK_E_INVALID_ARG, "pk_get_obs_d: bad argument") : PK_E_INVALID_ARG;
     ON_DEVICE(h);
-    FLUSH(h);
+    FLUSH_READER(h);
     hipLaunchKernelGGL(k_obs, dim3(flat_grid(h->T)), dim3(256), 0, h->stream, h->S, h->N, player, out_d);
     HIPCHK(h, hipGetLastError());
     return PK_OK;
@@ -782,7 +813,7 @@ int pk_get_obs_packed(pk_handle *h, int player, uint8_t *out) {
 int pk_get_obs_packed_d(pk_handle *h, int player, uint8_t *out_d) {
     if (!h || !out_d || bad_player(h, player) || ((uintptr_t)out_d & 7)) return h ? h->fail(PK_E_INVALID_ARG, "pk_get_obs_packed_d: bad argument (out_d must be 8-byte aligned)") : PK_E_INVALID_ARG;
     ON_DEVICE(h);
-    FLUSH(h);
+    FLUSH_READER(h);
     hipLaunchKernelGGL(k_obs_packed, dim3(flat_grid(h->T)), dim3(256), 0, h->stream, h->S, h->N, player, out_d);
     HIPCHK(h, hipGetLastError());
     return PK_OK;
@@ -833,7 +864,7 @@ int pk_check_actions(pk_handle *h, const int32_t *actions, int32_t *first_bad) {
 int pk_get_valid_actions_d(pk_handle *h, int player, uint8_t *out_d) {
     if (!h || !out_d || bad_player(h, player)) return h ? h->fail(PK_E_INVALID_ARG, "pk_get_valid_actions_d: bad argument") : PK_E_INVALID_ARG;
     ON_DEVICE(h);
-    FLUSH(h);
+    FLUSH_READER(h);
     size_t n = (size_t)h->T * PK_NUM_MOVES;
     hipLaunchKernelGGL(k_export_valid, dim3(flat_grid(n)), dim3(256), 0, h->stream, h->S, h->N, player, out_d);
     HIPCHK(h, hipGetLastError());
@@ -1030,7 +1061,7 @@ int pk_env_end_multi_d(pk_handle *h) {
 int pk_pick_actions_d(pk_handle *h, int policy, int32_t *actions_d) {
     if (!h || !actions_d || bad_policy(policy)) return h ? h->fail(PK_E_INVALID_ARG, "pk_pick_actions_d: bad argument") : PK_E_INVALID_ARG;
     ON_DEVICE(h);
-    FLUSH(h);
+    FLUSH_READER(h);
     DISPATCH_N(h, k_pick, table_grid(h), h->S, h->hot, policy, actions_d);
     HIPCHK(h, hipGetLastError());
     return PK_OK;

@@ -107,8 +107,16 @@ __global__ void __launch_bounds__(PK_TABLE_BLOCK) k_pick(State S, Hot H, int pol
 // would run empty).
 // k_step's formal parameter = the layout of its kernarg segment: the two output pointers are read through the kernarg
 // segment pointer after the loop (see EnvArgs below for why).
-struct StepKernArgs { const State *Sp; Hot H; const int32_t *actions; uint8_t *flags, *terr; int park, auto_reset; };
-template <int N, bool ONE_PASS, int POLICY, int PASSES = 0>
+struct StepKernArgs { const State *Sp; Hot H; const int32_t *actions; uint8_t *flags, *terr; int park, auto_reset; uint8_t *ready; int max_end; };
+// BOUNDED (pk_step_async_d, only with the external policy): a launch runs at most `max_end` end_blocks.  A Game.step that rolls on through
+// further hands (the reference's next_player loop plays whole hands nobody can act in, game.py:607-611: ~1 table in 10 000 per step, yet
+// the SLOWEST table of 65 536 needs ~4 hands and every end_hand is ~3 us of serial work) stays IN FLIGHT -- its machine state is in the
+// table's cursor bits and State::mid, as for a deferred rollout launch -- and the next launch carries on with it, ignoring actions[t];
+// ready[t] says whose step has returned.  Per table the sequence of steps, flags and RNG draws is the synchronous one.
+#ifndef PK_STEP_ROLLING
+#define PK_STEP_ROLLING 16   // hands rolled inside one Game.step from which a bounded launch carries that step to its end (as PK_ENV_ROLLING)
+#endif
+template <int N, bool ONE_PASS, int POLICY, int PASSES = 0, bool BOUNDED = false>
 __device__ __forceinline__ void rollout_body(const State *__restrict__ Sp, const Hot &H, int K, int auto_reset, int park, int slack, int clear_terr,
                                              const int32_t *actions = nullptr, const StepKernArgs *ext = nullptr) {
     // Array bases by pointer (loaded only where the table is loaded / stored), loop scalars by value: see pk::Hot.
@@ -131,13 +139,16 @@ __device__ __forceinline__ void rollout_body(const State *__restrict__ Sp, const
     double high_bet;
     int ext_action = -1;
     bool ext_ok = true;
+    static_assert(!BOUNDED || POLICY == PK_POLICY_EXTERNAL, "bounded launches are pk_step_async_d's");
     if (EXTERNAL) {                                                                // game.py:648-651
         const uint32_t vm = tb.valid_mask(high_bet);
         ext_action = live ? as_global(actions)[t] : -1;
-        ext_ok = live && ext_action >= 0 && ext_action < PK_NUM_MOVES && ((vm >> ext_action) & 1);
+        const bool carried = BOUNDED && live && tb.stepped;                        // a step of an earlier launch is in flight: its action was taken then
+        ext_ok = carried || (live && ext_action >= 0 && ext_action < PK_NUM_MOVES && ((vm >> ext_action) & 1));
         owed = ext_ok ? 1u : 0u;                                                   // (the host has flushed: nothing was owed)
         alive = ext_ok;
     }
+    int nend = 0;
     uint32_t late = (live ? 1u : 0u) | (ext_ok ? 2u : 0u);   // the epilogue's lane predicates travel through the loop in ONE VGPR
     if (EXTERNAL) asm volatile("" : "+v"(late));               // (as lane masks: an SGPR pair each, live across the loop; see env_step_body)
     // lanes that can work at all in this launch; the launch ends once more than `slack` of them have run out of work
@@ -200,6 +211,10 @@ __device__ __forceinline__ void rollout_body(const State *__restrict__ Sp, const
         const int runnable = __popcll(__ballot(alive && tb.lstate == LS_DONE && owed > 0));
         if (parked + runnable < quit) break;
         if (parked >= park || runnable == 0) {
+            if constexpr (BOUNDED) {   // the budget is used up: what is parked stays in flight -- unless a step is rolling hand after hand
+                if (ext->max_end > 0 && nend >= ext->max_end && !__any(tb.stepped && tb.hands_this_step >= PK_STEP_ROLLING)) break;
+                ++nend;
+            }
             tb.template end_block<ONE_PASS>(H, t, table_id, lds, auto_reset != 0);
             retire();
         }
@@ -213,16 +228,20 @@ __device__ __forceinline__ void rollout_body(const State *__restrict__ Sp, const
         const bool ext_ok_l = late & 2u;
         if (late & 1u) {
             const auto flags_out = as_global(ext->flags), terr_out = as_global(ext->terr);
+            const bool returned = !BOUNDED || !ext_ok_l || tb.lstate == LS_DONE;   // (an invalid action returns at once, table untouched)
             if (ext_ok_l) {
-                tb.template store<PAY>(S, t);
+                tb.template store<PAY>(S, t);                                      // (a step in flight: with its machine state in the cursor bits)
                 tb.store_show(S.show, S.T, t, lds);
-                as_global(S.mid)[t] = 0;
-                as_global(S.valid)[t] = (uint8_t)tb.valid_mask(high_bet);
+                as_global(S.mid)[t] = returned ? 0u : (uint32_t)tb.hands_this_step;
+                if (returned) as_global(S.valid)[t] = (uint8_t)tb.valid_mask(high_bet);
             }
-            const uint8_t te = ext_ok_l ? (uint8_t)(tb.terr | tb.seen) : (uint8_t)PK_TERR_INVALID_ACTION;   // (seen: the error bits of a table pk_step_auto_d reset on the spot)
-            flags_out[t] = ext_ok_l ? (uint8_t)tb.flags : (uint8_t)0;              // :649-651: no mutation
-            as_global(S.terr)[t] = te;
-            if (terr_out) terr_out[t] = te;
+            if (returned) {
+                const uint8_t te = ext_ok_l ? (uint8_t)(tb.terr | tb.seen) : (uint8_t)PK_TERR_INVALID_ACTION;   // (seen: the error bits of a table pk_step_auto_d reset on the spot)
+                flags_out[t] = ext_ok_l ? (uint8_t)tb.flags : (uint8_t)0;          // :649-651: no mutation
+                as_global(S.terr)[t] = te;
+                if (terr_out) terr_out[t] = te;
+            }
+            if constexpr (BOUNDED) as_global(ext->ready)[t] = returned ? 1 : 0;
         }
         PK_PROF(tb.prof.flush(S.prof);)
         return;                                                                    // Game.step is not counted as rollout work
@@ -262,6 +281,12 @@ __global__ void __launch_bounds__(PK_TABLE_BLOCK, PK_WAVES_PER_SIMD_N(N)) k_step
     const StepKernArgs *ka = (const StepKernArgs *)__builtin_amdgcn_kernarg_segment_ptr();
     const Hot H = ka->H;
     rollout_body<N, false, PK_POLICY_EXTERNAL, 1>(ka->Sp, H, 0, ka->auto_reset, ka->park, PK_WAVE, 1, ka->actions, ka);
+}
+template <int N>
+__global__ void __launch_bounds__(PK_TABLE_BLOCK, PK_WAVES_PER_SIMD_N(N)) k_step_async(StepKernArgs) {   // pk_step_async_d: bounded launches
+    const StepKernArgs *ka = (const StepKernArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+    const Hot H = ka->H;
+    rollout_body<N, false, PK_POLICY_EXTERNAL, 1, true>(ka->Sp, H, 0, ka->auto_reset, ka->park, PK_WAVE, 1, ka->actions, ka);
 }
 template <int N>
 __global__ void __launch_bounds__(PK_TABLE_BLOCK, PK_WAVES_PER_SIMD_N(N)) k_rollout_single(const State *__restrict__ Sp, Hot H, int K, int auto_reset, int park, int slack, int clear_terr) {
@@ -1033,6 +1058,7 @@ __global__ void k_eval7_prefix(int a, int b, int fast, uint32_t count, uint32_t 
     X(N, k_rollout_call, PK_ROLLOUT_SIG)                                     \
     X(N, k_rollout_single, PK_ROLLOUT_SIG)                                   \
     X(N, k_step, (StepKernArgs))                                             \
+    X(N, k_step_async, (StepKernArgs))                                       \
     X(N, k_env_reset, (EnvResetKernArgs))                                    \
     X(N, k_env_step, (EnvKernArgs))                                          \
     X(N, k_env_step_async, (EnvKernArgs))                                    \

@@ -121,6 +121,14 @@ class VecGame:
         fn = self._lib.pk_step_auto_d if auto_reset else self._lib.pk_step_d
         L.check(fn(self._h, self._dptr(actions_d), self._dptr(flags_d), self._dptr(terr_d)), self._h)
 
+    def step_async_d(self, actions_d, flags_d, terr_d, ready_d, max_hands=1, auto_reset=False):
+        """`Game.step` as a bounded launch (pk_step_async_d): tables whose step has returned get ready_d[t] = 1 and their flags_d /
+        terr_d; a table whose step rolls on through further hands (game.py:607-611) stays in flight on the device, ready_d[t] = 0,
+        and the next call carries on with it, ignoring actions_d[t].  max_hands <= 0 drains (every table ready); until then every
+        other method that reads or changes tables raises (PK_E_BUSY).  Per table the steps, flags and RNG draws are the synchronous ones."""
+        L.check(self._lib.pk_step_async_d(self._h, self._dptr(actions_d), self._dptr(flags_d), self._dptr(terr_d), self._dptr(ready_d),
+                                          int(max_hands), int(bool(auto_reset))), self._h)
+
     def pick_actions_d(self, actions_d, policy=0):
         """The action the in-kernel agent `policy` takes on every table -> actions_d i32[T] (pk_pick_actions_d)."""
         L.check(self._lib.pk_pick_actions_d(self._h, int(policy), self._dptr(actions_d)), self._h)

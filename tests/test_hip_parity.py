@@ -536,6 +536,96 @@ def test_stream_pool_drain(HB):
     g.close()
 
 
+def test_async_game_step(HB, O):
+    """pk_step_async_d: Game.step as a bounded launch.  Tables whose step returned are delivered (ready 1, flags, terr); a table whose
+    step rolls on through further hands stays in flight and is delivered by a later call, which ignores its action.  Per table the
+    DELIVERED (flags, terr) must equal what the oracle returned for that step -- it made the step at the call that started it -- and
+    after a drain every state byte.  Full-width ragged waves, small batches, blinds far above the stacks (every step rolls hands), both
+    reset rules, one and two hand ends per launch, invalid actions in between."""
+    from pokerl_amd import _lib as L
+    from pokerl_amd.hipmem import DeviceBuffer
+    lib = L.lib()
+    cases = [(65536 + 19, 6, 100, 2, 1, 40, 1, True), (4096, 6, 100, 2, 1, 120, 1, False), (1500, 9, 100, 2, 1, 150, 2, True),
+             (900, 5, [3, 100, 5, 40, 7.5], 40, 7.5, 120, 1, True), (2048, 3, 2, 40, 20, 60, 1, False), (65, 16, 10, 3, 1, 200, 1, True)]
+    for T, N, stacks, bb, sb, calls, max_hands, auto in cases:
+        hb = HB(T, N, stacks, bb, sb, seed=4711)
+        g = hb.g
+        o = O.OracleGame(T, N, stacks, bb, sb, seed=4711)
+        o.reset(); g.reset()
+        act, flags, terr, ready = DeviceBuffer(T * 4), DeviceBuffer(T), DeviceBuffer(T), DeviceBuffer(T)
+        where = "T=%d N=%d bb=%s max_hands=%d auto=%d" % (T, N, bb, max_hands, auto)
+        idle = np.ones(T, bool)                                          # no step of that table is in flight on the device
+        want_f, want_e = np.zeros(T, np.uint8), np.zeros(T, np.uint8)    # what the oracle returned for the step in flight / just made
+        inflight_seen = delivered = 0
+
+        def over_of(f, e):                                               # game over, or a step the reference would never leave
+            return ((f & 1) | ((e & 4) >> 2)).astype(np.uint8)
+
+        def check(mask, what):                                           # the rows delivered for the tables in `mask`
+            fl, te = flags.download(np.uint8, T), terr.download(np.uint8, T)
+            exp_f = ((want_f & 6) | over_of(want_f, want_e)).astype(np.uint8) if auto else want_f
+            badrow = mask & ((fl != exp_f) | (te != want_e))
+            assert not badrow.any(), (where, what, [(int(t), int(exp_f[t]), int(fl[t]), int(want_e[t]), int(te[t])) for t in np.nonzero(badrow)[0][:6]], int(badrow.sum()))
+
+        def drain():                                                     # finish what is in flight; idle tables: "no step" (an invalid action)
+            act.upload(np.full(T, -1, np.int32))
+            g.step_async_d(act, flags, terr, ready, max_hands=0, auto_reset=auto); g.sync()
+            assert (ready.download(np.uint8, T) != 0).all(), where
+            fin = ~idle
+            check(fin, "drain")
+            assert (terr.download(np.uint8, T)[idle] == L.TERR_INVALID_ACTION).all()
+            idle[:] = True
+            return fin
+
+        for c in range(calls):
+            g.pick_actions_d(act, 0)                                     # (a device reader: works while steps are in flight)
+            g.sync()                                                     # (the handle's stream is non-blocking: hipMemcpy does not wait for it)
+            a = act.download(np.int32, T)
+            if c % 7 == 3:                                               # some tables get an invalid action: returned at once, untouched
+                a = np.where(np.arange(T) % 11 == c % 11, 9, a).astype(np.int32)
+                act.upload(a)
+            fo, eo = o.step(np.where(idle, a, -1).astype(np.int32))      # the oracle makes the steps that START in this call
+            want_f = np.where(idle, fo, want_f); want_e = np.where(idle, eo, want_e)
+            g.step_async_d(act, flags, terr, ready, max_hands=max_hands, auto_reset=auto)
+            g.sync()
+            r = ready.download(np.uint8, T) != 0
+            check(r, "call %d" % c)
+            inflight_seen += int((~r).sum()); delivered += int(r.sum())
+            done_now = r.copy()
+            idle = r.copy()
+            if not auto and ((~idle).any() or (r & (over_of(want_f, want_e) != 0)).any()):
+                done_now |= drain()                                      # the caller's own reset needs a drained handle (PK_E_BUSY otherwise)
+            m = (done_now & (over_of(want_f, want_e) != 0)).astype(np.uint8)
+            if m.any():                                                  # auto: the launch has reset them already
+                o.reset(mask=m)
+                if not auto:
+                    g.reset(mask=m)
+        fin = drain()
+        m = (fin & (over_of(want_f, want_e) != 0)).astype(np.uint8)
+        if m.any():
+            o.reset(mask=m)
+            if not auto:
+                g.reset(mask=m)
+        assert_same(o.snapshot(), hb.snapshot(), where)
+        if bb != 40:
+            assert delivered > 0.9 * T * calls, where                    # (blinds far above the stacks: half of the steps roll on and are delivered by the drains)
+        if bb == 40 or T > 60000:
+            assert inflight_seen > 0, where                              # the bound was exercised: steps did stay in flight
+        # while steps may be in flight every other entry point is busy -- except the device readers
+        g.pick_actions_d(act, 0)
+        g.step_async_d(act, flags, terr, ready, max_hands=1, auto_reset=auto)
+        assert lib.pk_get_i32(g._h, 0, L.ptr(np.zeros(T, np.int32))) == L.PK_E_BUSY and lib.pk_reset(g._h, None, 0) == L.PK_E_BUSY
+        assert lib.pk_step_d(g._h, act.ptr, flags.ptr, terr.ptr) == L.PK_E_BUSY
+        assert lib.pk_step_async_d(g._h, act.ptr, flags.ptr, terr.ptr, ready.ptr, 1, 0 if auto else 1) == L.PK_E_INVALID_ARG
+        assert lib.pk_pick_actions_d(g._h, 0, act.ptr) == L.PK_OK and lib.pk_sync(g._h) == L.PK_OK
+        act.upload(np.full(T, -1, np.int32))
+        g.step_async_d(act, flags, terr, ready, max_hands=0, auto_reset=auto); g.sync()
+        assert lib.pk_get_i32(g._h, 0, L.ptr(np.zeros(T, np.int32))) == L.PK_OK
+        for b in (act, flags, terr, ready):
+            b.free()
+        g.close()
+
+
 def test_bad_arguments_are_reported_not_fatal(HB):
     import ctypes as C
     import pokerl_amd
@@ -829,12 +919,13 @@ def test_bench_json_contract():
     assert c["cpu_baseline"]["kind"] == "port" and c["cpu_baseline"]["cores"] == 1 and c["cpu_baseline"]["value"] > 0 and c["cpu_baseline"]["sample"]
     assert c["evaluator"]["hand_evals_per_s"] > 0 and 0.0 < c["evaluator"]["frac"] <= 1.0
     cx = c["extra_workloads"]
-    assert len(cx) == 9 and all(len(x["name"]) <= 40 for x in cx)
+    assert len(cx) == 10 and all(len(x["name"]) <= 40 for x in cx)
     for x in cx:
         assert set(x) >= {"name", "value", "unit", "kernel_ms", "bound", "frac", "hbm_frac"} and x["value"] > 0 and 0.0 < x["frac"] <= 1.0, x
-    assert [x["name"].split()[0] for x in cx] == ["cfg1", "cfg4", "cfg2", "Game.step", "Game.step", "Game.step", "env.step", "env.step", "env.step"]
-    assert cx[3]["bound"] == cx[4]["bound"] == cx[5]["bound"] == "hbm" and cx[3]["unit"] == "env-steps/s" and cx[4]["value"] >= cx[3]["value"] * 0.95
-    assert cx[5]["frac"] > cx[4]["frac"]                  # a batch that fills the chip is bound by its bytes, 65 536 tables by the slowest table's chain
+    assert [x["name"].split()[0] for x in cx] == ["cfg1", "cfg4", "cfg2", "Game.step", "Game.step", "Game.step", "Game.step", "env.step", "env.step", "env.step"]
+    assert cx[3]["bound"] == cx[4]["bound"] == cx[5]["bound"] == cx[6]["bound"] == "hbm" and cx[3]["unit"] == "env-steps/s" and cx[4]["value"] >= cx[3]["value"] * 0.95
+    assert cx[6]["frac"] > cx[4]["frac"]                  # a batch that fills the chip is bound by its bytes, 65 536 tables by the slowest table's chain
+    assert cx[5]["value"] > cx[3]["value"]                # bounded launches: the tables whose step rolls on do not hold the launch
     assert abs(cx[1]["hand_evals_per_s"] / cx[1]["value"] - 1.0) < 1e-3       # configs[4]: one in-game evaluation per env-step
 
     # ---- the detail file: what the line held up to round 4
@@ -871,7 +962,7 @@ def test_bench_json_contract():
     assert cm["half_rate_share_source"] and 0.4 < cm["half_rate_share"] < 0.8
     # the other single-GPU BASELINE configs, Game.step with the caller's actions and the PokerGameEnv path are driver-timed legs
     xs = r["extra_workloads"]
-    assert len(xs) == 9 and [("configs[1]" in xs[0]["name"]), ("configs[4]" in xs[1]["name"])] == [True, True]
+    assert len(xs) == 10 and [("configs[1]" in xs[0]["name"]), ("configs[4]" in xs[1]["name"])] == [True, True]
     assert "one launch per call" in xs[2]["name"] and xs[2]["launch_stats"]["max"] == 20 and xs[2]["value"] < r["value"]
     for x in xs:
         for k in ("name", "short", "value", "unit", "kernel", "kernel_ms", "launches", "roofline"):
@@ -882,14 +973,15 @@ def test_bench_json_contract():
         assert abs(xr["frac"] - xr["achieved"] / xr["peak"]) < 1e-9
     # configs[4] is the showdown-heavy half of the metric: one in-game evaluation per env-step
     assert abs(xs[1]["hand_evals_per_s"] / xs[1]["value"] - 1.0) < 1e-3 and xs[0]["unit"] == xs[1]["unit"] == "env-steps/s"
-    for x in xs[3:6]:                                              # Game.step legs: the HBM roofline on SURVEY 8d's bytes + measured traffic
+    assert 0.99 < xs[5]["ready_fraction_per_launch"] < 1.0 and "k_step_async" in xs[5]["kernel"]
+    for x in xs[3:7]:                                              # Game.step legs: the HBM roofline on SURVEY 8d's bytes + measured traffic
         xr = x["roofline"]
         assert x["unit"] == "env-steps/s" and "k_step" in x["kernel"] and xr["bound"] == "hbm" and x["tables_with_error_bits"] < 40
         assert abs(xr["achieved"] - 478 * x["value"] / 1e9) / xr["achieved"] < 1e-6 and xr["traffic"] > 0.5 * 65536 * 478
-    for x in xs[6:]:                                               # PokerGameEnv legs: measured HBM traffic beside the VALU figure
+    for x in xs[7:]:                                               # PokerGameEnv legs: measured HBM traffic beside the VALU figure
         assert x["unit"] == "env.step/s" and x["kernel"].startswith("k_env_step") and 0.0 < x["roofline"]["hbm"]["frac"] <= 1.0
         assert x["roofline"]["traffic"] > 0 and 4.0 < x["game_steps_per_env_step"] < 8.0
-    assert xs[6]["ready_fraction_per_launch"] == 1.0 and 0.3 < xs[7]["ready_fraction_per_launch"] < 1.0
+    assert xs[7]["ready_fraction_per_launch"] == 1.0 and 0.3 < xs[8]["ready_fraction_per_launch"] < 1.0
 
 
 @pytest.mark.parametrize("N,policy", [(6, 0), (9, 1), (2, 0), (10, 0)])

@@ -22,6 +22,7 @@ tools/profile_env.sh ${R}_env_async8_inner3_524288x6 --env-async 8 --tables 5242
 tools/profile_eval7.sh ${R}_eval7
 tools/profile_step.sh ${R}_step_65536x6 --steps 1000 --warmup 100
 tools/profile_step.sh ${R}_step_1048576x6 --tables 1048576 --steps 200 --warmup 50
+tools/profile_step.sh ${R}_step_async_65536x6 --steps 1000 --warmup 100 --step-async 1
 fi
 if [ "$WHAT" = "all" ] || [ "$WHAT" = "benches" ]; then
 cd $ROOT
@@ -38,6 +39,7 @@ python bench.py --mode step --steps 2000 --warmup 200 2>/dev/null | tail -1 > gp
 python bench.py --mode step --steps 2000 --warmup 200 --step-replay 2>/dev/null | tail -1 > gpurun_out/${R}_bench_step_65536x6_replay.json
 python bench.py --mode step --steps 2000 --warmup 200 --step-unfused-reset 2>/dev/null | tail -1 > gpurun_out/${R}_bench_step_65536x6_unfused_reset.json
 python bench.py --mode step --tables 1048576 --steps 300 --warmup 50 --step-replay 2>/dev/null | tail -1 > gpurun_out/${R}_bench_step_1048576x6_replay.json
+python bench.py --mode step --steps 2000 --warmup 200 --step-async 1 2>/dev/null | tail -1 > gpurun_out/${R}_bench_step_async_65536x6.json
 python bench.py --mode env --steps 200 --warmup 20 2>/dev/null | tail -1 > gpurun_out/${R}_bench_env.json
 python bench.py --mode env --steps 200 --warmup 20 --env-batches 4 2>/dev/null | tail -1 > gpurun_out/${R}_bench_env_sync_batches4.json
 python bench.py --mode env --steps 2000 --warmup 200 --env-async 8 2>/dev/null | tail -1 > gpurun_out/${R}_bench_env_async8_batches1.json

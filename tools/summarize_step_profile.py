@@ -17,7 +17,7 @@ tag = sys.argv[1]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", "prof_" + tag)
 dst = os.path.join(root, "profiles")
-KERNELS = ("k_pick<", "k_step<", "k_reset<", "k_step_bet<", "k_step_end<")
+KERNELS = ("k_pick<", "k_step<", "k_step_async<", "k_reset<")
 
 
 def bench_line(log):
@@ -46,9 +46,11 @@ for r in csv.DictReader(open(trace)):
         per[k].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
         first.setdefault(k, r)
 m = re.search(r"(\d+) x (\d+)", line["name"])
-summary = {"tag": tag, "workload": {"tables": int(m.group(1)), "players": int(m.group(2)), "replay": "replayed" in line["name"],
+if "ready_fraction_per_launch" in line:
+    pass
+summary = {"tag": tag, "workload": {"tables": int(m.group(1)), "players": int(m.group(2)), "replay": "replayed" in line["name"], "bounded": "bounded launches" in line["name"],
                                     "command": json.load(open(os.path.join(src, "workload.json")))["command"]},
-           "bench_line_of_the_traced_run": {k: line[k] for k in ("value", "kernel_ms", "launches", "device_ms", "ms_per_step")},
+           "bench_line_of_the_traced_run": {k: line[k] for k in ("value", "kernel_ms", "launches", "device_ms", "ms_per_step", "ready_fraction_per_launch") if k in line},
            "kernels": {}}
 for k, d in per.items():
     d.sort()
@@ -58,6 +60,7 @@ for k, d in per.items():
                              "lds_bytes": int(r["LDS_Block_Size"]), "scratch_bytes": int(r["Scratch_Size"]),
                              "grid": int(r["Grid_Size_X"]), "workgroup": int(r["Workgroup_Size_X"])}
 summary["k_step_avg_ms"] = sum(summary["kernels"][k]["avg_ms"] for k in summary["kernels"] if k.startswith("k_step"))
+summary["k_step_min_median_max_ms"] = [[summary["kernels"][k][x] for x in ("min_ms", "median_ms", "max_ms")] for k in summary["kernels"] if k.startswith("k_step")][0]
 summary["kernel_ms_per_step_sum"] = sum(v["avg_ms"] for v in summary["kernels"].values() if v["launches"] * 2 >= max(x["launches"] for x in summary["kernels"].values()))
 # PMC passes: per kernel, the mean per launch; a loop iteration = one launch of each kernel of the loop
 for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
