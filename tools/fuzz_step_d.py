@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """One-off confidence run (GPU box): Game.step with the caller's actions on DEVICE buffers -- pk_pick_actions_d + pk_step_auto_d
-(the reset of a finished game inside the step's launch) and, on a twin handle, pk_step_d + pk_reset_d(flags, GAME_OVER) -- against
+(the reset of a finished game inside the step's launch), on a twin handle pk_step_d + pk_reset_d(flags, GAME_OVER), and on a third one the
+BOUNDED form pk_step_async_d (one or two hand ends per launch, reset inside; a table whose step rolls on stays in flight and is delivered by
+a later call: its delivered flags / terr must be those the oracle returned when the step started, its state equal after a drain) -- against
 the CPU oracle's step + reset over seeded odd configurations (every N, zero / fractional / oversized blinds, per-seat stacks
 0.5 .. 1e6, any table-id base and dealer, batches from 65 to 4 097 tables: full and nearly empty waves).  This is the path on which a
 step that rolls hand after hand is served by end_block's single-table paths (lone showdown, deck stock).
@@ -31,7 +33,8 @@ def same(a, b, where):
         assert GU.bits_equal(a[k], b[k]), (where, k)
 
 
-steps = resets = 0
+steps = resets = async_steps = async_inflight = 0
+async_off = False
 for i in range(n_cfg):
     N = 2 + i % 15
     start = [rng.choice(stacks) for _ in range(N)] if rng.random() < 0.5 else rng.choice(stacks)
@@ -49,9 +52,32 @@ for i in range(n_cfg):
     where = "cfg %d: T=%d N=%d start=%s bb=%s sb=%s policy=%d K=%d" % (i, T, N, start, bb, sb, policy, K)
     o = O.OracleGame(T, N, start, bb, sb, seed=seed, table_id_base=base)
     ha, hb = HB(T, N, start, bb, sb, seed=seed, table_id_base=base), HB(T, N, start, bb, sb, seed=seed, table_id_base=base)
-    o.reset(); ha.reset(); hb.reset()                 # (pk_step_auto_d resets with dealer 0, as Game.reset() does)
-    bufs = [DeviceBuffer(T * 4), DeviceBuffer(T), DeviceBuffer(T), DeviceBuffer(T * 4), DeviceBuffer(T), DeviceBuffer(T)]
-    act_a, fl_a, te_a, act_b, fl_b, te_b = bufs
+    hc, oc = HB(T, N, start, bb, sb, seed=seed, table_id_base=base), O.OracleGame(T, N, start, bb, sb, seed=seed, table_id_base=base)
+    o.reset(); ha.reset(); hb.reset(); hc.reset(); oc.reset()   # (pk_step_auto_d resets with dealer 0, as Game.reset() does)
+    bufs = [DeviceBuffer(T * 4), DeviceBuffer(T), DeviceBuffer(T), DeviceBuffer(T * 4), DeviceBuffer(T), DeviceBuffer(T),
+            DeviceBuffer(T * 4), DeviceBuffer(T), DeviceBuffer(T), DeviceBuffer(T)]
+    act_a, fl_a, te_a, act_b, fl_b, te_b, act_c, fl_c, te_c, rdy_c = bufs
+    hands_c = 1 + i % 2
+    idle = np.ones(T, bool); want_f = np.zeros(T, np.uint8); want_e = np.zeros(T, np.uint8)
+
+    def async_call(actions_for_idle, budget):
+        """One pk_step_async_d call of the third handle against its own oracle `oc` (which makes a step at the call that starts it)."""
+        global want_f, want_e, idle, async_steps, async_inflight, async_off
+        fo2, eo2 = oc.step(np.where(idle, actions_for_idle, -1).astype(np.int32))
+        want_f = np.where(idle, fo2, want_f); want_e = np.where(idle, eo2, want_e)
+        hc.g.step_async_d(act_c, fl_c, te_c, rdy_c, max_hands=budget, auto_reset=True); hc.g.sync()
+        r = rdy_c.download(np.uint8, T) != 0
+        ov = ((want_f & 1) | ((want_e & 4) >> 2)).astype(np.uint8)
+        exp = ((want_f & 6) | ov).astype(np.uint8)
+        assert np.array_equal(fl_c.download(np.uint8, T)[r], exp[r]) and np.array_equal(te_c.download(np.uint8, T)[r], want_e[r]), (where, "async")
+        if (r & ((want_e & 2) != 0)).any():               # game.py:473 on a delivered step (the caller would drain and reset it): the twin
+            async_off = True                              # stops here for this configuration
+        m2 = (r & (ov != 0)).astype(np.uint8)
+        if m2.any():
+            oc.reset(mask=m2)
+        async_steps += int(r.sum()); async_inflight += int((~r).sum())
+        idle = r.copy()
+
     for s in range(K):
         a = o.pick_actions(policy)
         fo, eo = o.step(a)
@@ -73,14 +99,29 @@ for i in range(n_cfg):
         if over.any():
             o.reset(mask=over)
             resets += int(over.sum())
+        if not async_off and not (eo & 2).any():
+            hc.g.pick_actions_d(act_c, policy); hc.g.sync()
+            async_call(act_c.download(np.int32, T), hands_c)
+        else:
+            async_off = True                              # (the twin stops at the first game.py:473 table of this configuration)
         if s % 40 == 39 or s == K - 1:
             snap = o.snapshot()
             same(snap, ha.snapshot(), where + " step %d (auto)" % s)
             same(snap, hb.snapshot(), where + " step %d (step_d + reset_d)" % s)
+    if not async_off:
+        act_c.upload(np.full(T, -1, np.int32))            # drain: idle tables get "no step"
+        async_call(np.full(T, -1, np.int32), 0)
+        if not async_off:
+            assert idle.all()
+            same(oc.snapshot(), hc.snapshot(), where + " (async, drained)")
+    async_off = False
+    hc.g.close()
     steps += 2 * T * K
     for b in bufs:
         b.free()
     ha.g.close(); hb.g.close()
     if i % 25 == 24:
         print("%d configurations bit-exact so far" % (i + 1), flush=True)
-print("fuzz: %d configurations, %d device-resident Game.steps, %d games reset inside a step's launch, all bit-exact vs the oracle" % (n_cfg, steps, resets))
+print("fuzz: %d configurations, %d device-resident Game.steps, %d games reset inside a step's launch, all bit-exact vs the oracle; "
+      "bounded launches: %d steps delivered, %d times a table's step was left in flight, every delivery and every drained state equal"
+      % (n_cfg, steps, resets, async_steps, async_inflight))
