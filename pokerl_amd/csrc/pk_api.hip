@@ -667,6 +667,7 @@ static int any_terr(const uint8_t *terr, int T) {
 int pk_step(pk_handle *h, const int32_t *actions, uint8_t *flags, uint8_t *terr) {
     if (!h || !actions || !flags) return h ? h->fail(PK_E_INVALID_ARG, "pk_step: NULL buffer") : PK_E_INVALID_ARG;
     ON_DEVICE(h);
+    if (in_flight(h)) return flush(h);     // PK_E_BUSY, before anything is queued
     const size_t T = (size_t)h->T;
     HIPCHK(h, hipMemcpyAsync(h->d_actions, actions, T * 4, hipMemcpyHostToDevice, h->stream));
     int rc = pk_step_d(h, h->d_actions, h->d_flags, h->d_terr);
@@ -912,6 +913,7 @@ int pk_env_step_async_d(pk_handle *h, const int32_t *actions_d, int seat0_policy
         (!actions_d && (bad_policy(seat0_policy))))
         return h ? h->fail(PK_E_INVALID_ARG, "pk_env_step_async_d: bad argument") : PK_E_INVALID_ARG;
     ON_DEVICE(h);
+    if (h->host_step || h->step_pending) return flush(h);   // PK_E_BUSY: a host-buffer step awaits its end / Game.steps are in flight
     const int s0 = actions_d ? -1 : seat0_policy, au = auto_reset ? 1 : 0;
     // steps in flight keep THEIR agents and reset rule (as owed rollout steps do): a call that would change them is refused
     if (h->env_pending && (h->env_multi || s0 != h->env_seat0 || opp_policy != h->env_opp || au != h->env_auto))
@@ -1025,6 +1027,7 @@ int pk_env_step_multi_d(pk_handle *h, const int32_t *actions_d, const uint8_t *r
     if (rc) return rc;
     if (ext && !actions_d) return h->fail(PK_E_INVALID_ARG, "pk_env_step_multi_d: actions_d is required when a seat is PK_POLICY_EXTERNAL");
     ON_DEVICE(h);
+    if (h->host_step || h->step_pending) return flush(h);   // PK_E_BUSY
     const int au = auto_reset ? 1 : 0;
     // steps in flight keep THEIR agents and reset rule: a call that would change them is refused
     if (h->env_pending && (!h->env_multi || seat_policies != h->env_seats || au != h->env_auto))
@@ -1090,7 +1093,7 @@ static int fetch_counters(pk_handle *h, uint64_t *counters) {
 // fused: one launch that may leave work for later (counters == NULL) or must complete it (counters != NULL);
 // unfused: k_steps complete single-step launches (state round-trips HBM every step).
 static int enqueue_rollout(pk_handle *h, int k_steps, int policy, int auto_reset, int fused, bool complete, bool may_coalesce = true) {
-    if (h->env_pending) return flush(h);   // PK_E_BUSY
+    if (in_flight(h)) return flush(h);     // PK_E_BUSY (k_rollout would carry a Game.step of pk_step_async_d on as if it were deferred rollout work)
     if ((h->pending || h->acc) && (policy != h->pend_policy || auto_reset != h->pend_auto)) FLUSH(h);  // owed steps keep THEIR agents
     if (!fused) {
         FLUSH(h);
@@ -1197,6 +1200,7 @@ int pk_env_step(pk_handle *h, const int32_t *actions, int opp_policy, double *re
     if (!h || !actions || !reward || !done || !hand || bad_policy(opp_policy))
         return h ? h->fail(PK_E_INVALID_ARG, "pk_env_step: bad argument") : PK_E_INVALID_ARG;
     ON_DEVICE(h);
+    if (in_flight(h)) return flush(h);     // PK_E_BUSY, before anything is queued
     const size_t T = (size_t)h->T;
     HIPCHK(h, hipMemcpyAsync(h->d_actions, actions, T * 4, hipMemcpyHostToDevice, h->stream));
     int rc = pk_env_step_d(h, h->d_actions, opp_policy, h->d_reward, h->d_done, h->d_handf, h->d_terr);

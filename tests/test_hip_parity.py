@@ -616,6 +616,8 @@ def test_async_game_step(HB, O):
         g.step_async_d(act, flags, terr, ready, max_hands=1, auto_reset=auto)
         assert lib.pk_get_i32(g._h, 0, L.ptr(np.zeros(T, np.int32))) == L.PK_E_BUSY and lib.pk_reset(g._h, None, 0) == L.PK_E_BUSY
         assert lib.pk_step_d(g._h, act.ptr, flags.ptr, terr.ptr) == L.PK_E_BUSY
+        assert lib.pk_rollout(g._h, 5, 0, 1, 1, None) == L.PK_E_BUSY and lib.pk_env_reset_d(g._h, None, 0) == L.PK_E_BUSY
+        assert lib.pk_env_step_async_d(g._h, None, 0, 0, 1, 4, act.ptr, flags.ptr, flags.ptr, terr.ptr, None, ready.ptr) == L.PK_E_BUSY
         assert lib.pk_step_async_d(g._h, act.ptr, flags.ptr, terr.ptr, ready.ptr, 1, 0 if auto else 1) == L.PK_E_INVALID_ARG
         assert lib.pk_pick_actions_d(g._h, 0, act.ptr) == L.PK_OK and lib.pk_sync(g._h) == L.PK_OK
         act.upload(np.full(T, -1, np.int32))
