@@ -158,9 +158,10 @@ n, base = bench.shard(65536 * world, ctx)
 # stand-in workload: rank r "runs" n*10 steps in (1 + r) seconds
 total_steps, seconds = ctx.aggregate(n * 10, 1.0 + rank)
 bases = ctx.sum_list([base if r == rank else 0 for r in range(world)])     # every rank's table_id_base, gathered by SUM
+dist_block = ctx.describe(rank %% 4, n)                                       # the `dist` block of the bench line (collective)
 ctx.barrier()
 if rank == 0:
-    print(json.dumps(dict(n=n, base=base, total=total_steps, seconds=seconds, world=world, bases=bases,
+    print(json.dumps(dict(n=n, base=base, total=total_steps, seconds=seconds, world=world, bases=bases, dist=dist_block,
                           cfg=bench.baseline_config_index(65536, 6, "random", world))))
 ctx.close()
 '''
@@ -207,6 +208,7 @@ def test_bench_aggregation_gloo_world2(tmp_path):
     assert r["world"] == 2 and r["n"] == 65536 and r["base"] == 0
     assert r["total"] == 131072 * 10          # units of ALL ranks
     assert r["seconds"] == 2.0                # MAX over ranks
+    assert r["dist"] == {"backend": "gloo", "world": 2, "devices": [0, 1], "tables_per_rank": [65536, 65536], "collectives_on_step_path": 0}
 
 
 def test_bench_aggregation_gloo_world8(tmp_path):
@@ -225,6 +227,7 @@ def test_bench_aggregation_gloo_world8(tmp_path):
     assert r["bases"] == [k * 65536 for k in range(8)]          # rank k hosts tables [k * 65 536, (k + 1) * 65 536)
     assert r["total"] == 524288 * 10                            # units of ALL ranks
     assert r["seconds"] == 8.0                                  # MAX over ranks (rank 7: 1 + 7 s)
+    assert r["dist"]["world"] == 8 and r["dist"]["devices"] == [0, 1, 2, 3, 0, 1, 2, 3] and r["dist"]["tables_per_rank"] == [65536] * 8
 
 
 GATHER_WORKER = r'''
