@@ -38,6 +38,25 @@ dt = time.perf_counter() - t0
 assert not (terr.download(np.uint8, T) & L.TERR_INVALID_ACTION).any()
 print("%d tables x %d device-resident Game.steps in %.3f s = %.2f G steps/s (%.1f us per step of the whole batch); "
       "%d games ended in the sampled steps; mean pot now %.2f" % (T, steps, dt, T * steps / dt / 1e9, dt / steps * 1e6, games, game.pot.mean()))
-for b in (actions, flags, terr, obs):
+
+# The same loop as BOUNDED launches (pk_step_async_d): a synchronous step launch lasts as long as the one table whose step rolls through
+# several hands (game.py:607-611 plays hands nobody can act in); here such a table stays in flight, ready[t] says whose step has returned,
+# and the loop acts on those.  Drain (max_hands=0) before touching the game through any other method.
+ready = DeviceBuffer(T)
+delivered = 0
+game.sync()
+t0 = time.perf_counter()
+for s in range(steps):
+    game.pick_actions_d(actions, pokerl_amd.Policy.RANDOM)     # a device reader: allowed while steps are in flight (rows of tables in flight: ignore)
+    game.step_async_d(actions, flags, terr, ready, max_hands=1, auto_reset=True)
+    if s % 500 == 499:
+        game.sync()
+        delivered += int(ready.download(np.uint8, T).sum())    # (sampled: 99.98 % of the tables are ready after every launch)
+game.step_async_d(actions, flags, terr, ready, max_hands=0, auto_reset=True)   # drain: every table ready
+game.sync()
+dt = time.perf_counter() - t0
+print("bounded launches: %.1f us per step of the whole batch (%.2f G steps/s if every table were ready; %.4f of them were in the sampled launches)"
+      % (dt / steps * 1e6, T * steps / dt / 1e9, delivered / float(T * max(1, steps // 500))))
+for b in (actions, flags, terr, obs, ready):
     b.free()
 game.close()
