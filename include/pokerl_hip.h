@@ -347,7 +347,11 @@ int pk_env_step_end(pk_handle *h);
  * Use auto_reset != 0 with bounded launches: pk_env_reset_d is one of the entry points that are busy meanwhile, so a
  * finished episode could only be reset after a drain.  Steps in flight keep their agents: while that state lasts every
  * call must pass the same seat-0 source (actions_d NULL or not, seat0_policy), opp_policy and auto_reset as the call that
- * started it, else PK_E_INVALID_ARG (nothing done). */
+ * started it, else PK_E_INVALID_ARG (nothing done).
+ * How long a table can stay in flight: a Game.step that rolls hand after hand is carried to its end inside one launch once it has rolled
+ * 16 hands; an env.step whose loops never reach seat 0 (seat 0 broke with the game not over: the reference would spin forever, here
+ * PK_ENV_STEP_CAP = 8 192 opponent steps end it with PK_TERR_ENV_CAP) makes about max_passes Game.steps per launch, i.e. is delivered
+ * after ~8 192 / max_passes launches -- slow, never stuck; the other tables are not held up by it. */
 int pk_env_step_async_d(pk_handle *h, const int32_t *actions_d, int seat0_policy, int opp_policy, int auto_reset,
                         int max_passes, double *reward_d, uint8_t *done_d, uint8_t *hand_d, uint8_t *terr_d,
                         double *obs_d, uint8_t *ready_d);
