@@ -624,14 +624,17 @@ def _leg(out, name, fn):
 
 
 
-def step_workload(ctx, device, tables, players, steps=400, warmup=100, replay=False, fused_reset=True, async_hands=0):
+def step_workload(ctx, device, tables, players, steps=400, warmup=100, replay=False, fused_reset=True, async_hands=0, obs=None, obs_fused=True):
     """`Game.step` with CALLER-SUPPLIED actions on device buffers (reference pokerl/game.py:621-700) as the device-resident loop of
     examples/random_game.py:8-12: pick (pk_pick_actions_d) + step with the reset of a finished game in the same launch
     (pk_step_auto_d) -- two launches per step, the table state round-trips HBM in each; fused_reset=False: pk_step_d + pk_reset_d on
     the step's own flags, three launches.  replay: the actions a first pass recorded are replayed, so that the timed loop is the
     step kernel alone.  async_hands > 0: pk_step_async_d with that budget of hand ends per launch -- a table whose step rolls on through
     further hands stays in flight and the loop acts on the tables that are ready; the value counts DELIVERED steps (ready flags of the timed
-    launches).  HIP events on the handle's stream around the timed steps; the serials prove the steps were made."""
+    launches).  obs = "packed" / "dense": the loop also produces `game.active_state` (game.py:323-332: the StateView row of the player to act)
+    after every step -- obs_fused: written by the step kernel itself from registers (pk_set_step_obs), else by a second launch
+    (pk_get_obs_packed_d / pk_get_obs_d) that re-reads the tables.  HIP events on the handle's stream around the timed steps; the serials
+    prove the steps were made."""
     import ctypes as C
     import numpy as np
     import pokerl_amd
@@ -645,6 +648,16 @@ def step_workload(ctx, device, tables, players, steps=400, warmup=100, replay=Fa
     ready = DeviceBuffer(T * (steps + 1), device) if async_hands > 0 else None     # one slice per timed launch (slice 0: warm-up)
     ev0, ev1 = DeviceEvent(), DeviceEvent()
     assert not (async_hands > 0 and (replay or not fused_reset)), "the asynchronous leg picks on the device and resets inside the launch"
+    assert obs in (None, "packed", "dense"), obs
+    row_bytes = 0 if obs is None else (16 + 8 * (3 * players + 1)) if obs == "packed" else 8 * (17 + 3 * players)     # PK_OBS_PACKED_BYTES / PK_OBS_DIM
+    rows = DeviceBuffer(T * row_bytes, device) if obs else None
+    lib = L.lib()
+    if obs and obs_fused:
+        g.set_step_obs(rows if obs == "dense" else None, rows if obs == "packed" else None)
+
+    def observe():     # the second launch of the unfused form
+        if obs and not obs_fused:
+            L.check((lib.pk_get_obs_packed_d if obs == "packed" else lib.pk_get_obs_d)(g._h, -1, rows.ptr), g._h)
 
     def act(s):
         return C.c_void_p(rec.ptr.value + (s * T * 4 if replay else 0))
@@ -655,10 +668,12 @@ def step_workload(ctx, device, tables, players, steps=400, warmup=100, replay=Fa
                 g.pick_actions_d(act(s), 0)
             if async_hands > 0:
                 g.step_async_d(act(s), flags, terr, C.c_void_p(ready.ptr.value + (s - warmup + 1 if s >= warmup else 0) * T), async_hands, True)
+                observe()
                 continue
             g.step_d(act(s), flags, terr, auto_reset=fused_reset)
             if not fused_reset:
                 g.reset_d(flags, L.FLAG_GAME_OVER)
+            observe()
 
     def drain():
         if async_hands > 0:
@@ -686,8 +701,17 @@ def step_workload(ctx, device, tables, players, steps=400, warmup=100, replay=Fa
         drain(); g.sync()
     made = int(g.step_serial.sum()) - s0
     bad = int((terr.download(np.uint8, T) != 0).sum())
+    if obs:            # the rows were really written: they are the getter's rows of the final state
+        ref = DeviceBuffer(T * row_bytes, device)
+        L.check((lib.pk_get_obs_packed_d if obs == "packed" else lib.pk_get_obs_d)(g._h, -1, ref.ptr), g._h)
+        g.sync()
+        same = rows.download(np.uint8, T * row_bytes).tobytes() == ref.download(np.uint8, T * row_bytes).tobytes()
+        ref.free()
+        assert same or async_hands > 0, "the observation rows of the last step differ from the getter's"     # (bounded launches: the drain's extra step has re-written some rows)
+        if obs_fused:
+            g.set_step_obs(None, None)
     g.close()
-    for b in (flags, terr, rec, ready):
+    for b in (flags, terr, rec, ready, rows):
         if b is not None:
             b.free()
     if async_hands > 0:     # (every delivered step was made; the drain's pick + step adds up to one more per table)
@@ -697,10 +721,11 @@ def step_workload(ctx, device, tables, players, steps=400, warmup=100, replay=Fa
     return dict(tables=T, players=players, steps=steps, warmup=warmup, replay=replay, seconds=dt, device_ms=dev_ms,
                 game_steps=delivered if delivered is not None else made, async_hands=async_hands,
                 ready_fraction_per_launch=(delivered / float(T * steps)) if delivered is not None else 1.0,
-                tables_with_error_bits=bad, fused_reset=fused_reset, launches_per_step=(1 if replay else 2) + (0 if fused_reset else 1))
+                tables_with_error_bits=bad, fused_reset=fused_reset, obs=obs, obs_fused=bool(obs and obs_fused), obs_row_bytes=row_bytes,
+                launches_per_step=(1 if replay else 2) + (0 if fused_reset else 1) + (1 if (obs and not obs_fused) else 0))
 
 
-def step_profile_summary(tables, players, bounded=False):
+def step_profile_summary(tables, players, bounded=False, obs=None, obs_fused=False):
     """The committed rocprofv3 summary of the Game.step loop (profiles/rNN_step_*_summary.json: kernel trace + PMC passes of
     tools/profile_step.sh), latest round; None if none."""
     import glob
@@ -711,7 +736,7 @@ def step_profile_summary(tables, players, bounded=False):
         except Exception:
             continue
         w = d.get("workload", {})
-        if (w.get("tables"), w.get("players"), bool(w.get("bounded", False))) == (tables, players, bool(bounded)):
+        if (w.get("tables"), w.get("players"), bool(w.get("bounded", False)), w.get("obs"), bool(w.get("obs_fused", False))) == (tables, players, bool(bounded), obs, bool(obs_fused)):
             best = (d, os.path.basename(f))
     return best
 
@@ -722,14 +747,17 @@ def step_line(res, name):
     T, N = res["tables"], res["players"]
     ms_step = res["device_ms"] / res["steps"]
     rate = res["game_steps"] / (res["device_ms"] * 1e-3)
-    alg = b_step(N) * res["game_steps"] / res["steps"]           # algorithmic bytes of one step of the whole batch
+    row = res.get("obs_row_bytes", 0)
+    alg = (b_step(N) + row) * res["game_steps"] / res["steps"]   # algorithmic bytes of one step of the whole batch (+ the observation row where the loop produces one)
     gbs = alg / (ms_step * 1e-3) / 1e9
     roof = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
-            "kernel": " + ".join(([] if res["replay"] else ["k_pick"]) + ["k_step_async" if res.get("async_hands") else "k_step"] + ([] if res["fused_reset"] else ["k_reset(masked)"])),
+            "kernel": " + ".join(([] if res["replay"] else ["k_pick"]) + [("k_step_async" if res.get("async_hands") else "k_step") + ("[+%s row]" % res["obs"] if res.get("obs_fused") else "")] +
+                                 ([] if res["fused_reset"] else ["k_reset(masked)"]) + (["k_obs_packed" if res["obs"] == "packed" else "k_obs"] if (res.get("obs") and not res.get("obs_fused")) else [])),
+            "obs_row_bytes": row,
             "kernel_ms": ms_step, "launches_timed": res["steps"] * res["launches_per_step"], "algorithmic_bytes_per_step": alg,
             "kernel_ms_source": "HIP events (pk_record_event) around the timed steps on the handle's stream / steps: ALL launches of one "
                                 "loop iteration, launch gaps included"}
-    prof = step_profile_summary(T, N, bool(res.get("async_hands")))
+    prof = step_profile_summary(T, N, bool(res.get("async_hands")), res.get("obs"), bool(res.get("obs_fused")))
     if prof:
         d, src = prof
         mine = [k for k in d.get("loop_kernels", d.get("kernels", {})) if not (res["replay"] and k == "k_pick") and not (res["fused_reset"] and k == "k_reset")]   # the kernels of THIS leg's loop iteration
@@ -859,6 +887,14 @@ def extra_workloads(ctx, device):
     _leg(out, "Game.step replay", lambda: step_line(step_workload(ctx, device, 65536, 6, steps=2000, warmup=200, replay=True),
                                                     "Game.step, pk_step_auto_d alone on pre-picked (replayed) actions, 65 536 x 6")
          | {"short": "Game.step step_auto_d replay 65536x6"})
+    # ... with `game.active_state` after every step (SURVEY f2 on this path): the packed StateView row of the player to act, by a second launch
+    # that re-reads the tables (pk_get_obs_packed_d) and from the step kernel's registers (pk_set_step_obs)
+    _leg(out, "Game.step + obs, 2 launches", lambda: step_line(step_workload(ctx, device, 65536, 6, steps=2000, warmup=200, replay=True, obs="packed", obs_fused=False),
+                                                               "Game.step + packed observation row: pk_step_auto_d, then pk_get_obs_packed_d (two launches), replayed actions, 65 536 x 6")
+         | {"short": "Game.step+obs_packed 2 launches 65536x6"})
+    _leg(out, "Game.step + obs, fused", lambda: step_line(step_workload(ctx, device, 65536, 6, steps=2000, warmup=200, replay=True, obs="packed", obs_fused=True),
+                                                          "Game.step + packed observation row written by the step kernel (pk_set_step_obs; one launch), replayed actions, 65 536 x 6")
+         | {"short": "Game.step+obs_packed fused 65536x6"})
     # ... as bounded launches (pk_step_async_d): the few tables whose step rolls on through further hands stay in flight instead of
     # holding the launch; the loop acts on the tables that are ready, the value counts delivered steps
     _leg(out, "Game.step async", lambda: step_line(step_workload(ctx, device, 65536, 6, steps=2000, warmup=200, async_hands=1),
@@ -897,6 +933,8 @@ def main():
     ap.add_argument("--step-replay", action="store_true", help="--mode step: the step kernel alone on replayed (pre-picked) actions")
     ap.add_argument("--step-unfused-reset", action="store_true", help="--mode step: pk_step_d + pk_reset_d(flags) instead of pk_step_auto_d")
     ap.add_argument("--step-async", type=int, default=0, metavar="HANDS", help="--mode step through pk_step_async_d with this budget of hand ends per launch")
+    ap.add_argument("--step-obs", choices=["packed", "dense"], default=None, help="--mode step: the loop also produces the StateView row of the player to act after every step")
+    ap.add_argument("--step-obs-separate", action="store_true", help="--mode step --step-obs: by a second launch (pk_get_obs(_packed)_d) instead of from the step kernel (pk_set_step_obs)")
     ap.add_argument("--env-batches", type=int, default=1, help="--mode env: independent batches in flight, one stream each")
     ap.add_argument("--env-async", type=int, default=0, metavar="PASSES",
                     help="--mode env through pk_env_step_async_d with this pass budget per launch (0: synchronous)")
@@ -925,7 +963,8 @@ def main():
         ctx.close()
         return
     if args.mode == "step":   # Game.step with caller-supplied actions as its own line (tools/profile_step.sh profiles this command)
-        res = step_workload(ctx, device, args.tables, args.players, args.steps, args.warmup, args.step_replay, not args.step_unfused_reset, args.step_async)
+        res = step_workload(ctx, device, args.tables, args.players, args.steps, args.warmup, args.step_replay, not args.step_unfused_reset, args.step_async,
+                            args.step_obs, not args.step_obs_separate)
         if ctx.rank == 0:
             print(json.dumps(step_line(res, "Game.step device-resident loop, %d x %d%s%s" % (args.tables, args.players, ", replayed actions" if args.step_replay else "",
                                                                                               ", bounded launches (%d hand end(s) each)" % args.step_async if args.step_async else ""))))

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define PK_ABI_VERSION 5
+#define PK_ABI_VERSION 6
 #define PK_MIN_PLAYERS 2
 #define PK_MAX_PLAYERS 16 /* the reference takes any num_players (game.py:246; the deck allows 23).  Up to 16 the numpy routines it
                              calls are restated exactly: np.sum's eight-lane pairwise blocks (one up to 15 seats, two at 16) and
@@ -317,6 +317,19 @@ int pk_env_step_fused_d(pk_handle *h, const int32_t *actions_d, int seat0_policy
  * buffer.  PK_E_BUSY while env steps are in flight. */
 int pk_set_env_obs_packed(pk_handle *h, uint8_t *obs_packed_d);
 int pk_get_obs_packed_d(pk_handle *h, int player, uint8_t *out_d);
+
+/* The observation from the Game.step kernels themselves (pokerl/game.py:323-332: `game.active_state`, the StateView of the player to act,
+ * is what a learner that drives Game.step reads right after every step; pokerl/game.py:117-131).  Once a buffer is set here, every
+ * pk_step_d / pk_step_auto_d / pk_step_async_d launch (pk_step too: it runs pk_step_d) writes, for each table whose step RETURNED in that
+ * launch, the row of the player to act -- from the registers the step left, in the same launch -- into
+ *   obs_d         [T][PK_OBS_DIM(N)] f64, the row of pk_get_obs_d(h, -1, ...), and / or
+ *   obs_packed_d  [T][PK_OBS_PACKED_BYTES(N)], the row of pk_get_obs_packed_d(h, -1, ...);
+ * either may be NULL (both NULL: off, the default).  A table whose action was refused (PK_TERR_INVALID_ACTION) gets the row of its untouched
+ * table; a table pk_step_auto_d reset on the spot gets the first row of its new game; a table whose step is still in flight after a bounded
+ * launch (ready_d[t] == 0) keeps the row it had.  Saves the k_obs launch per step and the second pass over the 285 B/table the step kernel has
+ * just stored.  8-byte aligned buffers; the handle keeps the RAW pointers: call pk_set_step_obs(h, NULL, NULL) before freeing them.  Rows are NOT
+ * written by pk_reset / pk_reset_d / pk_rollout (refresh with pk_get_obs(_packed)_d after those).  PK_E_BUSY while steps are in flight. */
+int pk_set_step_obs(pk_handle *h, double *obs_d, uint8_t *obs_packed_d);
 
 /* pk_env_step through host buffers in two halves, for callers that want the copies off their critical path:
  * pk_env_step_begin uploads actions[T], launches PokerGameEnv.step (auto_reset != 0: finished episodes are reset on the spot,

@@ -16,7 +16,7 @@ I_ACTIVE_PLAYER, I_TURN, I_DEALER_IDX, I_SMALL_BLIND_IDX, I_BIG_BLIND_IDX, I_HAN
 TF_POT, TF_HIGH_BET, TF_MIN_RAISE = 0, 1, 2
 ACTION_SKIP = -2   # pk_env_step_multi_d: leave an idle table alone (PK_ACTION_SKIP)
 POLICY_EXTERNAL = 15
-ABI_VERSION = 5
+ABI_VERSION = 6
 NUM_COUNTERS = 4
 MIN_PLAYERS, MAX_PLAYERS = 2, 16
 
@@ -31,7 +31,7 @@ SYMBOLS = ["pk_abi_version", "pk_device_count", "pk_last_error", "pk_create", "p
            "pk_pick_actions_d", "pk_flush", "pk_get_owed", "pk_env_step_fused_d", "pk_env_step_async_d", "pk_set_tuning", "pk_get_stream", "pk_set_stream", "pk_wait_event",
            "pk_record_event", "pk_use_own_stream", "pk_set_coalesce", "pk_get_launch_stats", "pk_env_step_multi_d", "pk_env_end_multi_d", "pk_get_f64_d", "pk_set_env_batches", "pk_env_last_range",
            "pk_get_obs_packed", "pk_get_obs_packed_d", "pk_set_env_obs_packed", "pk_host_alloc", "pk_host_free", "pk_check_actions",
-           "pk_env_step_begin", "pk_env_step_end", "pk_reset_d", "pk_step_auto_d", "pk_stream_pool_drain", "pk_step_async_d"]
+           "pk_env_step_begin", "pk_env_step_end", "pk_reset_d", "pk_step_auto_d", "pk_stream_pool_drain", "pk_step_async_d", "pk_set_step_obs"]
 
 
 class PokerlHipError(RuntimeError):
@@ -106,6 +106,7 @@ def lib():
     L.pk_get_obs_packed.argtypes = [_vp, C.c_int, _vp]
     L.pk_get_obs_packed_d.argtypes = [_vp, C.c_int, _vp]
     L.pk_set_env_obs_packed.argtypes = [_vp, _vp]
+    L.pk_set_step_obs.argtypes = [_vp, _vp, _vp]
     L.pk_host_alloc.argtypes = [C.POINTER(_vp), C.c_size_t]
     L.pk_host_free.argtypes = [_vp]
     L.pk_check_actions.argtypes = [_vp, _vp, C.POINTER(C.c_int32)]

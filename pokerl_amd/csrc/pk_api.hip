@@ -81,6 +81,8 @@ struct pk_handle {
     uint8_t *h_pinned = nullptr;  // [T] pinned: per-table error bytes of pk_step / pk_env_step
     uint8_t *d_obs_packed = nullptr;     // [T][PK_OBS_PACKED_BYTES(N)]: device staging of pk_env_step_begin (allocated on first use)
     uint8_t *env_obs_packed = nullptr;   // pk_set_env_obs_packed: device buffer [T][PK_OBS_PACKED_BYTES(N)] or NULL
+    double *step_obs = nullptr;          // pk_set_step_obs: device buffers the Game.step kernels write the row of the player to act into, or NULL
+    uint8_t *step_obs_packed = nullptr;
     std::string err;
     int fail(int code, const char *what, hipError_t e = hipSuccess) {
         err = what;
@@ -630,7 +632,7 @@ int pk_reset_d(pk_handle *h, const uint8_t *mask_d, int mask_bits, int dealer) {
 static int launch_step(pk_handle *h, const int32_t *actions_d, uint8_t *flags_d, uint8_t *terr_d, int auto_reset) {
     ON_DEVICE(h);
     FLUSH(h);
-    const StepKernArgs ka{(const State *)h->d_S, h->hot, actions_d, flags_d, terr_d, scaled_park(h, 28), auto_reset ? 1 : 0, nullptr, 0};
+    const StepKernArgs ka{(const State *)h->d_S, h->hot, actions_d, flags_d, terr_d, scaled_park(h, 28), auto_reset ? 1 : 0, nullptr, 0, h->step_obs, h->step_obs_packed};
     DISPATCH_N(h, k_step, table_grid(h), ka);
     HIPCHK(h, hipGetLastError());
     return PK_OK;
@@ -651,7 +653,8 @@ int pk_step_async_d(pk_handle *h, const int32_t *actions_d, uint8_t *flags_d, ui
             return h->fail(PK_E_INVALID_ARG, "pk_step_async_d: Game.steps are in flight with another auto_reset; drain them first (max_hands = 0)");
         if (h->env_pending || h->host_step) return flush(h);
     } else FLUSH(h);
-    const StepKernArgs ka{(const State *)h->d_S, h->hot, actions_d, flags_d, terr_d, scaled_park(h, 28), auto_reset ? 1 : 0, ready_d, max_hands > 0 ? max_hands : 0};
+    const StepKernArgs ka{(const State *)h->d_S, h->hot, actions_d, flags_d, terr_d, scaled_park(h, 28), auto_reset ? 1 : 0, ready_d, max_hands > 0 ? max_hands : 0,
+                          h->step_obs, h->step_obs_packed};
     DISPATCH_N(h, k_step_async, table_grid(h), ka);
     HIPCHK(h, hipGetLastError());
     h->step_pending = max_hands > 0;
@@ -824,6 +827,13 @@ int pk_set_env_obs_packed(pk_handle *h, uint8_t *obs_packed_d) {
     if (!h || ((uintptr_t)obs_packed_d & 7)) return h ? h->fail(PK_E_INVALID_ARG, "pk_set_env_obs_packed: the buffer must be 8-byte aligned") : PK_E_INVALID_ARG;
     if (in_flight(h)) return h->fail(PK_E_BUSY, "pk_set_env_obs_packed: PokerGameEnv steps are in flight");
     h->env_obs_packed = obs_packed_d;
+    return PK_OK;
+}
+
+int pk_set_step_obs(pk_handle *h, double *obs_d, uint8_t *obs_packed_d) {
+    if (!h || ((uintptr_t)obs_d & 7) || ((uintptr_t)obs_packed_d & 7)) return h ? h->fail(PK_E_INVALID_ARG, "pk_set_step_obs: the buffers must be 8-byte aligned") : PK_E_INVALID_ARG;
+    if (in_flight(h)) return h->fail(PK_E_BUSY, "pk_set_step_obs: steps are in flight; drain them first");
+    h->step_obs = obs_d; h->step_obs_packed = obs_packed_d;
     return PK_OK;
 }
 

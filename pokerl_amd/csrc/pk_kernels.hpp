@@ -45,6 +45,38 @@ __global__ void __launch_bounds__(256) k_sum_counters(unsigned long long *slots,
 
 #endif
 
+// Game.StateView(player to act), game.py:117-131 -- what `game.active_state` builds right after every step (game.py:323-332) -- written
+// from the REGISTERS of the kernel that made the step: the dense f64 row (layout: pokerl_hip.h PK_OBS_DIM; the row k_obs builds from HBM) ...
+// First 8 bytes of a packed observation row (pokerl_hip.h PK_OBS_PACKED_BYTES): seat, turn, valid mask, hole cards, flop.
+__device__ __forceinline__ uint64_t obs_packed_header0(uint32_t who, uint32_t turn, uint32_t vmask, uint32_t h0, uint32_t h1, uint32_t c0, uint32_t c1, uint32_t c2) {
+    return (uint64_t)(who | (turn << 8) | ((vmask & 0x7fu) << 16) | (h0 << 24)) | ((uint64_t)(h1 | (c0 << 8) | (c1 << 16) | (c2 << 24)) << 32);
+}
+template <int N>
+__device__ __forceinline__ void write_obs_row(const Table<N> &tb, uint32_t vmask, PK_GLOBAL double *o) {
+    const int who = tb.active;
+    o[0] = who; o[1] = tb.turn; o[2] = tb.min_raise;
+    for (int a = 0; a < PK_NUM_MOVES; ++a) o[3 + a] = (vmask >> a) & 1;
+    double h0 = 0.0, h1 = 0.0;
+    PK_FOR(p, N) h0 = (who == p) ? (double)tb.card(5 + 2 * p) : h0; h1 = (who == p) ? (double)tb.card(6 + 2 * p) : h1; PK_END
+    o[10] = h0; o[11] = h1;                                                    // game.py:385-389
+    PK_FOR(c, 5) o[12 + c] = (tb.turn != 0 && c < tb.turn + 2) ? (double)tb.card(c) : -1.0; PK_END   // game.py:278
+    PK_FOR(p, N) o[17 + p] = tb.credits[p]; o[17 + N + p] = tb.bets[p]; o[17 + 2 * N + p] = tb.pending[p]; PK_END
+}
+// ... and the compact one (layout: pokerl_hip.h PK_OBS_PACKED_BYTES; k_obs_packed's row): 16 header bytes + (3N+1) f64
+template <int N>
+__device__ __forceinline__ void write_obs_packed_row(const Table<N> &tb, uint32_t vmask, PK_GLOBAL uint64_t *o) {
+    const uint32_t who = (uint32_t)tb.active;
+    uint32_t h0 = 0, h1 = 0;
+    PK_FOR(p, N) h0 = (who == (uint32_t)p) ? tb.card(5 + 2 * p) : h0; h1 = (who == (uint32_t)p) ? tb.card(6 + 2 * p) : h1; PK_END
+    uint32_t cc[5];
+    PK_FOR(c, 5) cc[c] = (tb.turn != 0 && c < tb.turn + 2) ? tb.card(c) : 0xffu; PK_END
+    o[0] = obs_packed_header0(who, (uint32_t)tb.turn, vmask, h0, h1, cc[0], cc[1], cc[2]);
+    o[1] = (uint64_t)cc[3] | ((uint64_t)cc[4] << 8);
+    const auto m = (PK_GLOBAL double *)(o + 2);
+    m[0] = tb.min_raise;
+    PK_FOR(p, N) m[1 + p] = tb.credits[p]; m[1 + N + p] = tb.bets[p]; m[1 + 2 * N + p] = tb.pending[p]; PK_END
+}
+
 template <int N>
 __global__ void __launch_bounds__(PK_TABLE_BLOCK) k_reset(State S, Hot H, const uint8_t *mask, int mask_bits, int dealer) {  // Game.reset, game.py:397-412
     int t = blockIdx.x * H.tpb + threadIdx.x;
@@ -107,7 +139,8 @@ __global__ void __launch_bounds__(PK_TABLE_BLOCK) k_pick(State S, Hot H, int pol
 // would run empty).
 // k_step's formal parameter = the layout of its kernarg segment: the two output pointers are read through the kernarg
 // segment pointer after the loop (see EnvArgs below for why).
-struct StepKernArgs { const State *Sp; Hot H; const int32_t *actions; uint8_t *flags, *terr; int park, auto_reset; uint8_t *ready; int max_end; };
+struct StepKernArgs { const State *Sp; Hot H; const int32_t *actions; uint8_t *flags, *terr; int park, auto_reset; uint8_t *ready; int max_end;
+                      double *obs; uint8_t *obs_packed; };   // pk_set_step_obs: the StateView row of the player to act, from registers (NULL: off)
 // BOUNDED (pk_step_async_d, only with the external policy): a launch runs at most `max_end` end_blocks.  A Game.step that rolls on through
 // further hands (the reference's next_player loop plays whole hands nobody can act in, game.py:607-611: ~1 table in 10 000 per step, yet
 // the SLOWEST table of 65 536 needs ~4 hands and every end_hand is ~3 us of serial work) stays IN FLIGHT -- its machine state is in the
@@ -242,6 +275,19 @@ __device__ __forceinline__ void rollout_body(const State *__restrict__ Sp, const
                 if (terr_out) terr_out[t] = te;
             }
             if constexpr (BOUNDED) as_global(ext->ready)[t] = returned ? 1 : 0;
+            // game.active_state (game.py:323-332: the StateView of the player to act, built right after every step) for a learner that drives
+            // Game.step itself: the row of every table whose step has returned -- also of one whose action was refused (its table is as it
+            // was), and after an auto-reset the first view of the new game -- from the registers the step left, not by a second launch that
+            // re-reads the table this one has just stored (k_obs / k_obs_packed write the same rows).  A step still in flight: row untouched.
+            if (returned) {
+                const auto obs = as_global(ext->obs);
+                const auto obs_packed = as_global(ext->obs_packed);
+                if (obs || obs_packed) {
+                    const uint32_t vmask = tb.valid_mask(high_bet);
+                    if (obs) write_obs_row<N>(tb, vmask, obs + (size_t)t * PK_OBS_DIM(N));
+                    if (obs_packed) write_obs_packed_row<N>(tb, vmask, (PK_GLOBAL uint64_t *)(obs_packed + (size_t)t * PK_OBS_PACKED_BYTES(N)));
+                }
+            }
         }
         PK_PROF(tb.prof.flush(S.prof);)
         return;                                                                    // Game.step is not counted as rollout work
@@ -285,7 +331,12 @@ __global__ void __launch_bounds__(PK_TABLE_BLOCK, PK_WAVES_PER_SIMD_N(N)) k_step
 template <int N>
 __global__ void __launch_bounds__(PK_TABLE_BLOCK, PK_WAVES_PER_SIMD_N(N)) k_step_async(StepKernArgs) {   // pk_step_async_d: bounded launches
     const StepKernArgs *ka = (const StepKernArgs *)__builtin_amdgcn_kernarg_segment_ptr();
-    const Hot H = ka->H;
+    Hot H = ka->H;
+    // The first 32 bytes of the argument block (Sp, H.fresh, the blinds) arrive as ONE s_load_dwordx8; the blinds are live across the whole loop, and
+    // with six and fourteen seats the allocator spilled the eight-register tuple as a unit -- then rematerialised the load instead, leaving a dead
+    // 36-byte stack object behind that made every dispatch set up scratch memory (.amdhsa_private_segment_fixed_size 36 with not one
+    // scratch instruction in the kernel).  Passing the two doubles through an empty asm makes them registers of their own; the tuple dies at once.
+    asm volatile("" : "+s"(H.big_blind), "+s"(H.small_blind));
     rollout_body<N, false, PK_POLICY_EXTERNAL, 1, true>(ka->Sp, H, 0, ka->auto_reset, ka->park, PK_WAVE, 1, ka->actions, ka);
 }
 template <int N>
@@ -433,10 +484,6 @@ __device__ __constant__ const EnvTransitions g_env_transitions{};
 // to act inside a PokerGameEnv.step / .reset, the table YIELDS (ready[t] = 2, who[t] = the seat, obs row = that seat's
 // StateView), its env call stays in flight exactly like a step that ran out of passes, and the next launch takes
 // actions[t] as that seat's action.  reset_req[t] != 0 starts PokerGameEnv.reset() on that table instead of a step.
-// First 8 bytes of a packed observation row (pokerl_hip.h PK_OBS_PACKED_BYTES): seat, turn, valid mask, hole cards, flop.
-__device__ __forceinline__ uint64_t obs_packed_header0(uint32_t who, uint32_t turn, uint32_t vmask, uint32_t h0, uint32_t h1, uint32_t c0, uint32_t c1, uint32_t c2) {
-    return (uint64_t)(who | (turn << 8) | ((vmask & 0x7fu) << 16) | (h0 << 24)) | ((uint64_t)(h1 | (c0 << 8) | (c1 << 16) | (c2 << 24)) << 32);
-}
 
 // The arguments of the PokerGameEnv.step kernels as ONE block, read through the kernarg segment pointer WHERE A FIELD IS USED:
 // formal kernel parameters are all s_load-ed in the entry block and then live across the whole step loop -- the seven output
@@ -662,31 +709,9 @@ __device__ __forceinline__ void env_step_body() {
         terr[t] = (uint8_t)te;
     }
     const auto obs = as_global(A.obs);
-    if (obs) {  // Game.StateView(player to act), game.py:117-131, from registers (same row k_obs builds from HBM)
-        const auto o = obs + (size_t)t * PK_OBS_DIM(N);
-        const int who = tb.active;
-        o[0] = who; o[1] = tb.turn; o[2] = tb.min_raise;
-        for (int a = 0; a < PK_NUM_MOVES; ++a) o[3 + a] = (vmask >> a) & 1;
-        double h0 = 0.0, h1 = 0.0;
-        PK_FOR(p, N) h0 = (who == p) ? (double)tb.card(5 + 2 * p) : h0; h1 = (who == p) ? (double)tb.card(6 + 2 * p) : h1; PK_END
-        o[10] = h0; o[11] = h1;                                                    // game.py:385-389
-        PK_FOR(c, 5) o[12 + c] = (tb.turn != 0 && c < tb.turn + 2) ? (double)tb.card(c) : -1.0; PK_END   // game.py:278
-        PK_FOR(p, N) o[17 + p] = tb.credits[p]; o[17 + N + p] = tb.bets[p]; o[17 + 2 * N + p] = tb.pending[p]; PK_END
-    }
+    if (obs) write_obs_row<N>(tb, vmask, obs + (size_t)t * PK_OBS_DIM(N));      // Game.StateView(player to act), from registers
     const auto obs_packed = as_global(A.obs_packed);
-    if (obs_packed) {  // the same row, compact (layout: pokerl_hip.h PK_OBS_PACKED_BYTES): 16 header bytes + (3N+1) f64
-        const auto o = (PK_GLOBAL uint64_t *)(obs_packed + (size_t)t * PK_OBS_PACKED_BYTES(N));
-        const uint32_t who = (uint32_t)tb.active;
-        uint32_t h0 = 0, h1 = 0;
-        PK_FOR(p, N) h0 = (who == (uint32_t)p) ? tb.card(5 + 2 * p) : h0; h1 = (who == (uint32_t)p) ? tb.card(6 + 2 * p) : h1; PK_END
-        uint32_t cc[5];
-        PK_FOR(c, 5) cc[c] = (tb.turn != 0 && c < tb.turn + 2) ? tb.card(c) : 0xffu; PK_END
-        o[0] = obs_packed_header0(who, (uint32_t)tb.turn, vmask, h0, h1, cc[0], cc[1], cc[2]);
-        o[1] = (uint64_t)cc[3] | ((uint64_t)cc[4] << 8);
-        const auto m = (PK_GLOBAL double *)(o + 2);
-        m[0] = tb.min_raise;
-        PK_FOR(p, N) m[1 + p] = tb.credits[p]; m[1 + N + p] = tb.bets[p]; m[1 + 2 * N + p] = tb.pending[p]; PK_END
-    }
+    if (obs_packed) write_obs_packed_row<N>(tb, vmask, (PK_GLOBAL uint64_t *)(obs_packed + (size_t)t * PK_OBS_PACKED_BYTES(N)));
 }
 template <int N>
 __global__ void __launch_bounds__(PK_TABLE_BLOCK) k_env_step(EnvKernArgs) { env_step_body<N, false, false>(); }

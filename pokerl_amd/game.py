@@ -129,6 +129,13 @@ class VecGame:
         L.check(self._lib.pk_step_async_d(self._h, self._dptr(actions_d), self._dptr(flags_d), self._dptr(terr_d), self._dptr(ready_d),
                                           int(max_hands), int(bool(auto_reset))), self._h)
 
+    def set_step_obs(self, obs_d=None, obs_packed_d=None):
+        """`game.active_state` (game.py:323-332) from the step kernels themselves (pk_set_step_obs): from now on step_d / step_async_d (and
+        step) write the StateView row of the player to act of every table whose step returned into obs_d (f64 [T, PK_OBS_DIM(N)], the row of
+        observations_of(None)) and / or obs_packed_d ([T] rows of state_view.packed_dtype(N)) -- device buffers the caller keeps alive;
+        None, None switches it off.  One launch per step instead of step + observation."""
+        L.check(self._lib.pk_set_step_obs(self._h, self._dptr(obs_d), self._dptr(obs_packed_d)), self._h)
+
     def pick_actions_d(self, actions_d, policy=0):
         """The action the in-kernel agent `policy` takes on every table -> actions_d i32[T] (pk_pick_actions_d)."""
         L.check(self._lib.pk_pick_actions_d(self._h, int(policy), self._dptr(actions_d)), self._h)

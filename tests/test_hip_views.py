@@ -574,3 +574,152 @@ def test_packed_rows_from_the_env_kernels_and_the_pinned_host_path(O):
     pin.free(); ea.close(); eb.close()
     for b in bufs.values():
         b.free()
+
+
+@pytest.mark.parametrize("name", GU.VIEW_SETS)
+def test_step_kernels_write_the_reference_state_views(HB, name):
+    """SURVEY f2 on row a7's path: the Game.step kernels write `game.active_state` (game.py:323-332) themselves (pk_set_step_obs) -- the
+    dense and the packed row of the player to act, from registers, in the step's own launch.  Against the reference's recorded
+    StateView.__getstate__() tuples after every step (the `views_*` fixtures), and against the getter kernels' rows."""
+    from pokerl_amd import StateView, packed_dtype, unpack_obs
+    from pokerl_amd.hipmem import DeviceBuffer
+    meta = GU.load_json(name)
+    h = HB.from_meta(meta)
+    g = h.g
+    h.reset(dealer=meta.get("dealer", 0))
+    n, T = meta["n"], meta["tables"]
+    D, dt = 17 + 3 * n, packed_dtype(n)
+    act, flags, terr = DeviceBuffer(T * 4), DeviceBuffer(T), DeviceBuffer(T)
+    obs, packed = DeviceBuffer(T * D * 8), DeviceBuffer(T * dt.itemsize)
+    g.set_step_obs(obs, packed)
+    for s in range(meta["steps"]):
+        acts = np.array(meta["actions"][s], np.int32)
+        act.upload(acts)
+        g.step_d(act, flags, terr)
+        g.sync()
+        assert flags.download(np.uint8, T).tolist() == meta["flags"][s] and not terr.download(np.uint8, T).any()
+        dense = obs.download(np.float64, T * D).reshape(T, D)
+        rows = packed.download(np.uint8, T * dt.itemsize).view(dt)
+        rec = meta["views"][s]
+        for t in range(T):
+            assert _tuple_of(StateView(dense[t], n)) == rec[t]["active"], (s, t)
+        assert unpack_obs(rows, n).tobytes() == dense.tobytes(), s
+        assert dense.tobytes() == g.observations_of(None).tobytes() and rows.tobytes() == g.observations_packed_of(None).tobytes(), s
+        reset = (np.array(meta["flags"][s], np.uint8) & 1).astype(np.uint8)
+        if reset.any():
+            h.reset(mask=reset)
+    g.set_step_obs(None, None)
+    for b in (act, flags, terr, obs, packed):
+        b.free()
+
+
+def test_step_kernels_write_the_observation_rows(HB, O):
+    """pk_set_step_obs at full size and in every form of the step call: pk_step_d + pk_reset_d, pk_step_auto_d (the row after an auto-reset is the
+    first view of the NEW game), pk_step_async_d (only the rows of ready tables are written: a step in flight keeps the row it had), with
+    invalid actions in between (row of the untouched table) -- each row byte for byte what pk_get_obs_d / pk_get_obs_packed_d deliver right
+    after the call, the steps themselves against the oracle.  One buffer at a time, too (dense only / packed only)."""
+    from pokerl_amd import _lib as L, packed_dtype
+    from pokerl_amd.hipmem import DeviceBuffer
+    lib = L.lib()
+    for T, N, steps, mode in ((65536 + 19, 6, 24, "both"), (1500, 9, 120, "both"), (4096, 2, 60, "dense"), (700, 16, 60, "packed"), (300, 13, 50, "both")):
+        D, dt = 17 + 3 * N, packed_dtype(N)
+        P = dt.itemsize
+        hs = [HB(T, N, seed=31337) for _ in range(3)]            # 0: step_d + reset_d, 1: step_auto_d, 2: step_async_d (auto-reset)
+        o = O.OracleGame(T, N, seed=31337)
+        o.reset()
+        bufs = []
+        for hb in hs:
+            hb.g.reset()
+            b = dict(act=DeviceBuffer(T * 4), flags=DeviceBuffer(T), terr=DeviceBuffer(T), ready=DeviceBuffer(T),
+                     obs=DeviceBuffer(T * D * 8), packed=DeviceBuffer(T * P), ref=DeviceBuffer(T * D * 8), refp=DeviceBuffer(T * P))
+            hb.g.set_step_obs(b["obs"] if mode != "packed" else None, b["packed"] if mode != "dense" else None)
+            bufs.append(b)
+
+        def rows_of(g, b):                                       # (fused dense, fused packed, getter dense, getter packed) after the call
+            L.check(lib.pk_get_obs_d(g._h, -1, b["ref"].ptr), g._h)
+            L.check(lib.pk_get_obs_packed_d(g._h, -1, b["refp"].ptr), g._h)
+            g.sync()
+            return (b["obs"].download(np.float64, T * D).reshape(T, D), b["packed"].download(np.uint8, T * P).reshape(T, P),
+                    b["ref"].download(np.float64, T * D).reshape(T, D), b["refp"].download(np.uint8, T * P).reshape(T, P))
+
+        def check_rows(g, b, mask, where):
+            fd, fp, rd, rp = rows_of(g, b)
+            if mode != "packed":
+                bad = mask & (fd.view(np.uint64) != rd.view(np.uint64)).any(axis=1)
+                assert not bad.any(), (where, "dense", np.nonzero(bad)[0][:5].tolist(), int(bad.sum()))
+            if mode != "dense":
+                bad = mask & (fp != rp).any(axis=1)
+                assert not bad.any(), (where, "packed", np.nonzero(bad)[0][:5].tolist(), int(bad.sum()))
+            return fd, fp
+
+        all_t = np.ones(T, bool)
+        inflight_seen = 0
+        for s in range(steps):
+            a = o.pick_actions(0)
+            if s % 5 == 2:                                       # some tables get an invalid action: untouched, row of the table as it is
+                a = np.where(np.arange(T) % 13 == s % 13, 8, a).astype(np.int32)
+            fo, eo = o.step(a)
+            over = ((fo & 1) | ((eo & 4) >> 2)).astype(np.uint8)
+            where = "T=%d N=%d step %d" % (T, N, s)
+            # ---- synchronous, caller's reset: the row is that of the finished game until reset_d; refresh after the reset is the caller's business
+            g, b = hs[0].g, bufs[0]
+            b["act"].upload(a)
+            g.step_d(b["act"], b["flags"], b["terr"])
+            g.sync()
+            assert np.array_equal(b["flags"].download(np.uint8, T), fo) and np.array_equal(b["terr"].download(np.uint8, T), eo), where
+            check_rows(g, b, all_t, where + " step_d")
+            if over.any():
+                g.reset(mask=over)
+            # ---- synchronous with the reset inside the launch: the row is the first view of the new game
+            g, b = hs[1].g, bufs[1]
+            b["act"].upload(a)
+            g.step_d(b["act"], b["flags"], b["terr"], auto_reset=True)
+            g.sync()
+            assert np.array_equal(b["terr"].download(np.uint8, T), eo), where
+            check_rows(g, b, all_t, where + " step_auto_d")
+            # ---- bounded launches: rows of the ready tables only; a table in flight keeps the (poisoned) row
+            g, b = hs[2].g, bufs[2]
+            b["act"].upload(a)                                   # (every table is idle here: the previous iteration drained what stayed in flight)
+            if mode != "packed":
+                b["obs"].upload(np.full(T * D, -7.25, np.float64))
+            if mode != "dense":
+                b["packed"].upload(np.full(T * P, 0xA5, np.uint8))
+            g.step_async_d(b["act"], b["flags"], b["terr"], b["ready"], max_hands=1, auto_reset=True)
+            g.sync()
+            r = b["ready"].download(np.uint8, T) != 0
+            if not r.all():                                      # steps stayed in flight: their rows are untouched; drain them, then every row is written
+                inflight_seen += int((~r).sum())
+                fd, fp = check_rows(g, b, r, where + " step_async_d (ready rows)")
+                if mode != "packed":
+                    assert (fd[~r] == -7.25).all(), where
+                if mode != "dense":
+                    assert (fp[~r] == 0xA5).all(), where
+                b["act"].upload(np.full(T, -1, np.int32))        # drain: ready tables get "no step" (an invalid action: untouched, row rewritten)
+                g.step_async_d(b["act"], b["flags"], b["terr"], b["ready"], max_hands=0, auto_reset=True)
+                g.sync()
+                assert (b["ready"].download(np.uint8, T) != 0).all()
+            check_rows(g, b, all_t, where + " step_async_d")
+            if over.any():
+                o.reset(mask=over)
+        GU.assert_snap(hs[0].snapshot(), o.snapshot(), "step_d + obs T=%d N=%d" % (T, N))
+        GU.assert_snap(hs[1].snapshot(), o.snapshot(), "step_auto_d + obs T=%d N=%d" % (T, N))
+        GU.assert_snap(hs[2].snapshot(), o.snapshot(), "step_async_d + obs T=%d N=%d" % (T, N))
+        if T > 60000:
+            assert inflight_seen > 0
+        # the rows are the Game.step kernels' only: a rollout, a reset and the env kernels leave the caller's buffers alone; PK_E_BUSY while in flight
+        g, b = hs[1].g, bufs[1]
+        b["obs"].upload(np.full(T * D, -7.25, np.float64)); b["packed"].upload(np.full(T * P, 0xA5, np.uint8))
+        g.rollout(3, 0); g.reset()
+        assert (b["obs"].download(np.float64, T * D) == -7.25).all() and (b["packed"].download(np.uint8, T * P) == 0xA5).all()
+        g, b = hs[2].g, bufs[2]
+        g.pick_actions_d(b["act"], 0)
+        g.step_async_d(b["act"], b["flags"], b["terr"], b["ready"], max_hands=1, auto_reset=True)
+        assert lib.pk_set_step_obs(g._h, None, None) == L.PK_E_BUSY
+        b["act"].upload(np.full(T, -1, np.int32))
+        g.step_async_d(b["act"], b["flags"], b["terr"], b["ready"], max_hands=0, auto_reset=True); g.sync()
+        assert lib.pk_set_step_obs(g._h, C.c_void_p(b["obs"].ptr.value + 4), None) == L.PK_E_INVALID_ARG       # 8-byte aligned buffers
+        for hb, b in zip(hs, bufs):
+            hb.g.set_step_obs(None, None)
+            for x in b.values():
+                x.free()
+            hb.g.close()
