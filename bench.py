@@ -179,6 +179,14 @@ def profile_summary(tables, players, policy, kern_steps=None):
     return best[2], best[3]
 
 
+def profile_stale(summary):
+    """True when a committed counter summary was measured on OTHER kernel sources than the library now running (its `source_hash` -- stamped by
+    the tools/summarize_*.py scripts from pk_build_info -- differs, or it predates the stamp): every figure derived from it is then a figure
+    of an older kernel."""
+    from pokerl_amd import _lib as L
+    return summary.get("source_hash") != L.source_hash()
+
+
 def evaluator_leg(device, log2_m=None, reps=20):
     """Second half of the metric as a stand-alone kernel: pk_eval7_d streams 2^28 device-resident 7-card hands
     (2 GiB in, 1 GiB out: far beyond L2 / Infinity Cache) -- 12 algorithmic bytes per evaluation, HBM by definition.
@@ -200,7 +208,7 @@ def evaluator_leg(device, log2_m=None, reps=20):
     if src:
         d = json.load(open(src))
         per_eval = d.get("hbm_traffic_bytes_per_launch", 0) / float(d.get("hands_per_launch", 1))
-        roof.update({"traffic": per_eval * m, "traffic_unit": "HBM bytes per launch of this size (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE, KiB), = %.3f x algorithmic" % (per_eval / 12.0),
+        roof.update({"profile_stale": profile_stale(d), "traffic": per_eval * m, "traffic_unit": "HBM bytes per launch of this size (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE, KiB), = %.3f x algorithmic" % (per_eval / 12.0),
                      "source": os.path.basename(src), "valu_insts_per_eval": d.get("valu_wave_insts_per_eval_x64"),
                      "lds_lookups_per_eval": d.get("lds_wave_insts_per_eval_x64"),
                      "valu_issue_frac_of_peak": d.get("valu_issue_frac_of_peak"),
@@ -407,7 +415,7 @@ def env_roofline(res):
             resident = d.get("waves_per_simd_resident") or 1.0
             ceil_rate, ceil_cyc = mix_ceiling(resident)
             traffic = d.get("hbm_traffic_bytes_per_launch")
-            roof.update({"achieved": rate, "frac": rate / VALU_PEAK_WAVE_INSTS_PER_S, "source": src,
+            roof.update({"achieved": rate, "frac": rate / VALU_PEAK_WAVE_INSTS_PER_S, "source": src, "profile_stale": profile_stale(d),
                          "valu_wave_insts_per_launch": per_launch, "lanes_active": d.get("lanes_active"),
                          "waves_per_simd": resident, "wait_any_frac": d.get("wait_any_frac_of_wave_cycles"),
                          "ceiling_mix": {"peak": ceil_rate, "frac_of_ceiling": rate / ceil_rate, "cycles_per_instruction": ceil_cyc,
@@ -567,6 +575,7 @@ def rollout_roofline(w, world):
         pmc = d.get("pmc_per_full_launch", {})
         roof["traffic"] = hbm["traffic"] = d.get("hbm_traffic_bytes_per_launch")
         roof["traffic_source"] = src
+        roof["profile_stale"] = profile_stale(d)
         per_wave_step = d.get("valu_insts_per_wave_step")
         waves = pmc.get("SQ_WAVES")
         if per_wave_step and waves:
@@ -761,7 +770,7 @@ def step_line(res, name):
     if prof:
         d, src = prof
         mine = [k for k in d.get("loop_kernels", d.get("kernels", {})) if not (res["replay"] and k == "k_pick") and not (res["fused_reset"] and k == "k_reset")]   # the kernels of THIS leg's loop iteration
-        roof.update({"traffic": sum(d["kernels"][k].get("hbm_traffic_bytes_per_launch", 0.0) for k in mine), "source": src,
+        roof.update({"traffic": sum(d["kernels"][k].get("hbm_traffic_bytes_per_launch", 0.0) for k in mine), "source": src, "profile_stale": profile_stale(d),
                      "k_step_ms_rocprof": d.get("k_step_avg_ms"), "k_step_ms_rocprof_min_median_max": d.get("k_step_min_median_max_ms"), "kernels_in_traffic": mine,
                      "traffic_unit": "HBM bytes per loop iteration (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE, KiB), summed over its kernels"})
     return {"name": name, "metric": "Game.step env-steps/s (caller-supplied actions, device-resident)", "value": rate, "unit": "env-steps/s",
@@ -791,6 +800,8 @@ def _short_roofline(rf, with_alg=True):
            if k in rf}
     if rf.get("source"):
         out["source"] = rf["source"]
+    if "profile_stale" in rf:
+        out["profile_stale"] = bool(rf["profile_stale"])
     hb = rf.get("hbm_algorithmic")
     if with_alg and isinstance(hb, dict):
         out["hbm_algorithmic"] = {"frac": _sig(hb.get("frac"))}
@@ -807,6 +818,8 @@ def _short_leg(x):
            "kernel_ms": _sig(x.get("kernel_ms")), "bound": rf.get("bound"), "frac": _sig(rf.get("frac")), "hbm_frac": _sig(hbm_frac)}
     if x.get("hand_evals_per_s") and x.get("showdown_heavy"):
         out["hand_evals_per_s"] = _sig(x["hand_evals_per_s"])
+    if rf.get("profile_stale"):          # (only when true: a leg without the key rests on a summary of the running library's sources, or on none)
+        out["profile_stale"] = True
     return out
 
 
@@ -814,8 +827,8 @@ def compact_line(full):
     """The driver-facing line (<= LINE_LIMIT bytes) out of the full result: the contract's keys, `roofline`, `cpu_baseline`, the
     evaluator and one short entry per extra leg.  Prose and arrays stay in DETAIL_FILE."""
     keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
-            "dtype", "data")
-    line = {k: _sig(full[k]) for k in keep}
+            "dtype", "data", "reps", "samples", "timed_steps_per_table", "timed_s", "lib")
+    line = {k: _sig(full[k]) for k in keep if k in full}     # (the self-check keys are absent from results of earlier rounds)
     c = full["config"]
     line["config"] = {"workload": c["workload"], "tables_per_gpu": c["tables_per_gpu"], "num_players": c["num_players"],
                       "policy": c["policy"], "kernel": c.get("kernel_short") or str(c.get("kernel", ""))[:60],
@@ -826,6 +839,8 @@ def compact_line(full):
         ev = full["evaluator"]
         line["evaluator"] = {"hand_evals_per_s": _sig(ev["hand_evals_per_s"]), "frac": _sig(ev["roofline"]["frac"]),
                              "bound": "hbm", "kernel_ms": _sig(ev["kernel_ms"])}
+        if ev["roofline"].get("profile_stale"):
+            line["evaluator"]["profile_stale"] = True
     if "cpu_baseline" in full:
         cb = full["cpu_baseline"]
         line["cpu_baseline"] = {"value": _sig(cb["value"]), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
@@ -912,6 +927,11 @@ def extra_workloads(ctx, device):
     return out
 
 
+def pk_lib_info():
+    from pokerl_amd import _lib as L
+    return L.lib().pk_build_info().decode()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -966,8 +986,9 @@ def main():
         res = step_workload(ctx, device, args.tables, args.players, args.steps, args.warmup, args.step_replay, not args.step_unfused_reset, args.step_async,
                             args.step_obs, not args.step_obs_separate)
         if ctx.rank == 0:
-            print(json.dumps(step_line(res, "Game.step device-resident loop, %d x %d%s%s" % (args.tables, args.players, ", replayed actions" if args.step_replay else "",
-                                                                                              ", bounded launches (%d hand end(s) each)" % args.step_async if args.step_async else ""))))
+            print(json.dumps(step_line(res, "Game.step device-resident loop, %d x %d%s%s%s" % (args.tables, args.players, ", replayed actions" if args.step_replay else "",
+                                                                                                ", bounded launches (%d hand end(s) each)" % args.step_async if args.step_async else "",
+                                                                                                "" if not args.step_obs else ", %s observation rows %s" % (args.step_obs, "by a second launch" if args.step_obs_separate else "from the step kernel")))))
         ctx.close()
         return
     policy = 0 if args.policy == "random" else 1
@@ -985,6 +1006,8 @@ def main():
             "warmup": args.warmup, "ms_per_step": w["seconds"] / (K * reps) * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "reps": reps, "samples": len(w["sample_s"]), "sample_seconds": w["sample_s"], "sample_device_ms": w["sample_dev_ms"],
+            # self-check: ms_per_step (of the median sample) x timed_steps_per_table ~ timed_s (all samples) <= the run's wall clock
+            "timed_steps_per_table": K * reps * len(w["sample_s"]), "timed_s": sum(w["sample_s"]), "lib": pk_lib_info(),
             "timing": "each sample = %d block(s) of %d steps per table, launched back to back and completed by a sync inside "
                       "the timed region; value = steps of one sample / MEDIAN sample time (MAX over ranks per sample)" % (reps, K),
             "config": {"workload": "%d tables/GPU x %d GPU(s), num_players=%d, %s agents in-kernel (Philox4x32-10), "

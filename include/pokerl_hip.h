@@ -112,6 +112,10 @@ extern "C" {
 typedef struct pk_handle pk_handle;
 
 int pk_abi_version(void);
+/* "abi=<PK_ABI_VERSION> src=<16 hex digits>": the hash pokerl_amd/build.py takes over the kernel sources and compiler flags this library was built
+ * from (comments and white space excluded).  Every profiles/ *_summary.json carries the hash of the library it was measured on; bench.py marks a
+ * roofline figure that rests on a summary of OTHER sources `profile_stale`. */
+const char *pk_build_info(void);
 /* Number of visible HIP devices (0 if none / no driver). */
 int pk_device_count(void);
 const char *pk_last_error(const pk_handle *h); /* h may be NULL: last create/standalone error of this thread */

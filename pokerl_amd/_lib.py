@@ -31,7 +31,7 @@ SYMBOLS = ["pk_abi_version", "pk_device_count", "pk_last_error", "pk_create", "p
            "pk_pick_actions_d", "pk_flush", "pk_get_owed", "pk_env_step_fused_d", "pk_env_step_async_d", "pk_set_tuning", "pk_get_stream", "pk_set_stream", "pk_wait_event",
            "pk_record_event", "pk_use_own_stream", "pk_set_coalesce", "pk_get_launch_stats", "pk_env_step_multi_d", "pk_env_end_multi_d", "pk_get_f64_d", "pk_set_env_batches", "pk_env_last_range",
            "pk_get_obs_packed", "pk_get_obs_packed_d", "pk_set_env_obs_packed", "pk_host_alloc", "pk_host_free", "pk_check_actions",
-           "pk_env_step_begin", "pk_env_step_end", "pk_reset_d", "pk_step_auto_d", "pk_stream_pool_drain", "pk_step_async_d", "pk_set_step_obs"]
+           "pk_env_step_begin", "pk_env_step_end", "pk_reset_d", "pk_step_auto_d", "pk_stream_pool_drain", "pk_step_async_d", "pk_set_step_obs", "pk_build_info"]
 
 
 class PokerlHipError(RuntimeError):
@@ -55,6 +55,7 @@ def lib():
     L.pk_device_count.restype = C.c_int
     L.pk_last_error.restype = C.c_char_p
     L.pk_last_error.argtypes = [_vp]
+    L.pk_build_info.restype = C.c_char_p
     L.pk_create.argtypes = [C.POINTER(_vp), C.c_int, C.c_int, C.c_int, _vp, C.c_double, C.c_double, C.c_double,
                             C.c_int, C.c_uint64, C.c_uint32]
     L.pk_destroy.argtypes = [_vp]
@@ -124,7 +125,7 @@ def lib():
     L.pk_record_event.argtypes = [_vp, _vp]
     L.pk_time_rollout.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), _vp]
     for name in SYMBOLS:
-        if name != "pk_last_error":
+        if name not in ("pk_last_error", "pk_build_info"):
             getattr(L, name).restype = C.c_int
     if L.pk_abi_version() != ABI_VERSION:
         raise PokerlHipError("libpokerl_hip.so ABI version mismatch")
@@ -141,6 +142,12 @@ def check(rc, handle=None, allow_table_errors=False):
         return rc
     msg = lib().pk_last_error(handle)
     raise PokerlHipError("libpokerl_hip: error %d: %s" % (rc, msg.decode() if msg else "?"))
+
+
+def source_hash():
+    """The hash of the kernel sources the loaded library was built from (pk_build_info; pokerl_amd/build.py source_hash)."""
+    info = lib().pk_build_info().decode()
+    return info.split("src=")[-1]
 
 
 def device_count():

@@ -30,6 +30,26 @@ POST_MISCHED_OFF_SEATS = (4, 6)
 def table_flags(seats):
     return COMPILE_FLAGS + (["-mllvm", "-enable-post-misched=0"] if seats in POST_MISCHED_OFF_SEATS else [])
 
+def source_hash():
+    """16 hex digits over what the kernels are compiled from: csrc/* and the ABI header with comments and white space removed (a reworded
+    comment must not make every committed profile look stale), the compiler flags and the per-seat-count flag choices.  Embedded in the library
+    (pk_build_info) and stamped into every profiles/*_summary.json, so that bench.py can tell whether a committed counter summary describes
+    the library it is running (`profile_stale`)."""
+    import hashlib
+    import re
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(CSRC)) + [HEADERS[-1]]:
+        path = f if os.path.isabs(f) else os.path.join(CSRC, f)
+        if not path.endswith((".hip", ".hpp", ".h")):
+            continue
+        txt = open(path).read()
+        txt = re.sub(r"/\*.*?\*/", " ", txt, flags=re.S)
+        txt = re.sub(r"//[^\n]*", " ", txt)
+        h.update(os.path.basename(path).encode() + b"\0" + " ".join(txt.split()).encode() + b"\0")
+    h.update(repr((FLAGS, POST_MISCHED_OFF_SEATS, SEATS)).encode())
+    return h.hexdigest()[:16]
+
+
 def hipcc():
     exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(exe):
@@ -52,6 +72,8 @@ def _compile(job):
     src, obj, defines, verbose = job
     seats = [int(d.split("=")[1]) for d in defines if d.startswith("-DPK_SEATS=")]
     cmd = [hipcc()] + (table_flags(seats[0]) if seats else COMPILE_FLAGS) + defines + ["-c", os.path.join(CSRC, src), "-o", obj]
+    if not seats:      # pk_api.hip carries the hash of ALL kernel sources (pk_build_info)
+        cmd.insert(-4, '-DPK_SOURCE_HASH="%s"' % source_hash())
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

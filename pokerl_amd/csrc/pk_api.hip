@@ -191,6 +191,9 @@ static inline int env_grid(const pk_handle *h) { return (h->T + h->env_tpb - 1) 
 // (16: asynchronous env.step +1.3 % over 32 with the round's final kernels, synchronous unchanged; 12 the same, 24 half of it)
 static inline int env_park(const pk_handle *h) { return scaled_park(h, 16, h->env_tpb); }
 static inline int flat_grid(size_t n) { return (int)((n + 255) / 256); }
+// the observation getters: one table per lane, 64-thread workgroups -- 65 536 tables are 1 024 waves, one per SIMD (256-thread blocks put them on a quarter of the CUs' schedulers' slots)
+#define OBS_BLOCK 64
+static inline int obs_grid(int T) { return (T + OBS_BLOCK - 1) / OBS_BLOCK; }
 
 // One fused rollout launch: every table owes k_steps more steps; the launch ends once fewer than `endk` lanes of a
 // wave have work left (endk == 1: runs to completion).
@@ -356,6 +359,11 @@ static inline EnvKernArgs with_packed(const pk_handle *h, EnvKernArgs ka) { ka.A
 extern "C" {
 
 int pk_abi_version(void) { return PK_ABI_VERSION; }
+
+#ifndef PK_SOURCE_HASH
+#define PK_SOURCE_HASH "unknown"
+#endif
+const char *pk_build_info(void) { return "abi=" PK_STR(PK_ABI_VERSION) " src=" PK_SOURCE_HASH; }
 
 int pk_device_count(void) {
     int n = 0;
@@ -793,7 +801,7 @@ int pk_get_obs(pk_handle *h, int player, double *out) {
     if (!h || !out || bad_player(h, player)) return h ? h->fail(PK_E_INVALID_ARG, "pk_get_obs: bad argument") : PK_E_INVALID_ARG;
     size_t bytes = (size_t)h->T * PK_OBS_DIM(h->N) * 8;
     return export_to_host(h, out, bytes, [&] {
-        hipLaunchKernelGGL(k_obs, dim3(flat_grid(h->T)), dim3(256), 0, h->stream, h->S, h->N, player, (double *)h->d_export);
+        hipLaunchKernelGGL(k_obs, dim3(obs_grid(h->T)), dim3(OBS_BLOCK), 0, h->stream, h->S, h->N, player, (double *)h->d_export);
     });
 }
 
@@ -801,7 +809,7 @@ int pk_get_obs_d(pk_handle *h, int player, double *out_d) {
     if (!h || !out_d || bad_player(h, player)) return h ? h->fail(PK_E_INVALID_ARG, "pk_get_obs_d: bad argument") : PK_E_INVALID_ARG;
     ON_DEVICE(h);
     FLUSH_READER(h);
-    hipLaunchKernelGGL(k_obs, dim3(flat_grid(h->T)), dim3(256), 0, h->stream, h->S, h->N, player, out_d);
+    hipLaunchKernelGGL(k_obs, dim3(obs_grid(h->T)), dim3(OBS_BLOCK), 0, h->stream, h->S, h->N, player, out_d);
     HIPCHK(h, hipGetLastError());
     return PK_OK;
 }
@@ -810,7 +818,7 @@ int pk_get_obs_packed(pk_handle *h, int player, uint8_t *out) {
     if (!h || !out || bad_player(h, player)) return h ? h->fail(PK_E_INVALID_ARG, "pk_get_obs_packed: bad argument") : PK_E_INVALID_ARG;
     size_t bytes = (size_t)h->T * PK_OBS_PACKED_BYTES(h->N);
     return export_to_host(h, out, bytes, [&] {
-        hipLaunchKernelGGL(k_obs_packed, dim3(flat_grid(h->T)), dim3(256), 0, h->stream, h->S, h->N, player, (uint8_t *)h->d_export);
+        hipLaunchKernelGGL(k_obs_packed, dim3(obs_grid(h->T)), dim3(OBS_BLOCK), 0, h->stream, h->S, h->N, player, (uint8_t *)h->d_export);
     });
 }
 
@@ -818,7 +826,7 @@ int pk_get_obs_packed_d(pk_handle *h, int player, uint8_t *out_d) {
     if (!h || !out_d || bad_player(h, player) || ((uintptr_t)out_d & 7)) return h ? h->fail(PK_E_INVALID_ARG, "pk_get_obs_packed_d: bad argument (out_d must be 8-byte aligned)") : PK_E_INVALID_ARG;
     ON_DEVICE(h);
     FLUSH_READER(h);
-    hipLaunchKernelGGL(k_obs_packed, dim3(flat_grid(h->T)), dim3(256), 0, h->stream, h->S, h->N, player, out_d);
+    hipLaunchKernelGGL(k_obs_packed, dim3(obs_grid(h->T)), dim3(OBS_BLOCK), 0, h->stream, h->S, h->N, player, out_d);
     HIPCHK(h, hipGetLastError());
     return PK_OK;
 }

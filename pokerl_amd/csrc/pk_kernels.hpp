@@ -46,25 +46,26 @@ __global__ void __launch_bounds__(256) k_sum_counters(unsigned long long *slots,
 #endif
 
 // Game.StateView(player to act), game.py:117-131 -- what `game.active_state` builds right after every step (game.py:323-332) -- written
-// from the REGISTERS of the kernel that made the step: the dense f64 row (layout: pokerl_hip.h PK_OBS_DIM; the row k_obs builds from HBM) ...
+// from the REGISTERS of the kernel that made the step.  The two row forms as arrays of compile-time-indexed 64-bit words (they alias the table's
+// own registers): the dense f64 row (layout: pokerl_hip.h PK_OBS_DIM; the row k_obs builds from HBM) ...
 // First 8 bytes of a packed observation row (pokerl_hip.h PK_OBS_PACKED_BYTES): seat, turn, valid mask, hole cards, flop.
 __device__ __forceinline__ uint64_t obs_packed_header0(uint32_t who, uint32_t turn, uint32_t vmask, uint32_t h0, uint32_t h1, uint32_t c0, uint32_t c1, uint32_t c2) {
     return (uint64_t)(who | (turn << 8) | ((vmask & 0x7fu) << 16) | (h0 << 24)) | ((uint64_t)(h1 | (c0 << 8) | (c1 << 16) | (c2 << 24)) << 32);
 }
 template <int N>
-__device__ __forceinline__ void write_obs_row(const Table<N> &tb, uint32_t vmask, PK_GLOBAL double *o) {
+__device__ __forceinline__ void obs_row_words(const Table<N> &tb, uint32_t vmask, double (&o)[PK_OBS_DIM(N)]) {
     const int who = tb.active;
     o[0] = who; o[1] = tb.turn; o[2] = tb.min_raise;
-    for (int a = 0; a < PK_NUM_MOVES; ++a) o[3 + a] = (vmask >> a) & 1;
+    PK_FOR(a, PK_NUM_MOVES) o[3 + a] = (vmask >> a) & 1; PK_END
     double h0 = 0.0, h1 = 0.0;
     PK_FOR(p, N) h0 = (who == p) ? (double)tb.card(5 + 2 * p) : h0; h1 = (who == p) ? (double)tb.card(6 + 2 * p) : h1; PK_END
     o[10] = h0; o[11] = h1;                                                    // game.py:385-389
     PK_FOR(c, 5) o[12 + c] = (tb.turn != 0 && c < tb.turn + 2) ? (double)tb.card(c) : -1.0; PK_END   // game.py:278
     PK_FOR(p, N) o[17 + p] = tb.credits[p]; o[17 + N + p] = tb.bets[p]; o[17 + 2 * N + p] = tb.pending[p]; PK_END
 }
-// ... and the compact one (layout: pokerl_hip.h PK_OBS_PACKED_BYTES; k_obs_packed's row): 16 header bytes + (3N+1) f64
+// ... and the compact one (layout: pokerl_hip.h PK_OBS_PACKED_BYTES; k_obs_packed's row): 16 header bytes + (3N+1) f64 = 3(N+1) words
 template <int N>
-__device__ __forceinline__ void write_obs_packed_row(const Table<N> &tb, uint32_t vmask, PK_GLOBAL uint64_t *o) {
+__device__ __forceinline__ void obs_packed_words(const Table<N> &tb, uint32_t vmask, uint64_t (&o)[3 * N + 3]) {
     const uint32_t who = (uint32_t)tb.active;
     uint32_t h0 = 0, h1 = 0;
     PK_FOR(p, N) h0 = (who == (uint32_t)p) ? tb.card(5 + 2 * p) : h0; h1 = (who == (uint32_t)p) ? tb.card(6 + 2 * p) : h1; PK_END
@@ -72,10 +73,30 @@ __device__ __forceinline__ void write_obs_packed_row(const Table<N> &tb, uint32_
     PK_FOR(c, 5) cc[c] = (tb.turn != 0 && c < tb.turn + 2) ? tb.card(c) : 0xffu; PK_END
     o[0] = obs_packed_header0(who, (uint32_t)tb.turn, vmask, h0, h1, cc[0], cc[1], cc[2]);
     o[1] = (uint64_t)cc[3] | ((uint64_t)cc[4] << 8);
-    const auto m = (PK_GLOBAL double *)(o + 2);
-    m[0] = tb.min_raise;
-    PK_FOR(p, N) m[1 + p] = tb.credits[p]; m[1 + N + p] = tb.bets[p]; m[1 + 2 * N + p] = tb.pending[p]; PK_END
+    o[2] = (uint64_t)__double_as_longlong(tb.min_raise);
+    PK_FOR(p, N)
+        o[3 + p] = (uint64_t)__double_as_longlong(tb.credits[p]); o[3 + N + p] = (uint64_t)__double_as_longlong(tb.bets[p]);
+        o[3 + 2 * N + p] = (uint64_t)__double_as_longlong(tb.pending[p]);
+    PK_END
 }
+// Each lane stores its own row: 64 lanes x 8 bytes at a stride of one row (168 / 280 bytes at six seats) per instruction.  The PokerGameEnv kernels' form.
+template <int N>
+__device__ __forceinline__ void write_obs_row(const Table<N> &tb, uint32_t vmask, PK_GLOBAL double *o) {
+    double w[PK_OBS_DIM(N)];
+    obs_row_words<N>(tb, vmask, w);
+    PK_FOR(k, PK_OBS_DIM(N)) o[k] = w[k]; PK_END
+}
+template <int N>
+__device__ __forceinline__ void write_obs_packed_row(const Table<N> &tb, uint32_t vmask, PK_GLOBAL uint64_t *o) {
+    uint64_t w[3 * N + 3];
+    obs_packed_words<N>(tb, vmask, w);
+    PK_FOR(k, 3 * N + 3) o[k] = w[k]; PK_END
+}
+// (Tried in round 6: the wave's 64 rows -- one contiguous piece of the output -- staged through the idle showdown queue in LDS in chunks of N+1
+//  words and stored with consecutive lanes on consecutive words, 56-byte runs instead of 64 scattered 8-byte pieces per instruction.  No faster:
+//  Game.step + packed row at 65 536 x 6 21.7 us against 21.1 us with the plain per-lane stores, at 1 M tables 204 against 191 us, the dense row 269
+//  against 194 us -- L2 merges the scattered pieces of a line anyway, and the LDS round trip with its barriers is pure extra issue time:
+//  profiles/r06_step_obs_ab.txt.)
 
 template <int N>
 __global__ void __launch_bounds__(PK_TABLE_BLOCK) k_reset(State S, Hot H, const uint8_t *mask, int mask_bits, int dealer) {  // Game.reset, game.py:397-412
@@ -796,11 +817,25 @@ __global__ void k_export_valid(State S, int N, int player, uint8_t *out) {
 }
 // Game.StateView(game, player), game.py:117-131, as one dense f64 row per table (layout: pokerl_hip.h PK_OBS_DIM).
 // player < 0: the active player of each table (what `game.active_state` is, game.py:323-332).
-__global__ void k_obs(State S, int N, int player, double *out) {
+// The per-seat money of a table is LOADED FIRST, all of it (3 x 16 predicated loads in flight; runtime N: the export kernels are not templated),
+// then stored: with one load -> store pair per seat in a loop (rounds 1-5) the compiler could not move a load above the previous seat's store
+// (`out` may alias the state for all it knows) and the kernel ran at the latency of 3N dependent round trips -- 1.1 TB/s at 1 M tables.
+struct SeatMoney { double credits[PK_MAX_PLAYERS], bets[PK_MAX_PLAYERS], pending[PK_MAX_PLAYERS]; };
+__device__ __forceinline__ void load_seat_money(const State &S, int t, int N, SeatMoney &m) {
+    const size_t T = (size_t)S.T;
+#pragma unroll
+    for (int p = 0; p < PK_MAX_PLAYERS; ++p) {
+        const size_t i = (size_t)(p < N ? p : 0) * T + t;
+        m.credits[p] = S.credits[i]; m.bets[p] = S.bets[i]; m.pending[p] = S.pending[i];
+    }
+}
+__global__ void __launch_bounds__(64) k_obs(State S, int N, int player, double *__restrict__ out) {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= S.T) return;
     const int T = S.T, D = PK_OBS_DIM(N);
     double *o = out + (size_t)t * D;
+    SeatMoney m;
+    load_seat_money(S, t, N, m);
     uint32_t cur = S.cursors[t];
     int active = cur & 0xf, turn = (cur >> 16) & 0xf;
     const int who = player < 0 ? active : player;
@@ -810,19 +845,19 @@ __global__ void k_obs(State S, int N, int player, double *out) {
     for (int a = 0; a < PK_NUM_MOVES; ++a) o[3 + a] = (vm >> a) & 1;
     o[10] = card(5 + 2 * who); o[11] = card(6 + 2 * who);                          // game.py:385-389
     for (int c = 0; c < 5; ++c) o[12 + c] = (turn != 0 && c < turn + 2) ? card(c) : -1.0;  // game.py:278
-    for (int p = 0; p < N; ++p) {
-        o[17 + p] = S.credits[(size_t)p * T + t];
-        o[17 + N + p] = S.bets[(size_t)p * T + t];
-        o[17 + 2 * N + p] = S.pending[(size_t)p * T + t];
-    }
+#pragma unroll
+    for (int p = 0; p < PK_MAX_PLAYERS; ++p)
+        if (p < N) { o[17 + p] = m.credits[p]; o[17 + N + p] = m.bets[p]; o[17 + 2 * N + p] = m.pending[p]; }
 }
 // The same row as k_obs, compact: 16 header bytes (seat, turn, valid-mask bits, 2 hole cards, 5 community cards with 0xFF for a
 // card not yet visible, 6 zero bytes) + (3N+1) f64 (minimum_raise_value, credits, bets, pending_bets): pokerl_hip.h.
-__global__ void k_obs_packed(State S, int N, int player, uint8_t *out) {
+__global__ void __launch_bounds__(64) k_obs_packed(State S, int N, int player, uint8_t *__restrict__ out) {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= S.T) return;
     const int T = S.T;
     uint64_t *o = reinterpret_cast<uint64_t *>(out + (size_t)t * PK_OBS_PACKED_BYTES(N));
+    SeatMoney sm;
+    load_seat_money(S, t, N, sm);
     uint32_t cur = S.cursors[t];
     int active = cur & 0xf, turn = (cur >> 16) & 0xf;
     const int who = player < 0 ? active : player;
@@ -833,11 +868,9 @@ __global__ void k_obs_packed(State S, int N, int player, uint8_t *out) {
     o[1] = (uint64_t)comm(3) | ((uint64_t)comm(4) << 8);
     double *m = reinterpret_cast<double *>(o + 2);
     m[0] = S.min_raise[t];
-    for (int p = 0; p < N; ++p) {
-        m[1 + p] = S.credits[(size_t)p * T + t];
-        m[1 + N + p] = S.bets[(size_t)p * T + t];
-        m[1 + 2 * N + p] = S.pending[(size_t)p * T + t];
-    }
+#pragma unroll
+    for (int p = 0; p < PK_MAX_PLAYERS; ++p)
+        if (p < N) { m[1 + p] = sm.credits[p]; m[1 + N + p] = sm.bets[p]; m[1 + 2 * N + p] = sm.pending[p]; }
 }
 // Game.step's precondition (game.py:648-651) over a batch: the lowest table index whose action is not in its active player's mask.
 __global__ void k_check_actions(const uint8_t *valid, const int32_t *actions, int T, int32_t *first_bad) {

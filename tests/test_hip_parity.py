@@ -921,13 +921,23 @@ def test_bench_json_contract():
     assert c["cpu_baseline"]["kind"] == "port" and c["cpu_baseline"]["cores"] == 1 and c["cpu_baseline"]["value"] > 0 and c["cpu_baseline"]["sample"]
     assert c["evaluator"]["hand_evals_per_s"] > 0 and 0.0 < c["evaluator"]["frac"] <= 1.0
     cx = c["extra_workloads"]
-    assert len(cx) == 10 and all(len(x["name"]) <= 40 for x in cx)
+    assert len(cx) == 12 and all(len(x["name"]) <= 40 for x in cx)
     for x in cx:
         assert set(x) >= {"name", "value", "unit", "kernel_ms", "bound", "frac", "hbm_frac"} and x["value"] > 0 and 0.0 < x["frac"] <= 1.0, x
-    assert [x["name"].split()[0] for x in cx] == ["cfg1", "cfg4", "cfg2", "Game.step", "Game.step", "Game.step", "Game.step", "env.step", "env.step", "env.step"]
-    assert cx[3]["bound"] == cx[4]["bound"] == cx[5]["bound"] == cx[6]["bound"] == "hbm" and cx[3]["unit"] == "env-steps/s" and cx[4]["value"] >= cx[3]["value"] * 0.95
-    assert cx[6]["frac"] > cx[4]["frac"]                  # a batch that fills the chip is bound by its bytes, 65 536 tables by the slowest table's chain
-    assert cx[5]["value"] > cx[3]["value"]                # bounded launches: the tables whose step rolls on do not hold the launch
+    assert [x["name"].split()[0] for x in cx] == ["cfg1", "cfg4", "cfg2", "Game.step", "Game.step", "Game.step+obs_packed", "Game.step+obs_packed", "Game.step", "Game.step",
+                                                  "env.step", "env.step", "env.step"]
+    assert all(x["bound"] == "hbm" for x in cx[3:9]) and cx[3]["unit"] == "env-steps/s" and cx[4]["value"] >= cx[3]["value"] * 0.95
+    assert cx[8]["frac"] > cx[4]["frac"]                  # a batch that fills the chip is bound by its bytes, 65 536 tables by the slowest table's chain
+    assert cx[7]["value"] > cx[3]["value"]                # bounded launches: the tables whose step rolls on do not hold the launch
+    # SURVEY f2 on the Game.step path: the observation row from the step kernel's registers (one launch) beats step + getter kernel (two)
+    assert "2 launches" in cx[5]["name"] and "fused" in cx[6]["name"] and cx[6]["value"] > 1.2 * cx[5]["value"] and cx[6]["frac"] > cx[5]["frac"], (cx[5], cx[6])
+    # the line checks itself: ms_per_step (median sample) x the steps every table made inside the timed samples = the timed
+    # seconds (all samples), which fit inside this run's wall clock; `lib` names the kernel sources the figures were measured on
+    from pokerl_amd import _lib as L
+    assert c["timed_steps_per_table"] == c["steps"] * c["reps"] * c["samples"] == c["config"]["launch_stats"]["steps"]
+    assert abs(c["ms_per_step"] * 1e-3 * c["timed_steps_per_table"] - c["timed_s"]) < 0.15 * c["timed_s"], (c["ms_per_step"], c["timed_steps_per_table"], c["timed_s"])
+    assert c["lib"] == L.lib().pk_build_info().decode() and c["lib"].startswith("abi=6 src=")
+    assert isinstance(crf["profile_stale"], bool)
     assert abs(cx[1]["hand_evals_per_s"] / cx[1]["value"] - 1.0) < 1e-3       # configs[4]: one in-game evaluation per env-step
 
     # ---- the detail file: what the line held up to round 4
@@ -964,7 +974,7 @@ def test_bench_json_contract():
     assert cm["half_rate_share_source"] and 0.4 < cm["half_rate_share"] < 0.8
     # the other single-GPU BASELINE configs, Game.step with the caller's actions and the PokerGameEnv path are driver-timed legs
     xs = r["extra_workloads"]
-    assert len(xs) == 10 and [("configs[1]" in xs[0]["name"]), ("configs[4]" in xs[1]["name"])] == [True, True]
+    assert len(xs) == 12 and [("configs[1]" in xs[0]["name"]), ("configs[4]" in xs[1]["name"])] == [True, True]
     assert "one launch per call" in xs[2]["name"] and xs[2]["launch_stats"]["max"] == 20 and xs[2]["value"] < r["value"]
     for x in xs:
         for k in ("name", "short", "value", "unit", "kernel", "kernel_ms", "launches", "roofline"):
@@ -975,15 +985,24 @@ def test_bench_json_contract():
         assert abs(xr["frac"] - xr["achieved"] / xr["peak"]) < 1e-9
     # configs[4] is the showdown-heavy half of the metric: one in-game evaluation per env-step
     assert abs(xs[1]["hand_evals_per_s"] / xs[1]["value"] - 1.0) < 1e-3 and xs[0]["unit"] == xs[1]["unit"] == "env-steps/s"
-    assert 0.99 < xs[5]["ready_fraction_per_launch"] < 1.0 and "k_step_async" in xs[5]["kernel"]
-    for x in xs[3:7]:                                              # Game.step legs: the HBM roofline on SURVEY 8d's bytes + measured traffic
+    assert 0.99 < xs[7]["ready_fraction_per_launch"] < 1.0 and "k_step_async" in xs[7]["kernel"]
+    for i, x in enumerate(xs[3:9]):                                # Game.step legs: the HBM roofline on SURVEY 8d's bytes (+ the observation row's) + measured traffic
         xr = x["roofline"]
+        row = 168 if i in (2, 3) else 0                            # PK_OBS_PACKED_BYTES(6)
         assert x["unit"] == "env-steps/s" and "k_step" in x["kernel"] and xr["bound"] == "hbm" and x["tables_with_error_bits"] < 40
-        assert abs(xr["achieved"] - 478 * x["value"] / 1e9) / xr["achieved"] < 1e-6 and xr["traffic"] > 0.5 * 65536 * 478
-    for x in xs[7:]:                                               # PokerGameEnv legs: measured HBM traffic beside the VALU figure
+        assert xr["obs_row_bytes"] == row and abs(xr["achieved"] - (478 + row) * x["value"] / 1e9) / xr["achieved"] < 1e-6 and xr["traffic"] > 0.5 * 65536 * 478
+    assert xs[5]["kernel"] == "k_step + k_obs_packed" and xs[6]["kernel"] == "k_step[+packed row]" and xs[5]["launches"] == 2 * xs[6]["launches"]
+    assert xs[6]["roofline"]["traffic"] < xs[5]["roofline"]["traffic"]       # measured: the getter kernel re-reads the tables the step kernel has just stored
+    for x in xs[9:]:                                               # PokerGameEnv legs: measured HBM traffic beside the VALU figure
         assert x["unit"] == "env.step/s" and x["kernel"].startswith("k_env_step") and 0.0 < x["roofline"]["hbm"]["frac"] <= 1.0
         assert x["roofline"]["traffic"] > 0 and 4.0 < x["game_steps_per_env_step"] < 8.0
-    assert xs[7]["ready_fraction_per_launch"] == 1.0 and 0.3 < xs[8]["ready_fraction_per_launch"] < 1.0
+    assert xs[9]["ready_fraction_per_launch"] == 1.0 and 0.3 < xs[10]["ready_fraction_per_launch"] < 1.0
+    # every figure that rests on a committed counter summary says whether that summary was measured on THIS library's sources
+    assert abs(sum(r["sample_seconds"]) - c["timed_s"]) < 1e-3 * c["timed_s"]
+    src = json.load(open(os.path.join(root, "profiles", rf["source"])))
+    assert rf["profile_stale"] == (src.get("source_hash") != L.source_hash()) == crf["profile_stale"]
+    for short, full in zip(cx, xs):
+        assert bool(short.get("profile_stale", False)) == bool(full["roofline"].get("profile_stale", False)), short["name"]
 
 
 @pytest.mark.parametrize("N,policy", [(6, 0), (9, 1), (2, 0), (10, 0)])

@@ -701,6 +701,9 @@ def test_step_kernels_write_the_observation_rows(HB, O):
             check_rows(g, b, all_t, where + " step_async_d")
             if over.any():
                 o.reset(mask=over)
+        g, b = hs[2].g, bufs[2]                                  # (a bounded call leaves the handle busy even when every table was ready: drain)
+        b["act"].upload(np.full(T, -1, np.int32))
+        g.step_async_d(b["act"], b["flags"], b["terr"], b["ready"], max_hands=0, auto_reset=True); g.sync()
         GU.assert_snap(hs[0].snapshot(), o.snapshot(), "step_d + obs T=%d N=%d" % (T, N))
         GU.assert_snap(hs[1].snapshot(), o.snapshot(), "step_auto_d + obs T=%d N=%d" % (T, N))
         GU.assert_snap(hs[2].snapshot(), o.snapshot(), "step_async_d + obs T=%d N=%d" % (T, N))

@@ -23,6 +23,8 @@ tools/profile_eval7.sh ${R}_eval7
 tools/profile_step.sh ${R}_step_65536x6 --steps 1000 --warmup 100
 tools/profile_step.sh ${R}_step_1048576x6 --tables 1048576 --steps 200 --warmup 50
 tools/profile_step.sh ${R}_step_async_65536x6 --steps 1000 --warmup 100 --step-async 1
+tools/profile_step.sh ${R}_step_obs2_65536x6 --steps 1000 --warmup 100 --step-replay --step-obs packed --step-obs-separate
+tools/profile_step.sh ${R}_step_obsfused_65536x6 --steps 1000 --warmup 100 --step-replay --step-obs packed
 fi
 if [ "$WHAT" = "all" ] || [ "$WHAT" = "benches" ]; then
 cd $ROOT

@@ -55,5 +55,13 @@ if c.get("SQ_WAVES"):
     s["waves_per_launch"] = c["SQ_WAVES"]
 if c.get("GRBM_GUI_ACTIVE"):
     s["effective_clock_GHz"] = c["GRBM_GUI_ACTIVE"] / 8.0 / (s["avg_launch_ms"] * 1e-3) / 1e9
+try:    # which kernel sources this was measured on (pk_build_info of the library in the tree: bench.py marks figures from another build `profile_stale`)
+    import os as _os, sys as _sys
+    _sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
+    from pokerl_amd import _lib as _pk_lib
+    s["source_hash"] = _pk_lib.source_hash()
+except Exception as _e:   # noqa: BLE001
+    s["source_hash"] = None
+
 json.dump(s, open(os.path.join(dst, tag + "_summary.json"), "w"), indent=1)
 print(json.dumps(s, indent=1))

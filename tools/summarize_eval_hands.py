@@ -49,5 +49,13 @@ for case, label in ((0, "7 distinct cards (ncards = NULL: k_eval_hands_tab<false
         s["hbm_traffic_over_algorithmic"] = s["hbm_traffic_bytes_per_launch"] / alg
         s["hbm_frac_algorithmic"] = alg / (s["avg_launch_ms"] * 1e-3) / 8e12
     out["cases"][str(case)] = s
+try:    # which kernel sources this was measured on (pk_build_info of the library in the tree: bench.py marks figures from another build `profile_stale`)
+    import os as _os, sys as _sys
+    _sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
+    from pokerl_amd import _lib as _pk_lib
+    out["source_hash"] = _pk_lib.source_hash()
+except Exception as _e:   # noqa: BLE001
+    out["source_hash"] = None
+
 json.dump(out, open(os.path.join(root, "profiles", tag + "_summary.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))

@@ -107,5 +107,13 @@ if "SQ_ACTIVE_INST_VALU" in counters and "SQ_WAVE_CYCLES" in counters:
     summary["wait_any_frac_of_wave_cycles"] = counters.get("SQ_WAIT_ANY", 0) / counters["SQ_WAVE_CYCLES"]
 if "TCC_HIT_sum" in counters:
     summary["l2_hit_rate"] = counters["TCC_HIT_sum"] / (counters["TCC_HIT_sum"] + counters["TCC_MISS_sum"])
+try:    # which kernel sources this was measured on (pk_build_info of the library in the tree: bench.py marks figures from another build `profile_stale`)
+    import os as _os, sys as _sys
+    _sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
+    from pokerl_amd import _lib as _pk_lib
+    summary["source_hash"] = _pk_lib.source_hash()
+except Exception as _e:   # noqa: BLE001
+    summary["source_hash"] = None
+
 json.dump(summary, open(os.path.join(dst, tag + "_summary.json"), "w"), indent=1)
 print(json.dumps(summary, indent=1))

@@ -17,7 +17,7 @@ tag = sys.argv[1]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", "prof_" + tag)
 dst = os.path.join(root, "profiles")
-KERNELS = ("k_pick<", "k_step<", "k_step_async<", "k_reset<")
+KERNELS = ("k_pick<", "k_step<", "k_step_async<", "k_reset<", "k_obs_packed(", "k_obs(")
 
 
 def bench_line(log):
@@ -48,7 +48,9 @@ for r in csv.DictReader(open(trace)):
 m = re.search(r"(\d+) x (\d+)", line["name"])
 if "ready_fraction_per_launch" in line:
     pass
+obs = "packed" if "packed observation rows" in line["name"] else "dense" if "dense observation rows" in line["name"] else None
 summary = {"tag": tag, "workload": {"tables": int(m.group(1)), "players": int(m.group(2)), "replay": "replayed" in line["name"], "bounded": "bounded launches" in line["name"],
+                                    "obs": obs, "obs_fused": bool(obs) and "from the step kernel" in line["name"],
                                     "command": json.load(open(os.path.join(src, "workload.json")))["command"]},
            "bench_line_of_the_traced_run": {k: line[k] for k in ("value", "kernel_ms", "launches", "device_ms", "ms_per_step", "ready_fraction_per_launch") if k in line},
            "kernels": {}}
@@ -93,9 +95,18 @@ for k, v in summary["kernels"].items():
 summary["hbm_traffic_bytes_per_step"] = tot
 summary["hbm_traffic_note"] = "(2*FETCH_SIZE + WRITE_SIZE) KiB per mean launch, summed over the kernels of one loop iteration: FETCH_SIZE doubled per the guide's gfx950 correction (an upper estimate)"
 T, N = summary["workload"]["tables"], summary["workload"]["players"]
-summary["algorithmic_bytes_per_step"] = (2 * (35 * N + 21) + 16) * T
+row_bytes = 0 if obs is None else (16 + 8 * (3 * N + 1)) if obs == "packed" else 8 * (17 + 3 * N)
+summary["algorithmic_bytes_per_step"] = (2 * (35 * N + 21) + 16 + row_bytes) * T
 summary["traffic_over_algorithmic"] = tot / summary["algorithmic_bytes_per_step"] if tot else None
 if summary["k_step_avg_ms"]:
     summary["k_step_hbm_frac_algorithmic"] = summary["algorithmic_bytes_per_step"] / (summary["k_step_avg_ms"] * 1e-3) / 8e12
+try:    # which kernel sources this was measured on (pk_build_info of the library in the tree: bench.py marks figures from another build `profile_stale`)
+    import os as _os, sys as _sys
+    _sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
+    from pokerl_amd import _lib as _pk_lib
+    summary["source_hash"] = _pk_lib.source_hash()
+except Exception as _e:   # noqa: BLE001
+    summary["source_hash"] = None
+
 json.dump(summary, open(os.path.join(dst, tag + "_summary.json"), "w"), indent=1)
 print(json.dumps(summary, indent=1))
