@@ -215,6 +215,31 @@ def test_bench_line_is_compact():
     assert c["extra_workloads"][-1]["error"].startswith("RuntimeError") and len(c["extra_workloads"][-1]["error"]) <= 80
     assert c["extra_workloads"][3]["bound"] == "valu-issue" and 0 < c["extra_workloads"][3]["hbm_frac"] < 1      # env leg: measured HBM beside VALU
     assert c["dist"]["world"] == 8
+    # round 6: the line checks itself -- the timed seconds, the steps per table inside them and the library's source hash travel in it -- and a
+    # roofline figure that rests on a committed counter summary of OTHER kernel sources says so
+    full.update({"reps": 26215, "samples": 7, "timed_steps_per_table": 20 * 26215 * 7, "timed_s": 7.85, "lib": "abi=6 src=0123456789abcdef"})
+    full["roofline"]["profile_stale"] = True
+    full["extra_workloads"][3]["roofline"]["profile_stale"] = True
+    full["extra_workloads"][0]["roofline"]["profile_stale"] = False
+    c = json.loads(bench.compact_line(full))
+    assert c["timed_steps_per_table"] == 3670100 and c["timed_s"] == 7.85 and c["reps"] == 26215 and c["samples"] == 7 and c["lib"].endswith("0123456789abcdef")
+    assert c["roofline"]["profile_stale"] is True and c["extra_workloads"][3]["profile_stale"] is True and "profile_stale" not in c["extra_workloads"][0]
+    assert len(bench.compact_line(full)) < bench.LINE_LIMIT
+
+
+def test_source_hash_ignores_comments_and_is_embedded():
+    """pokerl_amd/build.py source_hash(): over the kernel sources without comments / white space + the compiler flags; the built library
+    reports the hash it was built from (pk_build_info) and the summaries under profiles/ that were made in round 6 or later carry one."""
+    import glob
+    import json
+    from pokerl_amd import _lib, build
+    build.build_lib()
+    h = build.source_hash()
+    assert re.fullmatch(r"[0-9a-f]{16}", h) and _lib.lib().pk_build_info().decode() == "abi=%d src=%s" % (_lib.ABI_VERSION, h) and _lib.source_hash() == h
+    import bench
+    assert bench.profile_stale({}) and bench.profile_stale({"source_hash": "0" * 16}) and not bench.profile_stale({"source_hash": h})
+    for f in glob.glob(os.path.join(ROOT, "profiles", "r0[6-9]_*_summary.json")):
+        assert re.fullmatch(r"[0-9a-f]{16}", json.load(open(f)).get("source_hash") or ""), f
 
 
 def test_bench_aggregation_gloo_world2(tmp_path):
