@@ -52,8 +52,15 @@ for s in range(steps):
     if s % 500 == 499:
         game.sync()
         delivered += int(ready.download(np.uint8, T).sum())    # (sampled: 99.98 % of the tables are ready after every launch)
+game.sync()
+te = terr.download(np.uint8, T)
+assert not (te[ready.download(np.uint8, T) != 0] & L.TERR_INVALID_ACTION).any()      # the picks were valid for every table that took one
+# A drain is a full step call: it would step the ready tables AGAIN with whatever `actions` holds.  "No step" is spelled as an invalid action (-1):
+# those tables come back untouched with TERR_INVALID_ACTION (by design, not an error); the tables in flight ignore their action and finish.
+actions.upload(np.full(T, -1, np.int32))
 game.step_async_d(actions, flags, terr, ready, max_hands=0, auto_reset=True)   # drain: every table ready
 game.sync()
+assert (ready.download(np.uint8, T) != 0).all() and not (terr.download(np.uint8, T) & ~np.uint8(L.TERR_INVALID_ACTION | L.TERR_HAND_CAP)).any()
 dt = time.perf_counter() - t0
 print("bounded launches: %.1f us per step of the whole batch (%.2f G steps/s if every table were ready; %.4f of them were in the sampled launches)"
       % (dt / steps * 1e6, T * steps / dt / 1e9, delivered / float(T * max(1, steps // 500))))

@@ -160,7 +160,11 @@ int pk_step_auto_d(pk_handle *h, const int32_t *actions_d, uint8_t *flags_d, uin
  * which every other entry point that reads or changes tables returns PK_E_BUSY (pk_sync only waits) -- EXCEPT the device-resident readers a
  * caller needs to act on the ready tables: pk_pick_actions_d, pk_get_obs_d, pk_get_obs_packed_d, pk_get_valid_actions_d, pk_get_f64_d (their
  * rows for a table in flight show that table in the middle of its step: ignore them).  auto_reset must not change while
- * steps are in flight (PK_E_INVALID_ARG).  A step that has already rolled 16 hands is carried to its end whatever the budget. */
+ * steps are in flight (PK_E_INVALID_ARG).  A step that has already rolled 16 hands is carried to its end whatever the budget.
+ * A DRAIN (max_hands <= 0) IS A FULL STEP CALL: besides finishing what is in flight it steps every idle (ready) table with actions_d[t], like any other
+ * call.  To drain WITHOUT stepping, fill actions_d with an invalid action (-1): those tables come back untouched with PK_TERR_INVALID_ACTION in terr_d[t]
+ * (the error byte of a table that was merely passed over -- not an error of the call).  Draining with the buffer the previous launch consumed steps the
+ * ready tables a second time with stale actions. */
 int pk_step_async_d(pk_handle *h, const int32_t *actions_d, uint8_t *flags_d, uint8_t *terr_d, uint8_t *ready_d, int max_hands, int auto_reset);
 
 /* Game.get_valid_actions(player), pokerl/game.py:339-383: out[T][7] one-hot bytes.  player < 0: each table's active
@@ -190,6 +194,9 @@ int pk_get_hand_ranks(pk_handle *h, uint8_t *rank, uint32_t *kick);
 
 /* pokerl.judger.eval_hand (pokerl/judger.py:7-99) on M hands.  cards[M][7] Card.value bytes (unused slots ignored),
  * ncards[M] in 0..7 (NULL = all 7).  rank[M], kick[M] (packed kickers, judger.py:101-109), nkick[M] (may be NULL).
+ * The FIRST call per device (of this or any other judger entry point that uses the table path) builds a 32 KB table: one hipMalloc, one small
+ * kernel on the legacy default stream and a hipStreamSynchronize(0) -- a one-off host block and an implicit sync with blocking streams, not legal
+ * inside a stream capture: make one warm-up call (any m >= 1) before capturing or timing.
  * Multiset semantics: duplicate cards are legal, as in the reference's own tests (those hands, hands of fewer than three cards and
  * hands with a byte that is no card -- suit > 3 or rank nibble > 12 -- take the reference's sort-and-scan; 3..7 DISTINCT cards a
  * table-driven evaluator that equals it on every subset of the deck: tools/host_sim `evalntab`, GPU digest fast = 4). */
@@ -447,7 +454,8 @@ int pk_sync(pk_handle *h);
  * queues); the sub-batch streams of pk_set_env_batches are created at the HIGHEST stream priority (env PK_ENV_STREAM_PRIO=0: normal), so a
  * learner's normal-priority kernels on the same GPU yield to the env ranges while those run.  pk_stream_pool_drain destroys the pooled (idle)
  * streams of `device` (-1: all devices) and returns how many -- call it before hipDeviceReset, which would leave stale handles in the pool
- * (pk_create drops a pool whose streams no longer work and retries), or to give the queues back. */
+ * (pk_create checks a pooled stream with hipStreamQuery before using it and drops the device's whole pool when it finds a dead one; a stream that
+ * cannot be synchronised when its handle is destroyed is not pooled), or to give the queues back. */
 int pk_stream_pool_drain(int device);
 /* Runs `reps` back-to-back fused rollouts of k_steps each (never coalesced) plus the flush of what they deferred and
  * returns the device time of all of it divided by `reps`, in milliseconds (events on the handle's stream): the time one

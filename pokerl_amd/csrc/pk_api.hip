@@ -295,7 +295,20 @@ static hipError_t stream_acquire(int device, hipStream_t *out, bool sub_batch = 
     if (device >= 0 && device < PK_MAX_DEVICES) {
         std::lock_guard<std::mutex> lock(g_stream_mu);
         auto &pool = g_stream_pool[device][cls];
-        if (!pool.empty()) { *out = pool.back(); pool.pop_back(); return hipSuccess; }
+        while (!pool.empty()) {
+            // A pooled handle may be STALE: the application reset the device (hipDeviceReset invalidates every stream) without draining the
+            // pool first.  hipStreamQuery tells: an idle live stream answers hipSuccess; anything else and the whole pool of this device is
+            // dropped -- its handles date from the same context -- and a fresh stream is created below.  (Round 5 accepted whatever it popped:
+            // the later uploads failed, pk_destroy put the dead handle back, and every pk_create on that device failed from then on: ADVICE r05.)
+            hipStream_t s = pool.back();
+            pool.pop_back();
+            const hipError_t q = hipStreamQuery(s);
+            if (q == hipSuccess) { *out = s; return hipSuccess; }
+            (void)hipGetLastError();
+            if (q == hipErrorNotReady) { (void)hipStreamSynchronize(s); (void)hipGetLastError(); continue; }   // (cannot happen: streams are pooled idle; not reused either way)
+            for (int c = 0; c < 2; ++c) g_stream_pool[device][c].clear();    // stale context: nothing left to destroy
+            break;
+        }
     }
     if (cls == 1) {
         int least = 0, greatest = 0;
@@ -307,7 +320,10 @@ static hipError_t stream_acquire(int device, hipStream_t *out, bool sub_batch = 
 }
 static void stream_release(int device, hipStream_t s, bool sub_batch = false) {   // the device is current; s is idle or about to be
     if (!s) return;
-    (void)hipStreamSynchronize(s);
+    if (hipStreamSynchronize(s) != hipSuccess) {      // a stream that cannot even be waited for (stale after a device reset, or broken) is not recycled
+        (void)hipGetLastError(); (void)hipStreamDestroy(s); (void)hipGetLastError();
+        return;
+    }
     static const bool prio = !(getenv("PK_ENV_STREAM_PRIO") && atoi(getenv("PK_ENV_STREAM_PRIO")) == 0);
     if (device >= 0 && device < PK_MAX_DEVICES) {
         std::lock_guard<std::mutex> lock(g_stream_mu);
@@ -430,9 +446,9 @@ int pk_create(pk_handle **out, int device, int num_tables, int num_players, cons
     auto bail = [&](int code) { g_err = h->err; pk_destroy(h); return code; };
     DeviceGuard guard(device);
     if (!guard.ok) return bail(h->fail(PK_E_HIP, "hipSetDevice"));
-    if (stream_acquire(device, &h->own_stream) != hipSuccess) {
-        (void)hipGetLastError(); drain_stream_pool(device);      // e.g. after the application reset the device: pooled handles are stale
-        if (stream_acquire(device, &h->own_stream) != hipSuccess) return bail(h->fail(PK_E_HIP, "hipStreamCreate"));
+    if (stream_acquire(device, &h->own_stream) != hipSuccess) {  // (stream_acquire has validated what it took from the pool, or created a fresh one)
+        (void)hipGetLastError();
+        return bail(h->fail(PK_E_HIP, "hipStreamCreate"));
     }
     h->stream = h->own_stream;
     if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess ||
@@ -1255,13 +1271,15 @@ int pk_env_step_begin(pk_handle *h, const int32_t *actions, int opp_policy, int 
     ka.A.obs_packed = obs_packed ? h->d_obs_packed : nullptr;
     DISPATCH_N(h, k_env_step, env_grid(h), ka);
     HIPCHK(h, hipGetLastError());
+    // Busy from HERE on: if one of the copies below fails to queue, the earlier ones are already queued into the caller's buffers, and
+    // pk_env_step_end is the caller's sanctioned way to wait for them (round 5 set the flag after the last copy: ADVICE r05).
+    h->host_step = true;      // until pk_env_step_end: every entry point that reads or changes tables (another begin included) is PK_E_BUSY
     HIPCHK(h, hipMemcpyAsync(reward, h->d_reward, T * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(done, h->d_done, T, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(hand, h->d_handf, T, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(terr, h->d_terr, T, hipMemcpyDeviceToHost, h->stream));
     if (obs) HIPCHK(h, hipMemcpyAsync(obs, h->d_export, T * D * 8, hipMemcpyDeviceToHost, h->stream));
     if (obs_packed) HIPCHK(h, hipMemcpyAsync(obs_packed, h->d_obs_packed, T * PB, hipMemcpyDeviceToHost, h->stream));
-    h->host_step = true;      // until pk_env_step_end: every entry point that reads or changes tables (another begin included) is PK_E_BUSY
     return PK_OK;
 }
 
@@ -1329,7 +1347,8 @@ static void launch_eval_hands(const uint32_t *tab, const uint8_t *cards_d, const
                               uint8_t *nkick_d, hipStream_t stream) {
     static const bool use_tab = !(getenv("PK_EVAL_HANDS_TAB") && atoi(getenv("PK_EVAL_HANDS_TAB")) == 0);
     if (tab && use_tab) {
-        static const int grid_max = getenv("PK_EVAL_HANDS_GRID") ? atoi(getenv("PK_EVAL_HANDS_GRID")) : 256 * 8;
+        static const int grid_env = getenv("PK_EVAL_HANDS_GRID") ? atoi(getenv("PK_EVAL_HANDS_GRID")) : 256 * 8;
+        static const int grid_max = grid_env < 1 ? 1 : grid_env;              // (a knob value of 0 or below: one workgroup, never an empty or a wrapped-around grid)
         const size_t chunks = (m + EVAL_TAB_BLOCK - 1) / EVAL_TAB_BLOCK;      // every workgroup copies the 32 KB table: no more of them than have hands
         const unsigned grid = (unsigned)(chunks < (size_t)grid_max ? chunks : (size_t)grid_max);   // four resident per CU (LDS), two rounds; grid-stride over the rest
         if (ncards_d) hipLaunchKernelGGL(k_eval_hands_tab<true>, dim3(grid), dim3(EVAL_TAB_BLOCK), 0, stream, cards_d, ncards_d, m, rank_d, kick_d, nkick_d, tab);
@@ -1431,7 +1450,8 @@ static int launch_eval7(int device, const uint64_t *hands_d, size_t m, uint32_t 
         // A/B knob (bit 0 clear: software prefetch of the next hands; bit 1 clear: both hands' lookups issued before either is used):
         // all four within 1.5 % of each other at 2^28 hands; the plain form is the default
         static const int variant = getenv("PK_EVAL7_VARIANT") ? atoi(getenv("PK_EVAL7_VARIANT")) : 3;
-        static const int grid_max = getenv("PK_EVAL7_GRID") ? atoi(getenv("PK_EVAL7_GRID")) : 256 * 32;
+        static const int grid_env = getenv("PK_EVAL7_GRID") ? atoi(getenv("PK_EVAL7_GRID")) : 256 * 32;
+        static const int grid_max = grid_env < 1 ? 1 : grid_env;
         const size_t want = (m / 2 + 511) / 512;     // every workgroup copies the 32 KB table: no more of them than have hands
         const unsigned gridx = (unsigned)(want < 1 ? 1 : (want < (size_t)grid_max ? want : (size_t)grid_max));
         if (vec && variant == 1) hipLaunchKernelGGL((k_eval7_tab_stream<true, 1>), dim3(gridx), dim3(512), 0, 0, hands_d, m, out_d, tab);

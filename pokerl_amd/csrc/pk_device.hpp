@@ -855,6 +855,9 @@ struct Table {
     static constexpr uint32_t FULL = (1u << N) - 1;
     double credits[N], bets[N], pending[N], payoffs[N];
     double min_raise;
+#ifdef PK_CARRY_HB
+    double hb;                   // np.max(pending_bets) carried across the step instead of recomputed (experiment, round 6: see valid_mask)
+#endif
     uint32_t st_active, st_called, st_allin, st_broken;  // seat bitmasks; FOLDED = in none of them
     int active, dealer, sb, bb, turn, hand;
     uint64_t hand_serial, step_serial;
@@ -886,6 +889,9 @@ struct Table {
             pending[p] = g_pending[(size_t)p * T + t]; payoffs[p] = PAYOFFS ? g_payoffs[(size_t)p * T + t] : 0.0;
          PK_END
         pay_dirty = false;
+#ifdef PK_CARRY_HB
+        hb = vmax<N>(pending);
+#endif
         min_raise = as_global(S.min_raise)[t];
         uint64_t ss = as_global(S.seat_states)[t];
         st_active = (uint32_t)ss & 0xffff; st_called = (uint32_t)(ss >> 16) & 0xffff;
@@ -909,6 +915,9 @@ struct Table {
     __device__ __forceinline__ void blank() {
         PK_FOR(p, N) credits[p] = bets[p] = pending[p] = payoffs[p] = 0.0;  PK_END
         min_raise = 0.0; st_active = st_called = st_allin = 0; st_broken = FULL;
+#ifdef PK_CARRY_HB
+        hb = 0.0;
+#endif
         active = dealer = sb = bb = turn = hand = 0; hand_serial = step_serial = 0;
         PK_FOR(w, W) cards[w] = 0; PK_END
         PK_FOR(p, N) pot_wb[p] = 0.0; pot_hv[p] = NONE_V; PK_END
@@ -960,7 +969,14 @@ struct Table {
 
     // Game.get_valid_actions(active player) as a bitmask, game.py:339-383.  high_bet is returned for the step.
     __device__ __forceinline__ uint32_t valid_mask(double &high_bet) const {
+#ifdef PK_CARRY_HB
+        high_bet = hb;
+#ifdef PK_HOST_SIM
+        if (hb != vmax<N>(pending)) { printf("CARRIED HIGH BET %.17g != np.max(pending_bets) %.17g\n", hb, vmax<N>(pending)); abort(); }
+#endif
+#else
         high_bet = vmax<N>(pending);                                               // :365
+#endif
         double credit = sel<N>(credits, active);                                   // :366
         uint32_t mask = (1u << MV_FOLD) | (1u << MV_ALL_IN);                       // :367
         double d = credit - high_bet;
@@ -1051,6 +1067,9 @@ struct Table {
          PK_END
         st_active &= ~over; st_called &= ~over; st_broken &= ~over; st_allin |= over;
         min_raise = vmax<N>(pending);                                              // :446
+#ifdef PK_CARRY_HB
+        hb = min_raise;
+#endif
         hands_this_step += 1;
     }
     // Game.reset minus the shuffle, game.py:397-412
@@ -1087,6 +1106,9 @@ struct Table {
     __device__ __forceinline__ void load_fresh(const Fresh &f) {
         PK_FOR(p, N) credits[p] = f.credits[p]; bets[p] = 0.0; pending[p] = f.pending[p]; PK_END
         min_raise = f.min_raise;
+#ifdef PK_CARRY_HB
+        hb = f.min_raise;
+#endif
         st_active = f.st_active; st_called = f.st_called; st_allin = f.st_allin; st_broken = f.st_broken;
         active = f.active; dealer = f.dealer; sb = f.sb; bb = f.bb;
         hand = 1; turn = 0;
@@ -1110,6 +1132,9 @@ struct Table {
         st_active |= raises ? st_called : 0;                                       // :683 CALLED -> ACTIVE
         st_called = raises ? 0 : st_called;
         min_raise = raises ? bet_value - high_bet : min_raise;                     // :687
+#ifdef PK_CARRY_HB
+        hb = raises ? bet_value : hb;        // (a bet that is no raise never exceeds the high bet; the acting seat's own earlier bet is never the sole maximum it undercuts)
+#endif
         st_active &= ~b; st_called &= ~b; st_allin &= ~b; st_broken &= ~b;         // player_states[a] = ...
         st_allin |= (action == MV_ALL_IN) ? b : 0;                                 // :671
         st_called |= (action != MV_FOLD && action != MV_ALL_IN) ? b : 0;           // :660, :667 (FOLD: in no mask, :657)
@@ -1160,6 +1185,9 @@ struct Table {
     __device__ __forceinline__ void next_turns() {
         PK_FOR(p, N) bets[p] = bets[p] + pending[p]; credits[p] = credits[p] - pending[p]; pending[p] = 0.0; PK_END  // :554-557
         min_raise = 0.0;                                                           // :558
+#ifdef PK_CARRY_HB
+        hb = 0.0;
+#endif
         turn += 1;                                                                 // :561
         const bool more = turn < 4;                                                // :566-576, as selects (one basic block)
         const bool merge = more && __popc(st_called) > 1;
@@ -1207,6 +1235,9 @@ struct Table {
                 pending[p] = 0.0; payoffs[p] = 0.0;
              PK_END
             min_raise = 0.0;
+#ifdef PK_CARRY_HB
+            hb = 0.0;
+#endif
             uint32_t pw = (st_active | st_called | st_allin) & FULL;               // :471 (not BROKEN, not FOLDED)
             const int npw = __popc(pw);                                            // :472
             nowin = npw <= 0;                                                      // :473

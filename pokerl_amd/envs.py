@@ -289,6 +289,15 @@ class VecPokerGameEnv:
                 b['hand'].download(np.uint8, T) != 0, b['terr'].download(np.uint8, T))
 
 
+def _check_or_error(env, actions, table_offset):
+    """env.check_actions() as a value (for running the checks of several batches on the pool's threads): the ValueError it would raise, or None."""
+    try:
+        env.check_actions(actions, table_offset=table_offset)
+    except ValueError as e:
+        return e
+    return None
+
+
 class VecPokerGameEnvPool:
     """ONE environment object over `num_batches` independent batches of tables, each with its own handle and HIP stream.
 
@@ -361,16 +370,21 @@ class VecPokerGameEnvPool:
             raise L.PokerlHipError('table error bits %s' % np.unique(cat[4]))
         return cat[:4]
 
-    def step_pipelined(self, actions, obs='packed', auto_reset=False, strict=True):
+    def step_pipelined(self, actions, obs='packed', auto_reset=False, strict=False):
         """The host-array fast path over the pool: send() on every batch, then recv() on every batch -- batch b+1's launch
         and the other devices' work overlap with batch b's device-to-host copies.  Returns one (obs, reward, done, hand,
         terr) tuple of pinned VIEWS per batch (see VecPokerGameEnv.recv): no concatenation, no copy.
-        strict=True (the default, as step()): every batch's actions are checked first and the reference's ValueError is raised before
-        any table of any batch is mutated; strict=False: a table whose action is invalid is left unstepped and its terr is 1."""
+        strict=False (the default, as send()): nothing blocks before the launches; a table whose action is invalid is left unstepped and its
+        terr is TERR_INVALID_ACTION -- CHECK terr, an invalid action is not raised.  strict=True: every batch's actions are checked first (the
+        pk_check_actions round trips of all batches, in parallel on the pool's threads) and the reference's ValueError is raised before any table of
+        any batch is mutated -- the price is one blocking round trip per call, which the committed figures of this path
+        (profiles/r05_measure_api.txt) do not include."""
         a = np.ascontiguousarray(np.broadcast_to(np.asarray(actions), (self.num_tables,)))
         if strict:
-            for e, s in zip(self.envs, self.slices):
-                e.check_actions(a[s], table_offset=s.start)
+            errs = self._map(lambda e, s: _check_or_error(e, a[s], s.start), self.envs, self.slices)
+            for err in errs:                          # the lowest batch's error first: the reference names the first offending table
+                if err is not None:
+                    raise err
         for e, s in zip(self.envs, self.slices):
             e.send(a[s], obs=obs, auto_reset=auto_reset)
         return [e.recv() for e in self.envs]

@@ -58,7 +58,13 @@ class Card:
 
 
 class StateView:
-    """The game as seen by one table's active player (game.py:117-131)."""
+    """The game as seen by one table's active player (game.py:117-131) -- as a SNAPSHOT of the step it was made after.
+
+    The one documented difference from the reference: there `self.credits = game.credits` (game.py:128-130) stores the game's own arrays, so a
+    view held across a later Game.step changes under its holder (credits / bets for ever, pending_bets until the next setup_hand rebinds the
+    game's attribute, game.py:445); device memory cannot be aliased by a host object, so the arrays here are copies.  Code that relied on the
+    aliasing reads `game.credits / .bets / .pending_bets` (fresh on every access).  Pinned against the reference's behaviour by
+    tests/golden/views_alias_*.json ("StateView: snapshot, not alias")."""
 
     def __init__(self, row, num_players):
         n = int(num_players)

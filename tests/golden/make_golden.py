@@ -227,7 +227,7 @@ class _HandCapProbe:
 
 
 def game_trajectory(n, policy, seed, tables, steps, table_id_base=0, cfg=None, full=True, digest_every=0,
-                    auto_reset=True, dealer=0, serial_base=(0, 0), views=None, hand_cap=None):
+                    auto_reset=True, dealer=0, serial_base=(0, 0), views=None, hand_cap=None, held=None):
     """auto_reset=False: finished games are NOT reset (the lone survivor keeps being stepped, which the
     reference allows); a survivor's FOLD then trips `assert num_potential_winners > 0` (game.py:473):
     recorded as err=2 with the partially mutated state, after which that table is reset."""
@@ -248,6 +248,9 @@ def game_trajectory(n, policy, seed, tables, steps, table_id_base=0, cfg=None, f
     post, resets, reset_idx, digests = [], [], [], []
     for s in range(steps):
         row = []
+        if held is not None:     # a StateView HELD across the step: its arrays alias the game's (game.py:128-130), see ALIAS_SETS
+            kept = [(t.game.active_state, t.hand_serial) for t in ts]
+            made = [_state_tuple(v) for v, _ in kept]
         for i, t in enumerate(ts):
             a = t.pick(policy)
             actions[s, i] = a
@@ -271,6 +274,11 @@ def game_trajectory(n, policy, seed, tables, steps, table_id_base=0, cfg=None, f
             row.append(t.snapshot())
         if views is not None:
             views.append([view_record(t.game) for t in ts])
+        if held is not None:     # (before the auto-reset below)
+            held.append([dict(at_creation=made[i], after_step=_state_tuple(kept[i][0]), setup_hands=int(t.hand_serial - kept[i][1]),
+                              live=dict(credits=_hex(t.game.credits), bets=_hex(t.game.bets), pending_bets=_hex(t.game.pending_bets),
+                                        sb=int(t.game.small_blind_idx), bb=int(t.game.big_blind_idx)))
+                         for i, t in enumerate(ts)])
         if full:
             post.append(row)
         if digest_every and (s + 1) % digest_every == 0:
@@ -505,6 +513,17 @@ SERIAL_SETS = {
     "game_n6_serial_hi": (6, R.POLICY_RANDOM, SEED, 6, 120, 70000, None, ((1 << 32) - 9, (1 << 35) - 37)),
 }
 # observation contract: StateView.__getstate__ tuples of the reference itself, every seat
+# A StateView held ACROSS a Game.step (SURVEY a13 "arrays are aliases of live game arrays"): `self.credits = game.credits` (game.py:128-130) shares
+# the game's numpy arrays, so the held view's credits / bets change with the game (they are only ever mutated in place: game.py:408, :457-458, :480,
+# :528, :554-555); `pending_bets` is shared until the next setup_hand REBINDS the game's attribute (game.py:445 `self.pending_bets = np.minimum(...)`),
+# after which the view keeps the old array as :438-440 left it (zeros + the new hand's blinds, unclipped).  Everything else in the view is a value or
+# a fresh object.  The product's StateView is a SNAPSHOT (pokerl_amd/state_view.py); this fixture pins what the reference does, so that the
+# difference is a documented, tested rule: INTEGRATION.md section 3.
+ALIAS_SETS = {
+    "views_alias_n6_random": (6, R.POLICY_RANDOM, SEED ^ 0xA11A5, 4, 90, 0, None),
+    "views_alias_n3_percredits": (3, R.POLICY_RANDOM, 99, 4, 90, 5, dict(start_credits=[30, 100, 5], big_blind=4, small_blind=2)),
+}
+
 VIEW_SETS = {
     "views_n6_random": (6, R.POLICY_RANDOM, SEED ^ 0x77, 4, 60, 0, None),
     "views_n3_percredits": (3, R.POLICY_RANDOM, 7, 4, 60, 77, dict(start_credits=[30, 100, 5], big_blind=4, small_blind=2)),
@@ -657,6 +676,17 @@ def main():
             with open(os.path.join(HERE, name + ".json"), "w") as f:
                 json.dump(meta, f)
             print(name, "view records:", len(views) * tables)
+    for name, (n, pol, seed, tables, steps, base, cfg) in ALIAS_SETS.items():
+        if want(name):
+            held = []
+            out = game_trajectory(n, pol, seed, tables, steps, base, cfg, full=False, held=held)
+            meta = json.loads(str(out["meta"]))
+            meta["actions"] = out["actions"].tolist()
+            meta["flags"] = out["flags"].tolist()
+            meta["held"] = held              # [step][table] -> the view made BEFORE the step, as it was then and as it reads after the step
+            with open(os.path.join(HERE, name + ".json"), "w") as f:
+                json.dump(meta, f)
+            print(name, "held views:", len(held) * tables, "of which across a setup_hand:", sum(h["setup_hands"] > 0 for row in held for h in row))
     for name, (n, pol, seed, tables, steps, base, cfg) in NORESET_SETS.items():
         if want(name):
             out = game_trajectory(n, pol, seed, tables, steps, base, cfg, auto_reset=False)

@@ -160,6 +160,7 @@ GAME_SETS = ["game_n2_random", "game_n6_random", "game_n9_random", "game_n6_alli
 DIGEST_SETS = ["digest_n2_random", "digest_n6_random", "digest_n9_random", "digest_n9_allin", "digest_n6_shard1",
                "digest_n6_shard7", "digest_n15_random", "digest_n16_random"]
 VIEW_SETS = ["views_n6_random", "views_n3_percredits", "views_n13_random", "views_n16_random"]
+ALIAS_SETS = ["views_alias_n6_random", "views_alias_n3_percredits"]   # a StateView held across a step: what the reference's aliasing shows (game.py:128-130)
 ENV_SETS = ["env_n4_random", "env_n6_random", "env_n6_vs_allin", "env_n2_random", "env_n5_percredits",
             "env_n9_random_hi_base", "env_n3_big_blinds_vs_allin", "env_n3_vs_call", "env_n4_mixed_opponents",
             "env_n6_mixed_percredits", "env_n2_call_vs_call", "env_n11_random", "env_n12_mixed_opponents",

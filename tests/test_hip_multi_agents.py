@@ -400,6 +400,17 @@ def test_pool_over_a_device_list_plays_the_single_handle_trajectories(O):
     assert np.concatenate([o[0] for o in outs]).tobytes() == obs.tobytes()
     assert np.concatenate([o[1] for o in outs]).tobytes() == rew.tobytes()
     assert np.array_equal(np.concatenate([o[2] for o in outs]), done)
+    # an invalid action: by default (strict=False, nothing blocks before the launches) it is NOT raised -- that table is left unstepped and
+    # its terr says so; strict=True checks every batch first (in parallel on the pool's threads) and raises before any table of any batch moved
+    bad = one.game.pick_actions(0); bad[1203] = 9; bad[1499] = -3
+    before = [e.game.step_serial for e in pool.envs]
+    with pytest.raises(ValueError, match=r"table 1203\)"):
+        pool.step_pipelined(bad, obs=None, strict=True)
+    assert all(np.array_equal(b, e.game.step_serial) for b, e in zip(before, pool.envs))
+    terr = np.concatenate([o[4] for o in pool.step_pipelined(bad, obs=None)])
+    assert terr[1203] == 1 and terr[1499] == 1 and int((terr == 1).sum()) == 2
+    after = np.concatenate([e.game.step_serial for e in pool.envs])
+    assert after[1203] == np.concatenate(before)[1203] and (np.delete(after, [1203, 1499]) > np.delete(np.concatenate(before), [1203, 1499])).all()
     pool.close(); one.close()
 
 

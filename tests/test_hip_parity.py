@@ -1,6 +1,7 @@
 """GPU parity tests: the HIP path, called through the C ABI (ctypes), against (a) the golden vectors captured from the
 imported reference and (b) the CPU oracle on seeded inputs.  Bit-exact everywhere (bytes of every f64 compared)."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -534,6 +535,32 @@ def test_stream_pool_drain(HB):
     g.reset()
     assert g.rollout(5, 0)["steps"] == 256 * 5
     g.close()
+
+
+def test_create_survives_a_device_reset_with_pooled_streams(tmp_path):
+    """a host application that calls hipDeviceReset WITHOUT draining the stream pool leaves dead handles in it.  pk_create now checks
+    a pooled stream (hipStreamQuery) before using it, drops the device's pool when it finds a dead one and creates a fresh stream; a stream that
+    cannot be synchronised at pk_destroy is not pooled.  In a process of its own (a device reset takes every allocation of the process down)."""
+    import subprocess
+    import sys
+    script = tmp_path / "reset_pool.py"
+    script.write_text("""
+import ctypes as C, sys
+sys.path.insert(0, %r)
+import numpy as np
+import pokerl_amd
+hip = C.CDLL("libamdhip64.so")
+g = pokerl_amd.VecGame(256, num_players=3); g.reset(); assert g.rollout(5, 0)["steps"] == 1280
+g.close()                                   # its stream goes to the pool ...
+assert hip.hipDeviceReset() == 0            # ... and dies there
+for _ in range(2):                          # the first create finds the dead handle; the second one a healthy pool again
+    g = pokerl_amd.VecGame(256, num_players=3); g.reset()
+    assert g.rollout(7, 0)["steps"] == 256 * 7
+    g.close()
+print("ok")
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), (out.returncode, out.stdout[-500:], out.stderr[-2000:])
 
 
 def test_async_game_step(HB, O):

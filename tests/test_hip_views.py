@@ -726,3 +726,35 @@ def test_step_kernels_write_the_observation_rows(HB, O):
             for x in b.values():
                 x.free()
             hb.g.close()
+
+
+@pytest.mark.parametrize("name", GU.ALIAS_SETS)
+def test_state_views_are_snapshots_and_the_live_arrays_replace_the_alias(HB, name):
+    """The one place where the host mirror's StateView differs from the reference's: there `view.credits / bets / pending_bets` ALIAS the game's
+    arrays (game.py:128-130), here a view is a snapshot of the step it was made after.  Pinned against the reference's own behaviour
+    (views_alias_* fixtures: a view made before every step, dumped again after it): our held view still reads as the reference's did AT
+    CREATION, and what the reference's held view shows afterwards for credits / bets is what VecGame.credits / .bets return -- the documented
+    replacement for code that relied on the aliasing."""
+    meta = GU.load_json(name)
+    h = HB.from_meta(meta)
+    g = h.g
+    h.reset(dealer=meta.get("dealer", 0))
+    T = meta["tables"]
+    for s in range(meta["steps"]):
+        kept = g.state_views()                                  # made before the step, held across it
+        acts = np.array(meta["actions"][s], np.int32)
+        assert np.array_equal(h.pick_actions(meta["policy"]), acts)
+        flags, err = h.step(acts)
+        assert not err.any() and flags.tolist() == meta["flags"][s]
+        credits, bets, pending = g.credits, g.bets, g.pending_bets
+        for t in range(T):
+            rec = meta["held"][s][t]
+            assert _tuple_of(kept[t]) == rec["at_creation"], (s, t)                     # a snapshot: untouched by the step
+            assert _hex(credits[t]) == rec["after_step"]["credits"] == rec["live"]["credits"], (s, t)
+            assert _hex(bets[t]) == rec["after_step"]["bets"], (s, t)
+            assert _hex(pending[t]) == rec["live"]["pending_bets"], (s, t)
+            if rec["setup_hands"] == 0:
+                assert _hex(pending[t]) == rec["after_step"]["pending_bets"], (s, t)
+        reset = (flags & 1).astype(np.uint8)
+        if reset.any():
+            h.reset(mask=reset)

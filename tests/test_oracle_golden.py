@@ -170,3 +170,29 @@ def test_eval7_exhaustive_digest_vs_reference():
     assert counts.tolist() == gold["category_counts"]
     assert ["%016x" % int(x) for x in per_first] == gold["per_first_card"]
     assert "%016x" % (int(per_first.astype(object).sum()) % (1 << 64)) == gold["digest"]
+
+
+@pytest.mark.parametrize("name", GU.ALIAS_SETS)
+def test_reference_state_view_alias_rule(name):
+    """What a StateView HELD across a Game.step shows in the reference (game.py:128-130 `self.credits = game.credits` ...), recorded from the
+    imported reference by tests/golden/make_golden.py (ALIAS_SETS): credits and bets are the game's live arrays (only ever mutated in place);
+    pending_bets is live until the next setup_hand rebinds the game's attribute (game.py:445), after which the view keeps the old array as
+    game.py:438-440 left it -- zeros + the new hand's blinds, UNCLIPPED; every other field is a value or a fresh object and stays as it was.
+    pokerl_amd.StateView is a snapshot instead (the GPU twin of this test pins that and the replacement rule)."""
+    m = GU.load_json(name)
+    n, cfg = m["n"], m["cfg"]
+    across = 0
+    for row in m["held"]:
+        for h in row:
+            a, b, live = h["at_creation"], h["after_step"], h["live"]
+            assert b["credits"] == live["credits"] and b["bets"] == live["bets"]
+            for k in ("player", "valid_actions", "num_players", "turn", "player_cards", "community_cards", "minimum_raise_value"):
+                assert a[k] == b[k], k
+            if h["setup_hands"] == 0:
+                assert b["pending_bets"] == live["pending_bets"]
+            elif h["setup_hands"] == 1:
+                frozen = [0.0] * n
+                frozen[live["bb"]] = float(cfg["big_blind"]); frozen[live["sb"]] = float(cfg["small_blind"])     # (:440: the small blind is written last)
+                assert b["pending_bets"] == [x.hex() for x in frozen]
+                across += 1
+    assert across > 50
