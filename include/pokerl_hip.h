@@ -454,8 +454,10 @@ int pk_sync(pk_handle *h);
  * queues); the sub-batch streams of pk_set_env_batches are created at the HIGHEST stream priority (env PK_ENV_STREAM_PRIO=0: normal), so a
  * learner's normal-priority kernels on the same GPU yield to the env ranges while those run.  pk_stream_pool_drain destroys the pooled (idle)
  * streams of `device` (-1: all devices) and returns how many -- call it before hipDeviceReset, which would leave stale handles in the pool
- * (pk_create checks a pooled stream with hipStreamQuery before using it and drops the device's whole pool when it finds a dead one; a stream that
- * cannot be synchronised when its handle is destroyed is not pooled), or to give the queues back. */
+ * -- any call on such a handle, a query included, crashes inside the HIP runtime -- or to give the queues back.  Seat belt for an application that
+ * forgets: the pool keeps a small canary allocation per device and looks its ADDRESS up (hipMemGetAddressRange) before it hands a pooled stream out; a
+ * canary that has vanished means the device was reset, and the pool forgets its handles instead of using them (a stream that cannot be synchronised when
+ * its handle is destroyed is not pooled either). */
 int pk_stream_pool_drain(int device);
 /* Runs `reps` back-to-back fused rollouts of k_steps each (never coalesced) plus the flush of what they deferred and
  * returns the device time of all of it divided by `reps`, in milliseconds (events on the handle's stream): the time one

@@ -289,26 +289,36 @@ static std::vector<hipStream_t> g_stream_pool[PK_MAX_DEVICES][2];   // [device][
 // (one hipMemcpy or one torch kernel brings it to life) and whatever else the process has created -- with normal-priority streams a
 // process that had merely made one hipMemcpy before creating the handle ran 524 288 x 6 in three sub-batches at 2.57 G env.step/s
 // against 3.66 G (tools/env_queue_scenarios.py).  env PK_ENV_STREAM_PRIO=0: off.
+// How the pool notices a device reset WITHOUT touching a pooled (then dangling) stream handle: a small device allocation made when the first stream
+// of a device is pooled.  hipMemGetAddressRange looks an ADDRESS up in the runtime's allocation map -- no dereference of a dead object -- and
+// after a reset the canary is gone from it (or, should the application have re-allocated that very address in the meantime, would have to
+// come back with the same odd size: not impossible, so pk_stream_pool_drain before hipDeviceReset remains the rule; this is the seat belt).
+static void *g_pool_canary[PK_MAX_DEVICES];
+static const size_t POOL_CANARY_BYTES = 4096 + 272;
+static bool pool_alive(int device) {   // caller holds g_stream_mu and has the device current
+    void *c = g_pool_canary[device];
+    if (!c) return false;
+    hipDeviceptr_t base = nullptr;
+    size_t size = 0;
+    const hipError_t e = hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)c);
+    if (e != hipSuccess) (void)hipGetLastError();
+    const bool ok = e == hipSuccess && (void *)base == c && size == POOL_CANARY_BYTES;
+    if (!ok) g_pool_canary[device] = nullptr;          // (not freed: it no longer exists)
+    return ok;
+}
 static hipError_t stream_acquire(int device, hipStream_t *out, bool sub_batch = false) {   // the device is current
     static const bool prio = !(getenv("PK_ENV_STREAM_PRIO") && atoi(getenv("PK_ENV_STREAM_PRIO")) == 0);
     const int cls = (sub_batch && prio) ? 1 : 0;
     if (device >= 0 && device < PK_MAX_DEVICES) {
         std::lock_guard<std::mutex> lock(g_stream_mu);
         auto &pool = g_stream_pool[device][cls];
-        while (!pool.empty()) {
-            // A pooled handle may be STALE: the application reset the device (hipDeviceReset invalidates every stream) without draining the
-            // pool first.  hipStreamQuery tells: an idle live stream answers hipSuccess; anything else and the whole pool of this device is
-            // dropped -- its handles date from the same context -- and a fresh stream is created below.  (Round 5 accepted whatever it popped:
-            // the later uploads failed, pk_destroy put the dead handle back, and every pk_create on that device failed from then on: ADVICE r05.)
-            hipStream_t s = pool.back();
-            pool.pop_back();
-            const hipError_t q = hipStreamQuery(s);
-            if (q == hipSuccess) { *out = s; return hipSuccess; }
-            (void)hipGetLastError();
-            if (q == hipErrorNotReady) { (void)hipStreamSynchronize(s); (void)hipGetLastError(); continue; }   // (cannot happen: streams are pooled idle; not reused either way)
-            for (int c = 0; c < 2; ++c) g_stream_pool[device][c].clear();    // stale context: nothing left to destroy
-            break;
+        if (!pool.empty() && !pool_alive(device)) {
+            // The application reset the device (hipDeviceReset destroys every stream) without pk_stream_pool_drain: the pooled handles are
+            // dangling pointers -- ANY call on one, hipStreamQuery included, segfaults inside the runtime (measured, ROCm 7.2).  Forget them
+            // (nothing is left to destroy) and create a fresh stream below.
+            for (int c = 0; c < 2; ++c) g_stream_pool[device][c].clear();
         }
+        if (!pool.empty()) { *out = pool.back(); pool.pop_back(); return hipSuccess; }
     }
     if (cls == 1) {
         int least = 0, greatest = 0;
@@ -327,6 +337,10 @@ static void stream_release(int device, hipStream_t s, bool sub_batch = false) { 
     static const bool prio = !(getenv("PK_ENV_STREAM_PRIO") && atoi(getenv("PK_ENV_STREAM_PRIO")) == 0);
     if (device >= 0 && device < PK_MAX_DEVICES) {
         std::lock_guard<std::mutex> lock(g_stream_mu);
+        if (!g_pool_canary[device]) {                  // the pool's reset detector (pool_alive); without one the stream is not pooled
+            for (int c = 0; c < 2; ++c) g_stream_pool[device][c].clear();    // (whatever was pooled under an earlier, vanished canary is stale)
+            if (hipMalloc(&g_pool_canary[device], POOL_CANARY_BYTES) != hipSuccess) { (void)hipGetLastError(); g_pool_canary[device] = nullptr; (void)hipStreamDestroy(s); return; }
+        }
         g_stream_pool[device][(sub_batch && prio) ? 1 : 0].push_back(s);
     } else (void)hipStreamDestroy(s);
 }
@@ -342,9 +356,16 @@ static int drain_stream_pool(int device) {
             auto &pool = g_stream_pool[d][cls];
             if (pool.empty()) continue;
             DeviceGuard guard(d);
-            for (hipStream_t s : pool) { if (guard.ok) (void)hipStreamDestroy(s); ++n; }
-            (void)hipGetLastError();      // (a stream the application's device reset already killed: nothing left to destroy)
+            const bool alive = guard.ok && pool_alive(d);     // (after a device reset the handles are dangling: dropped, not destroyed)
+            for (hipStream_t s : pool) { if (alive) (void)hipStreamDestroy(s); ++n; }
+            (void)hipGetLastError();
             pool.clear();
+        }
+        if (g_pool_canary[d] && g_stream_pool[d][0].empty() && g_stream_pool[d][1].empty()) {
+            DeviceGuard guard(d);
+            if (guard.ok && pool_alive(d)) (void)hipFree(g_pool_canary[d]);
+            (void)hipGetLastError();
+            g_pool_canary[d] = nullptr;
         }
     }
     return n;
@@ -1328,13 +1349,27 @@ static int check_device(int device) {
 // Grow-only device scratch of the host-buffer judger calls, one per device: no hipMalloc / hipFree per call.
 static std::mutex g_scratch_mu;
 static struct { void *p; size_t cap; } g_scratch[PK_MAX_DEVICES];
+// A per-device cache of device memory (the judger's scratch arena, the evaluator table) outlives its allocation when the application resets the
+// device: a kernel launched on such a pointer would fault.  Same seat belt as the stream pool's canary: look the ADDRESS up before trusting it.
+// The allocator hands the same addresses out again after a reset (measured: the evaluator table's address came back as the next handle's arena),
+// so base AND size must match -- and every cached allocation has an odd size (PK_ODD_BYTES more than it needs) that no caller is likely to ask for.
+#define PK_ODD_BYTES 272
+static bool dev_alloc_alive(const void *p, size_t bytes) {
+    if (!p) return false;
+    hipDeviceptr_t base = nullptr;
+    size_t size = 0;
+    const hipError_t e = hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)p);
+    if (e != hipSuccess) (void)hipGetLastError();
+    return e == hipSuccess && (const void *)base == p && size == bytes;
+}
 static void *scratch(int device, size_t bytes) {  // caller holds g_scratch_mu and has the device current
     auto &s = g_scratch[device];
+    if (s.p && !dev_alloc_alive(s.p, s.cap + PK_ODD_BYTES)) { s.p = nullptr; s.cap = 0; }      // (the device was reset: the arena is gone, not freed)
     if (s.cap < bytes) {
         if (s.p) (void)hipFree(s.p);
         s.p = nullptr; s.cap = 0;
         size_t want = bytes < (1u << 20) ? (1u << 20) : bytes + bytes / 2;
-        if (hipMalloc(&s.p, want) != hipSuccess) { s.p = nullptr; return nullptr; }
+        if (hipMalloc(&s.p, want + PK_ODD_BYTES) != hipSuccess) { (void)hipGetLastError(); s.p = nullptr; return nullptr; }
         s.cap = want;
     }
     return s.p;
@@ -1431,9 +1466,10 @@ static uint32_t *g_eval_tab[PK_MAX_DEVICES];
 static const uint32_t *eval7_table(int device) {   // the device is current
     if (device < 0 || device >= PK_MAX_DEVICES) return nullptr;
     std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (g_eval_tab[device] && !dev_alloc_alive(g_eval_tab[device], EVAL7_TAB_WORDS * 4 + PK_ODD_BYTES)) g_eval_tab[device] = nullptr;   // (the device was reset: build it again)
     if (!g_eval_tab[device]) {
         uint32_t *p = nullptr;
-        if (hipMalloc((void **)&p, EVAL7_TAB_WORDS * 4) != hipSuccess) return nullptr;
+        if (hipMalloc((void **)&p, EVAL7_TAB_WORDS * 4 + PK_ODD_BYTES) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
         hipLaunchKernelGGL(k_make_eval7_tab, dim3(EVAL7_TAB_WORDS / 256), dim3(256), 0, 0, p);
         if (hipGetLastError() != hipSuccess || hipStreamSynchronize(0) != hipSuccess) { (void)hipFree(p); return nullptr; }
         g_eval_tab[device] = p;

@@ -305,11 +305,18 @@ __device__ __forceinline__ uint32_t compare_rankings(const uint32_t (&v)[N], int
 //   * the `flush` group is the suit with >=5 cards, else the lowest suit present (:52-58);
 //   * wheel checks are if/elif (:83-88): a 5-4-3-2 run in that group without its ace suppresses the plain wheel.
 // Equality with the reference on all C(52,7) hands is a test (tests/test_hip_parity.py, eval7 digest).
-__device__ __forceinline__ uint32_t eval7_distinct(const uint32_t (&c)[7]) {
-    // A card byte (suit<<4)|rank0 (cards.py:28-62) is already a bit index into a 64-bit word of four 16-bit suit lanes.
-    uint64_t bits = 0;
-#pragma unroll
-    for (int i = 0; i < 7; ++i) bits |= 1ull << (c[i] & 63);
+// ONE body for the in-game evaluator (SEVEN: the hand holds seven cards, every kicker tail is complete -- eval7_distinct) and for
+// n = 3 .. 7 DISTINCT cards with len(kickers) (eval_distinct_n, the register fast path of pk_eval_hands(_d) -- the reference's sort-and-scan,
+// eval_hand above, ~570 executed instructions, is needed only for hands that repeat a card, which its own tests feed it and a game never
+// does).  Same derivation for both (the scan of judger.py:50-99 visits fewer cards, its rules are the same); what changes with fewer
+// cards is the LENGTH of the kicker lists -- `islice(others, count)` yields what is there (judger.py:91-99) -- and get_kickers_value
+// (judger.py:101-109) packs the list as it is, so the tail takes min(nm, ranks left) nibbles.  Equal to eval_hand on EVERY 3-, 4-, 5-,
+// 6- and 7-card subset of the deck (rank, kickers value and count: tools/host_sim `evaln`); round 6 folded the two former copies of this
+// body into one template with the ISA of k_rollout<6> unchanged instruction for instruction.
+// `bits`: OR of (1 << Card.value) over the hand: a card byte (suit<<4)|rank0 (cards.py:28-62) is already a bit index into a 64-bit
+// word of four 16-bit suit lanes.
+template <bool SEVEN>
+__device__ __forceinline__ uint32_t eval_distinct_bits(uint64_t bits, int &nk) {
     // ace-high inside every lane at once (cards.py:14): rank0 0 (ace) -> bit 12, rank0 k -> bit k-1
     const uint64_t hi = ((bits >> 1) & 0x0fff0fff0fff0fffull) | ((bits & 0x0001000100010001ull) << 12);
     const uint32_t h01 = (uint32_t)hi, h23 = (uint32_t)(hi >> 32);
@@ -354,69 +361,11 @@ __device__ __forceinline__ uint32_t eval7_distinct(const uint32_t (&c)[7]) {
         taken |= take ? bit : 0; L = take ? (L & ~bit) : L;
     }
     uint32_t m = base & ~taken;
+    if constexpr (!SEVEN) {
+        const int left = __popc(m);
+        nm = nm < left ? nm : left;                                                // islice yields what is there
+    }
     // the top five ranks of m unconditionally (an exhausted mask yields rank nibble 0), then the top nm of them by a shift
-    uint32_t k5 = 0;
-#pragma unroll
-    for (int i = 0; i < 5; ++i) {
-        const uint32_t lz = (uint32_t)__clz((int)m);
-        k5 = (k5 << 4) | (32u - lz);
-        m &= ~(0x80000000u >> (lz & 31));
-    }
-    kick = (kick << (4 * nm)) | (nm ? (k5 >> (4 * (5 - nm))) : 0u);
-    return (cat << 20) | kick;
-}
-
-// eval7_distinct generalised to n = 3 .. 7 DISTINCT cards, with len(kickers): the fast path of pk_eval_hands(_d) -- the reference's
-// sort-and-scan (eval_hand above, ~570 executed instructions) is needed only for hands that repeat a card, which its own tests feed
-// it and a game never does.  Same derivation as eval7_distinct (the scan of judger.py:50-99 visits fewer cards, its rules are the
-// same); what changes with fewer cards is the LENGTH of the kicker lists -- `islice(others, count)` yields what is there
-// (judger.py:91-99) -- and get_kickers_value (judger.py:101-109) packs the list as it is, so the tail takes min(nm, ranks left) nibbles.
-// Equal to eval_hand on EVERY 3-, 4-, 5-, 6- and 7-card subset of the deck (rank, kickers value and count: tools/host_sim `evaln`).
-__device__ __forceinline__ uint32_t eval_distinct_n(const uint32_t (&c)[7], int n, int &nk) {
-    uint64_t bits = 0;
-#pragma unroll
-    for (int i = 0; i < 7; ++i) bits |= (i < n) ? (1ull << (c[i] & 63)) : 0ull;
-    const uint64_t hi = ((bits >> 1) & 0x0fff0fff0fff0fffull) | ((bits & 0x0001000100010001ull) << 12);
-    const uint32_t h01 = (uint32_t)hi, h23 = (uint32_t)(hi >> 32);
-    const uint32_t sa = h01 & 0x1fff, sb = h01 >> 16, sc = h23 & 0x1fff, sd = h23 >> 16;
-    const uint32_t um = sa | sb | sc | sd;
-    const uint32_t s1 = sa ^ sb, c1 = sa & sb, s2 = sc ^ sd, c2 = sc & sd;
-    const uint32_t bit0 = s1 ^ s2, t = c1 ^ c2 ^ (s1 & s2), quads = c1 & c2;
-    const uint32_t pairs = t & ~bit0, trips = t & bit0;
-    const bool fa = __popc(sa) >= 5, fb = __popc(sb) >= 5, fc = __popc(sc) >= 5, fd = __popc(sd) >= 5;
-    const bool has_flush = fa || fb || fc || fd;
-    uint32_t gm = sa ? sa : (sb ? sb : (sc ? sc : sd));
-    gm = fa ? sa : (fb ? sb : (fc ? sc : (fd ? sd : gm)));
-    const uint32_t run = gm & ~(gm + (gm & (0u - gm)));
-    const int bcount = __popc(run), btop = 31 - __clz((int)run);
-    const uint32_t m5 = um & (um >> 1) & (um >> 2) & (um >> 3) & (um >> 4);
-    uint32_t cat = HR_HIGH, L = 0, base = um, direct = 0;
-    int nl = 0, nm = 5;
-    if (pairs) { cat = HR_PAIR; L = pairs; nl = 1; nm = 3; }
-    if (pairs & (pairs - 1)) { cat = HR_TWO_PAIR; nl = 2; nm = 1; }
-    if (trips) { cat = HR_TRIS; L = trips; nl = 1; nm = 2; }
-    if (m5) { cat = HR_STRAIGHT; direct = (uint32_t)(31 - __clz((int)m5) + 5); nl = 0; nm = 0; }
-    if (has_flush) { cat = HR_FLUSH; L = 0; nl = 0; base = gm; nm = 5; direct = 0; }
-    if (trips && pairs) { cat = HR_FULL; L = trips; nl = 1; base = pairs; nm = 1; direct = 0; }
-    if (trips & (trips - 1)) { cat = HR_FULL; L = trips; nl = 2; nm = 0; direct = 0; }
-    if (quads) { cat = HR_POKER; L = quads; nl = 1; base = um; nm = 1; direct = 0; }
-    if (bcount >= 5) { cat = HR_SF; direct = (uint32_t)(btop + 1); nl = 0; nm = 0; }
-    if (bcount == 4 && btop == 3) {
-        if (gm & (1u << 12)) { cat = HR_SF; direct = 4; nl = 0; nm = 0; }
-    } else if (m5 == 0 && (um & 0x1f) == 0xf) {
-        if (um & (1u << 12)) { cat = HR_STRAIGHT; direct = 4; nl = 0; nm = 0; }
-    }
-    uint32_t kick = direct, taken = 0;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        uint32_t bit = 0x80000000u >> (__clz((int)L) & 31);
-        bool take = i < nl;
-        kick = take ? ((kick << 4) | (uint32_t)(32 - __clz((int)L))) : kick;
-        taken |= take ? bit : 0; L = take ? (L & ~bit) : L;
-    }
-    uint32_t m = base & ~taken;
-    const int left = __popc(m);
-    nm = nm < left ? nm : left;                                                    // islice yields what is there
     uint32_t k5 = 0;
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
@@ -427,6 +376,19 @@ __device__ __forceinline__ uint32_t eval_distinct_n(const uint32_t (&c)[7], int 
     kick = (kick << (4 * nm)) | (nm ? (k5 >> (4 * (5 - nm))) : 0u);
     nk = (direct ? 1 : 0) + nl + nm;
     return (cat << 20) | kick;
+}
+__device__ __forceinline__ uint32_t eval7_distinct(const uint32_t (&c)[7]) {
+    uint64_t bits = 0;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) bits |= 1ull << (c[i] & 63);
+    int nk;
+    return eval_distinct_bits<true>(bits, nk);
+}
+__device__ __forceinline__ uint32_t eval_distinct_n(const uint32_t (&c)[7], int n, int &nk) {
+    uint64_t bits = 0;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) bits |= (i < n) ? (1ull << (c[i] & 63)) : 0ull;
+    return eval_distinct_bits<false>(bits, nk);
 }
 // pk_eval_hands' evaluator: the fast path above for 3..7 distinct cards, the literal scan otherwise (0..2 cards: its first lines)
 __device__ __forceinline__ bool distinct_valid_cards(const uint32_t (&c)[7], int n);
@@ -478,10 +440,9 @@ struct Eval7Front {
 __device__ __forceinline__ uint32_t eval7_tab_at(const uint32_t *T, uint32_t mask4) {
     return *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(T) + mask4);
 }
-__device__ __forceinline__ Eval7Front eval7_tab_front(uint32_t lo, uint32_t hi, const uint32_t *T) {
+// `bits` = OR of (4 << Card.value) over the hand's cards: four 16-bit suit lanes of raw rank masks, shifted left by two
+__device__ __forceinline__ Eval7Front eval7_tab_front_bits(uint64_t bits, const uint32_t *T) {
     Eval7Front f;
-    const uint64_t bits = (4ull << (lo & 63)) | (4ull << ((lo >> 8) & 63)) | (4ull << ((lo >> 16) & 63)) | (4ull << ((lo >> 24) & 63)) |
-                          (4ull << (hi & 63)) | (4ull << ((hi >> 8) & 63)) | (4ull << ((hi >> 16) & 63));
     const uint32_t w01 = (uint32_t)bits, w23 = (uint32_t)(bits >> 32);
     const uint32_t sa = w01 & 0xffffu, sb = w01 >> 16, sc = w23 & 0xffffu, sd = w23 >> 16;   // raw rank masks per suit (x 4)
     f.um = sa | sb | sc | sd;
@@ -499,7 +460,19 @@ __device__ __forceinline__ Eval7Front eval7_tab_front(uint32_t lo, uint32_t hi, 
     f.e_t = eval7_tab_at(T, f.trips); f.e_q = eval7_tab_at(T, f.quads);
     return f;
 }
-__device__ __forceinline__ uint32_t eval7_tab_back(const Eval7Front &f, const uint32_t *T) {
+__device__ __forceinline__ Eval7Front eval7_tab_front(uint32_t lo, uint32_t hi, const uint32_t *T) {
+    const uint64_t bits = (4ull << (lo & 63)) | (4ull << ((lo >> 8) & 63)) | (4ull << ((lo >> 16) & 63)) | (4ull << ((lo >> 24) & 63)) |
+                          (4ull << (hi & 63)) | (4ull << ((hi >> 8) & 63)) | (4ull << ((hi >> 16) & 63));
+    return eval7_tab_front_bits(bits, T);
+}
+// ONE back end (round 6: the two former copies folded, ISA of k_eval7_tab_stream unchanged instruction for instruction).  SEVEN: the caller
+// knows the hand holds 7 cards -- every tail is complete (the streaming evaluator); else n = 3 .. 7 DISTINCT cards with len(kickers): the table
+// path of pk_eval_hands(_d) (the partial-hand rank feature of examples/q_learning.py:29-33).  What changes with fewer cards is what
+// eval_distinct_bits states: `islice(others, count)` yields what is there (judger.py:91-99), so the tail takes min(nm, ranks left) nibbles and
+// the whole kicker word moves down by the nibbles that are missing; len(kickers) = the leading kickers of the category + that tail.  Equal to
+// eval_hand on EVERY 3-, 4-, 5-, 6- and 7-card subset of the deck (value and count: tools/host_sim `evalntab`).
+template <bool SEVEN, bool NK>   // NK: len(kickers) is wanted
+__device__ __forceinline__ uint32_t eval_tab_back(const Eval7Front &f, const uint32_t *T, int &nk) {
     const uint32_t p1 = (f.e_p >> 16) & 15u, p12 = (f.e_p >> 12) & 0xffu, p2 = p12 & 15u, p3 = (f.e_p >> 8) & 15u;
     const uint32_t t1 = (f.e_t >> 16) & 15u, t2 = (f.e_t >> 12) & 15u, q1 = (f.e_q >> 16) & 15u;
     const uint32_t st = (f.e_um >> 20) & 15u;
@@ -520,78 +493,43 @@ __device__ __forceinline__ uint32_t eval7_tab_back(const Eval7Front &f, const ui
     // and never the ace, so its raw bit is 1 << p3 -- 4 << p3 in the shifted masks; p3 == 0 must clear nothing)
     const uint32_t taken2 = f.pairs & ~((4u << p3) & ~4u);
     const uint32_t taken = q1 ? f.quads : (t1 ? f.trips : taken2);
-    const uint32_t tail = (eval7_tab_at(T, f.um & ~taken) & 0xfffffu) >> (((W >> 20) & 7u) << 2);
-    uint32_t v = ((10u - (W >> 24)) << 20) | (W & 0xfffffu) | tail;
+    const uint32_t rest = f.um & ~taken;
+    uint32_t v;
+    if constexpr (SEVEN && !NK) {     // (the streaming evaluator's own spelling of the same value: its ISA is what round 3 tuned, kept to the instruction)
+        const uint32_t tail = (eval7_tab_at(T, rest) & 0xfffffu) >> (((W >> 20) & 7u) << 2);
+        v = ((10u - (W >> 24)) << 20) | (W & 0xfffffu) | tail;
+    } else {
+        const uint32_t shift = (W >> 20) & 7u, cat = W >> 24;
+        const uint32_t nm0 = 5u - shift, left = SEVEN ? 5u : (uint32_t)__popc(rest);
+        const uint32_t nm = SEVEN ? nm0 : min(nm0, left);                                      // islice yields what is there
+        const uint32_t tail = (eval7_tab_at(T, rest) & 0xfffffu) >> (shift << 2);
+        const uint32_t kick = ((W & 0xfffffu) | tail) >> ((nm0 - nm) << 2);
+        // len(kickers): the leading kickers per category (HIGH 0, PAIR 1, TWO_PAIR 2, TRIS 1, STRAIGHT 1, FLUSH 5, FULL 2, POKER 1, SF 1) + the tail
+        if constexpr (NK) nk = (int)(((0x1125112100ull >> (cat << 2)) & 15u) + nm);
+        v = ((10u - cat) << 20) | kick;
+    }
     // wheel checks of judger.py:83-88, if / elif: a 5-4-3-2 run as the flush group's lowest run decides alone
     const bool low4 = (f.e_gm >> 24) == 0x34u;
     const bool wheel_sf = low4 && (f.gm & 4u);
     const bool wheel_st = !low4 && st == 0 && (f.e_um >> 24) == 0x34u && (f.um & 4u);
     v = wheel_st ? (((uint32_t)HR_STRAIGHT << 20) | 4u) : v;
     v = wheel_sf ? (((uint32_t)HR_SF << 20) | 4u) : v;
+    if constexpr (NK) nk = (wheel_st || wheel_sf) ? 1 : nk;
     return v;
+}
+__device__ __forceinline__ uint32_t eval7_tab_back(const Eval7Front &f, const uint32_t *T) {
+    int nk = 0;
+    return eval_tab_back<true, false>(f, T, nk);
 }
 __device__ __forceinline__ uint32_t eval7_tab(uint32_t lo, uint32_t hi, const uint32_t *T) {
     const Eval7Front f = eval7_tab_front(lo, hi, T);
     return eval7_tab_back(f, T);
 }
-
-// eval7_tab generalised to n = 3 .. 7 DISTINCT cards with len(kickers): the table path of pk_eval_hands(_d) (the partial-hand rank feature
-// of examples/q_learning.py:29-33).  What changes with fewer cards is what eval_distinct_n states: `islice(others, count)` yields what is there
-// (judger.py:91-99), so the tail takes min(nm, ranks left) nibbles and the whole kicker word moves down by the nibbles that are missing;
-// len(kickers) = the leading kickers of the category + that tail.  Equal to eval_hand on EVERY 3-, 4-, 5-, 6- and 7-card subset of the deck
-// (value and count: tools/host_sim `evalntab`).
-// Input: `bits` = OR of (4 << Card.value) over the hand's cards (four 16-bit suit lanes of rank masks shifted left by two, as in
-// eval7_tab_front).
-template <bool SEVEN = false>   // SEVEN: the caller knows the hand holds 7 cards -- every tail is complete (what eval7_tab assumes)
+// The table path of pk_eval_hands(_d) on the suit-lane bit set (see tab_bits_of); SEVEN: ncards == NULL, every hand holds seven cards.
+template <bool SEVEN = false>
 __device__ __forceinline__ uint32_t eval_tab_bits(uint64_t bits, const uint32_t *T, int &nk) {
-    Eval7Front f;
-    {
-        const uint32_t w01 = (uint32_t)bits, w23 = (uint32_t)(bits >> 32);
-        const uint32_t sa = w01 & 0xffffu, sb = w01 >> 16, sc = w23 & 0xffffu, sd = w23 >> 16;
-        f.um = sa | sb | sc | sd;
-        const uint32_t s1 = sa ^ sb, c1 = sa & sb, s2 = sc ^ sd, c2 = sc & sd;
-        const uint32_t bit0 = s1 ^ s2, t = c1 ^ c2 ^ (s1 & s2);
-        f.quads = c1 & c2; f.pairs = t & ~bit0; f.trips = t & bit0;
-        const uint32_t ka = ((uint32_t)__popc(sa) << 15) | sa, kb = ((uint32_t)__popc(sb) << 15) | sb;
-        const uint32_t kc = ((uint32_t)__popc(sc) << 15) | sc, kd = ((uint32_t)__popc(sd) << 15) | sd;
-        const uint32_t gk = max(max(ka, kb), max(kc, kd));
-        f.has_flush = gk >= (5u << 15);
-        const uint32_t lp = sa ? sa : (sb ? sb : (sc ? sc : sd));
-        f.gm = f.has_flush ? (gk & 0x7fffu) : lp;
-        f.e_um = eval7_tab_at(T, f.um); f.e_gm = eval7_tab_at(T, f.gm); f.e_p = eval7_tab_at(T, f.pairs);
-        f.e_t = eval7_tab_at(T, f.trips); f.e_q = eval7_tab_at(T, f.quads);
-    }
-    const uint32_t p1 = (f.e_p >> 16) & 15u, p12 = (f.e_p >> 12) & 0xffu, p2 = p12 & 15u, p3 = (f.e_p >> 8) & 15u;
-    const uint32_t t1 = (f.e_t >> 16) & 15u, t2 = (f.e_t >> 12) & 15u, q1 = (f.e_q >> 16) & 15u;
-    const uint32_t st = (f.e_um >> 20) & 15u;
-    uint32_t W = 1u << 24;                                                                     // (the candidates of eval7_tab_back)
-    const uint32_t w_p = p2 ? ((3u << 24) | (4u << 20) | (p12 << 4)) : ((2u << 24) | (2u << 20) | (p1 << 12));
-    W = max(W, p1 ? w_p : 0u);
-    const uint32_t x2 = t2 ? t2 : p1;
-    const uint32_t w_t = (x2 ? ((7u << 24) | (5u << 20) | x2) : ((4u << 24) | (3u << 20))) | (t1 << (x2 ? 4u : 8u));
-    W = max(W, t1 ? w_t : 0u);
-    W = max(W, st ? ((5u << 24) | (5u << 20) | st) : 0u);
-    W = max(W, f.has_flush ? ((6u << 24) | (5u << 20) | (f.e_gm & 0xfffffu)) : 0u);
-    W = max(W, q1 ? ((8u << 24) | (4u << 20) | (q1 << 4)) : 0u);
-    W = max(W, ((f.e_gm >> 24) & 15u) >= 5u ? ((9u << 24) | (5u << 20) | ((f.e_gm >> 28) + 1u)) : 0u);
-    const uint32_t taken2 = f.pairs & ~((4u << p3) & ~4u);
-    const uint32_t taken = q1 ? f.quads : (t1 ? f.trips : taken2);
-    const uint32_t rest = f.um & ~taken;
-    const uint32_t shift = (W >> 20) & 7u, cat = W >> 24;
-    const uint32_t nm0 = 5u - shift, left = SEVEN ? 5u : (uint32_t)__popc(rest);
-    const uint32_t nm = SEVEN ? nm0 : min(nm0, left);                                          // islice yields what is there
-    const uint32_t tail = (eval7_tab_at(T, rest) & 0xfffffu) >> (shift << 2);
-    const uint32_t kick = ((W & 0xfffffu) | tail) >> ((nm0 - nm) << 2);
-    // len(kickers): the leading kickers per category (HIGH 0, PAIR 1, TWO_PAIR 2, TRIS 1, STRAIGHT 1, FLUSH 5, FULL 2, POKER 1, SF 1) + the tail
-    nk = (int)(((0x1125112100ull >> (cat << 2)) & 15u) + nm);
-    uint32_t v = ((10u - cat) << 20) | kick;
-    const bool low4 = (f.e_gm >> 24) == 0x34u;                                                 // judger.py:83-88, if / elif
-    const bool wheel_sf = low4 && (f.gm & 4u);
-    const bool wheel_st = !low4 && st == 0 && (f.e_um >> 24) == 0x34u && (f.um & 4u);
-    v = wheel_st ? (((uint32_t)HR_STRAIGHT << 20) | 4u) : v;
-    v = wheel_sf ? (((uint32_t)HR_SF << 20) | 4u) : v;
-    nk = (wheel_st || wheel_sf) ? 1 : nk;
-    return v;
+    const Eval7Front f = eval7_tab_front_bits(bits, T);
+    return eval_tab_back<SEVEN, true>(f, T, nk);
 }
 // Front end on the PACKED hand (card i = byte i of w, n = 3 .. 7 cards; bytes from n on are ignored): the suit-lane bit set of
 // eval_tab_bits and, with it, whether the hand may take the table at all -- every used byte a real card (suit < 4: byte < 0x40; rank0 < 13)

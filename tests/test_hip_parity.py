@@ -526,7 +526,11 @@ def test_stream_pool_drain(HB):
     lib = L.lib()
     g = pokerl_amd.VecGame(256, num_players=3)
     g.reset(); g.rollout(10, 0)
+    first = g.stream
     g.close()                                           # its stream goes to the pool
+    g = pokerl_amd.VecGame(64, num_players=2)           # ... and comes back out of it (the pool's reset detector -- a canary allocation whose
+    assert g.stream == first                            #     address range is looked up -- says the device has not been reset)
+    g.close()
     n = lib.pk_stream_pool_drain(0)
     assert n >= 1
     assert lib.pk_stream_pool_drain(0) == 0 and lib.pk_stream_pool_drain(-1) == 0
@@ -538,9 +542,10 @@ def test_stream_pool_drain(HB):
 
 
 def test_create_survives_a_device_reset_with_pooled_streams(tmp_path):
-    """a host application that calls hipDeviceReset WITHOUT draining the stream pool leaves dead handles in it.  pk_create now checks
-    a pooled stream (hipStreamQuery) before using it, drops the device's pool when it finds a dead one and creates a fresh stream; a stream that
-    cannot be synchronised at pk_destroy is not pooled.  In a process of its own (a device reset takes every allocation of the process down)."""
+    """a host application that calls hipDeviceReset WITHOUT draining the stream pool leaves dead handles in it.  Any call on such a handle
+    -- a query included -- crashes inside the runtime, so the pool keeps a canary allocation per device and looks its address up before handing a
+    stream out: canary gone = device reset = the pool (and the judger's per-device table / scratch arena) is forgotten, not used.  In a process of
+    its own (a device reset takes every allocation of the process down)."""
     import subprocess
     import sys
     script = tmp_path / "reset_pool.py"
@@ -550,13 +555,16 @@ sys.path.insert(0, %r)
 import numpy as np
 import pokerl_amd
 hip = C.CDLL("libamdhip64.so")
+hands = [["AS", "KS", "QS", "JS", "TS", "2D", "3C"], ["2S", "2H", "5D", "9C", "KD", "3S", "7H"]]
+before = [pokerl_amd.eval_hand(h) for h in hands]          # builds the per-device evaluator table and the judger's scratch arena
 g = pokerl_amd.VecGame(256, num_players=3); g.reset(); assert g.rollout(5, 0)["steps"] == 1280
 g.close()                                   # its stream goes to the pool ...
-assert hip.hipDeviceReset() == 0            # ... and dies there
-for _ in range(2):                          # the first create finds the dead handle; the second one a healthy pool again
+assert hip.hipDeviceReset() == 0            # ... and dies there, with the table and the arena
+for _ in range(2):                          # the first create finds the canary gone and forgets the pool; the second one a healthy pool again
     g = pokerl_amd.VecGame(256, num_players=3); g.reset()
     assert g.rollout(7, 0)["steps"] == 256 * 7
     g.close()
+assert [pokerl_amd.eval_hand(h) for h in hands] == before   # the table was rebuilt, not used stale
 print("ok")
 """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300)

@@ -17,11 +17,16 @@ dst = os.path.join(root, "profiles")
 shutil.copy(glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0], os.path.join(dst, tag + "_kernel_stats.csv"))
 rows = [r for r in csv.DictReader(open(glob.glob(os.path.join(src, "trace", "*", "*_kernel_trace.csv"))[0]))
         if kname in r["Kernel_Name"] and "stream" in r["Kernel_Name"]]
-durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in rows]
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 run = json.load(open(os.path.join(src, "unprofiled.json")))
+all_durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in rows]
+skip = int(run.get("warm_dispatches", 0)) + 1          # tools/eval7_bench.py's warm-up call and the untimed first dispatch of the timed call: the clock ramps
+rows = rows[skip:] if len(rows) > skip + 2 else rows
+durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in rows]
 m = run["hands"]
 s = {"tag": tag, "kernel": rows[0]["Kernel_Name"], "hands_per_launch": m, "launches": len(durs),
      "avg_launch_ms": sum(durs) / len(durs) / 1e6, "min_launch_ms": min(durs) / 1e6,
+     "launch_ms_of_every_dispatch_traced": [d / 1e6 for d in all_durs], "warm_dispatches_skipped": skip if len(durs) != len(all_durs) else 0,
      "vgpr": int(rows[0]["VGPR_Count"]), "sgpr": int(rows[0]["SGPR_Count"]), "lds_bytes": int(rows[0]["LDS_Block_Size"]),
      "workgroup": int(rows[0]["Workgroup_Size_X"]), "grid": int(rows[0]["Grid_Size_X"]), "unprofiled_run": run}
 c = {}
@@ -31,6 +36,7 @@ for f in sorted(glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.
         if kname in r["Kernel_Name"] and "stream" in r["Kernel_Name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in agg.items():
+        v = v[skip:] if len(v) > skip + 2 else v          # (the CSV is in dispatch order: the same warm-up dispatches as in the trace are left out)
         c[k] = sum(v) / len(v)
 s["pmc_per_launch"] = c
 if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
