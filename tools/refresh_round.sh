@@ -42,6 +42,9 @@ python bench.py --mode step --steps 2000 --warmup 200 --step-replay 2>/dev/null 
 python bench.py --mode step --steps 2000 --warmup 200 --step-unfused-reset 2>/dev/null | tail -1 > gpurun_out/${R}_bench_step_65536x6_unfused_reset.json
 python bench.py --mode step --tables 1048576 --steps 300 --warmup 50 --step-replay 2>/dev/null | tail -1 > gpurun_out/${R}_bench_step_1048576x6_replay.json
 python bench.py --mode step --steps 2000 --warmup 200 --step-async 1 2>/dev/null | tail -1 > gpurun_out/${R}_bench_step_async_65536x6.json
+python bench.py --mode step --steps 2000 --warmup 200 --step-replay --step-obs packed --step-obs-separate 2>/dev/null | tail -1 > gpurun_out/${R}_bench_step_obs2_65536x6.json
+python bench.py --mode step --steps 2000 --warmup 200 --step-replay --step-obs packed 2>/dev/null | tail -1 > gpurun_out/${R}_bench_step_obsfused_65536x6.json
+tools/r06_step_obs_ab.sh gpurun_out/${R}_step_obs_ab.txt > /dev/null 2>&1
 python bench.py --mode env --steps 200 --warmup 20 2>/dev/null | tail -1 > gpurun_out/${R}_bench_env.json
 python bench.py --mode env --steps 200 --warmup 20 --env-batches 4 2>/dev/null | tail -1 > gpurun_out/${R}_bench_env_sync_batches4.json
 python bench.py --mode env --steps 2000 --warmup 200 --env-async 8 2>/dev/null | tail -1 > gpurun_out/${R}_bench_env_async8_batches1.json

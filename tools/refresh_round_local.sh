@@ -25,7 +25,7 @@ print('$t', {k: (round(v, 4) if isinstance(v, float) else v) for k, v in d.items
 PY
 done
 [ -d gpurun_out/prof_${R}_eval7 ] && python tools/summarize_eval7.py ${R}_eval7 | tail -3
-for t in ${R}_step_65536x6 ${R}_step_1048576x6 ${R}_step_async_65536x6; do
+for t in ${R}_step_65536x6 ${R}_step_1048576x6 ${R}_step_async_65536x6 ${R}_step_obs2_65536x6 ${R}_step_obsfused_65536x6; do
   [ -d gpurun_out/prof_$t ] || continue
   python tools/summarize_step_profile.py $t > /tmp/sum_$t.txt 2>&1 || tail -3 /tmp/sum_$t.txt
   python - <<PY
@@ -34,9 +34,9 @@ d = json.load(open('profiles/${t}_summary.json'))
 print('$t', {k: (round(v['avg_ms'] * 1e3, 2), round(v.get('hbm_traffic_bytes_per_launch', 0) / 1e6, 1)) for k, v in d['kernels'].items()}, 'k_step hbm frac', round(d.get('k_step_hbm_frac_algorithmic', 0), 3), 'traffic/alg', d.get('traffic_over_algorithmic'))
 PY
 done
-for f in launch_overhead coalesce_sweep measure_api step_sweep eval_hands_bench; do [ -f gpurun_out/${R}_$f.txt ] && cp gpurun_out/${R}_$f.txt profiles/${R}_$f.txt; done
+for f in launch_overhead coalesce_sweep measure_api step_sweep eval_hands_bench step_obs_ab; do [ -f gpurun_out/${R}_$f.txt ] && cp gpurun_out/${R}_$f.txt profiles/${R}_$f.txt; done
 [ -s gpurun_out/${R}_bench_driver_line.json ] && tail -1 gpurun_out/${R}_bench_driver_line.json > profiles/${R}_bench_driver_line.json && wc -c profiles/${R}_bench_driver_line.json
-for f in driver driver_nocoalesce 65536x6 65536x9_allin 4096x2 1048576x6 65536x6_unfused 65536x10 65536x12 65536x13 65536x15 65536x16 step_65536x6 step_65536x6_replay step_65536x6_unfused_reset step_1048576x6_replay step_async_65536x6 env env_sync_batches4 env_async8_batches1 env_async8_batches4 env_async8_inner3_524288; do
+for f in driver driver_nocoalesce 65536x6 65536x9_allin 4096x2 1048576x6 65536x6_unfused 65536x10 65536x12 65536x13 65536x15 65536x16 step_65536x6 step_65536x6_replay step_65536x6_unfused_reset step_1048576x6_replay step_async_65536x6 step_obs2_65536x6 step_obsfused_65536x6 env env_sync_batches4 env_async8_batches1 env_async8_batches4 env_async8_inner3_524288; do
   [ -s gpurun_out/${R}_bench_$f.json ] || continue
   tail -1 gpurun_out/${R}_bench_$f.json > profiles/${R}_bench_$f.json
   python - <<PY
