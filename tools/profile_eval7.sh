@@ -6,6 +6,7 @@ TAG=$1; LOG2=${2:-28}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
+(cd $ROOT && python3 -c "from pokerl_amd import _lib; print(_lib.source_hash())") > $OUT/lib.txt 2>/dev/null   # the kernel sources this is measured on (pk_build_info)
 cd /tmp && export TMPDIR=/tmp
 python3 $ROOT/tools/eval7_bench.py $LOG2 20 > $OUT/unprofiled.json 2>/dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/tools/eval7_bench.py $LOG2 20 > $OUT/trace.log 2>&1 || echo "trace failed"

@@ -8,6 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 for CASE in 0 1; do
   OUT=$ROOT/gpurun_out/prof_${TAG}_case$CASE
   rm -rf $OUT; mkdir -p $OUT
+(cd $ROOT && python3 -c "from pokerl_amd import _lib; print(_lib.source_hash())") > $OUT/lib.txt 2>/dev/null   # the kernel sources this is measured on (pk_build_info)
   export PK_EHB_CASE=$CASE
   python3 $ROOT/tools/eval_hands_bench.py $LOG2 > $OUT/unprofiled.txt 2>/dev/null
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/tools/eval_hands_bench.py $LOG2 > $OUT/trace.log 2>&1 || echo "trace failed"

@@ -7,6 +7,7 @@ TAG=$1; K=$2; shift; shift
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
+(cd $ROOT && python3 -c "from pokerl_amd import _lib; print(_lib.source_hash())") > $OUT/lib.txt 2>/dev/null   # the kernel sources this is measured on (pk_build_info)
 cd /tmp && export TMPDIR=/tmp
 ARGS="--full-line --no-cpu-baseline --no-evaluator --no-extra --samples 3 --min-steps 65536 $*"
 echo "{\"tables\": ${PK_TABLES:-65536}, \"players\": ${PK_PLAYERS:-6}, \"policy\": \"${PK_POLICY:-random}\", \"steps_per_launch\": $K, \"fused\": true, \"command\": \"python3 bench.py $ARGS\"}" > $OUT/workload.json

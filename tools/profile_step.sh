@@ -8,6 +8,7 @@ TAG=$1; shift
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
+(cd $ROOT && python3 -c "from pokerl_amd import _lib; print(_lib.source_hash())") > $OUT/lib.txt 2>/dev/null   # the kernel sources this is measured on (pk_build_info)
 cd /tmp && export TMPDIR=/tmp
 ARGS="--mode step $*"
 echo "{\"command\": \"python3 bench.py $ARGS\"}" > $OUT/workload.json

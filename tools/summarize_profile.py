@@ -112,6 +112,11 @@ try:    # which kernel sources this was measured on (pk_build_info of the librar
     _sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
     from pokerl_amd import _lib as _pk_lib
     summary["source_hash"] = _pk_lib.source_hash()
+    for _d in (locals().get("src"), locals().get("d")):      # the hash the profiling script recorded ON THE BOX, if it did (lib.txt), wins
+        _p = _os.path.join(_d, "lib.txt") if isinstance(_d, str) else None
+        if _p and _os.path.exists(_p) and open(_p).read().strip():
+            summary["source_hash"] = open(_p).read().strip()
+            break
 except Exception as _e:   # noqa: BLE001
     summary["source_hash"] = None
 
