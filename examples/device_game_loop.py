@@ -22,12 +22,14 @@ N = 6
 game = pokerl_amd.VecGame(T, num_players=N)
 game.reset()
 actions, flags, terr = DeviceBuffer(T * 4), DeviceBuffer(T), DeviceBuffer(T)
-obs = DeviceBuffer(T * (17 + 3 * N) * 8)                       # dense StateView rows of the player to act, if the policy wants them
-
+obs = DeviceBuffer(T * (17 + 3 * N) * 8)                       # dense StateView rows of the player to act: what the policy reads
+L.check(L.lib().pk_get_obs_d(game._h, -1, obs.ptr), game._h)   # the rows of the freshly reset tables (one launch, once) ...
+game.set_step_obs(obs, None)                                   # ... from now on every step_d / step_async_d writes `game.active_state` itself
+                                                               #     (pk_set_step_obs: from the step kernel's registers, no launch of its own)
 games = 0
 t0 = time.perf_counter()
 for s in range(steps):
-    # L.lib().pk_get_obs_d(game._h, -1, obs.ptr)               # <- what a network would read (asynchronous on the handle's stream)
+    # `obs` holds the row of every table's player to act here (written by the previous step_d): what a network would read
     game.pick_actions_d(actions, pokerl_amd.Policy.RANDOM)     # <- your policy kernel goes here: int32[T], valid for each active player
     game.step_d(actions, flags, terr, auto_reset=True)         # Game.step on every table; a finished game is Game.reset() on the spot
     if s % 500 == 499:                                         # looking at the flags is a host round trip: do it rarely
@@ -64,6 +66,7 @@ assert (ready.download(np.uint8, T) != 0).all() and not (terr.download(np.uint8,
 dt = time.perf_counter() - t0
 print("bounded launches: %.1f us per step of the whole batch (%.2f G steps/s if every table were ready; %.4f of them were in the sampled launches)"
       % (dt / steps * 1e6, T * steps / dt / 1e9, delivered / float(T * max(1, steps // 500))))
+game.set_step_obs(None, None)                                  # the handle keeps raw pointers: unset them before freeing the buffer
 for b in (actions, flags, terr, obs, ready):
     b.free()
 game.close()
