@@ -24,6 +24,7 @@ struct pk_handle {
     int env_tpb = 64;  // ... of the PokerGameEnv kernels (hot_env): see pk_create; knob PK_ENV_TPB
     Hot hot_env{};
     bool occ3 = false;  // k_rollout_occ3 (registers capped for 3 waves per SIMD) vs k_rollout: see pk_create; knob PK_OCC3
+    int tab_min_steps = 16;  // k_rollout_tab for launches of at least this many steps (0: never; 20-step launches: no gain, no loss); knob PK_ROLLOUT_TAB
     // lanes parked at end_hand before a wave runs end_block (the kernels look every 4 betting passes); knob PK_PARK /
     // pk_set_tuning.  0 = the measured optimum of each kernel: 28 for k_rollout with random agents (20.9 vs 20.6 G at
     // 20-step launches, the same at long ones), 32 for the all-in agents (44.3 vs 43.3 G) and for the env kernels.
@@ -126,9 +127,12 @@ struct DeviceGuard {
 static_assert(PK_MIN_PLAYERS == 2 && PK_MAX_PLAYERS == 16, "the lists above name the seat counts");
 #define PK_DECLARE_ALL(N) PK_TABLE_KERNELS(PK_DECLARE_KERNEL, N)
 #define PK_DECLARE_ALL_LE10(N) PK_TABLE_KERNELS_LE10(PK_DECLARE_KERNEL, N)
+#define PK_DECLARE_ALL_LE6(N) PK_TABLE_KERNELS_LE6(PK_DECLARE_KERNEL, N)
+#define PK_FOR_SEATS_LE6(X) X(2) X(3) X(4) X(5) X(6)
 PK_FOR_SEATS_LE10(PK_DECLARE_ALL)
 PK_FOR_SEATS_GT10(PK_DECLARE_ALL)
 PK_FOR_SEATS_LE10(PK_DECLARE_ALL_LE10)
+PK_FOR_SEATS_LE6(PK_DECLARE_ALL_LE6)
 static inline bool seat_count_built(int n) {
 #define PK_SEAT_CASE(N) if (n == N) return PK_SEAT_ENABLED(N);
     PK_FOR_SEATS_LE10(PK_SEAT_CASE)
@@ -176,6 +180,19 @@ static inline bool seat_count_built(int n) {
         } \
     } while (0)
 
+// ... and up to six (k_rollout_tab)
+#define DISPATCH_N_LE6(h, KERNEL, grid, ...) \
+    do { \
+        dim3 g_((grid)), b_((h)->block); \
+        switch ((h)->N) { \
+            case 2: if constexpr (PK_SEAT_ENABLED(2)) hipLaunchKernelGGL(KERNEL<2>, g_, b_, 0, (h)->stream, __VA_ARGS__); break; \
+            case 3: if constexpr (PK_SEAT_ENABLED(3)) hipLaunchKernelGGL(KERNEL<3>, g_, b_, 0, (h)->stream, __VA_ARGS__); break; \
+            case 4: if constexpr (PK_SEAT_ENABLED(4)) hipLaunchKernelGGL(KERNEL<4>, g_, b_, 0, (h)->stream, __VA_ARGS__); break; \
+            case 5: if constexpr (PK_SEAT_ENABLED(5)) hipLaunchKernelGGL(KERNEL<5>, g_, b_, 0, (h)->stream, __VA_ARGS__); break; \
+            case 6: if constexpr (PK_SEAT_ENABLED(6)) hipLaunchKernelGGL(KERNEL<6>, g_, b_, 0, (h)->stream, __VA_ARGS__); break; \
+        } \
+    } while (0)
+
 #define PK_STR_(x) #x
 #define PK_STR(x) PK_STR_(x)
 static inline bool bad_policy(int policy) { return policy < 0 || policy >= PK_NUM_POLICIES; }
@@ -203,7 +220,11 @@ static int launch_rollout(pk_handle *h, int k_steps, int policy, int auto_reset,
     if (policy == PK_POLICY_RANDOM && k_steps == 1 && endk <= 1 && !h->occ3) DISPATCH_N(h, k_rollout_single, table_grid(h), ROLLOUT_ARGS);
     else if (policy == PK_POLICY_CALL) DISPATCH_N(h, k_rollout_call, table_grid(h), ROLLOUT_ARGS);
     else if (!h->occ3) {
-        if (policy == PK_POLICY_RANDOM) DISPATCH_N(h, k_rollout, table_grid(h), ROLLOUT_ARGS);
+        // k_rollout_tab: the showdown hands ranked by the table-driven evaluator -- where its 40 KB of LDS per wave cost no occupancy (at most one
+        // wave per SIMD: 1 024 workgroups) and the launch is long enough to pay for staging the table (~1.5 us); knob PK_ROLLOUT_TAB (min steps, 0 = off)
+        if (policy == PK_POLICY_RANDOM && h->N <= 6 && h->S.evtab && h->tab_min_steps > 0 && k_steps >= h->tab_min_steps && table_grid(h) <= 1024)
+            DISPATCH_N_LE6(h, k_rollout_tab, table_grid(h), ROLLOUT_ARGS);
+        else if (policy == PK_POLICY_RANDOM) DISPATCH_N(h, k_rollout, table_grid(h), ROLLOUT_ARGS);
         else DISPATCH_N(h, k_rollout_allin, table_grid(h), ROLLOUT_ARGS);
     } else {
         if (policy == PK_POLICY_RANDOM) DISPATCH_N_LE10(h, k_rollout_occ3, table_grid(h), ROLLOUT_ARGS);
@@ -393,6 +414,8 @@ static EnvKernArgs env_args(const pk_handle *h, const int32_t *actions_d, int se
 // pk_set_env_obs_packed: pk_env_step_fused_d / _async_d / _multi_d write the compact row of every table they deliver
 static inline EnvKernArgs with_packed(const pk_handle *h, EnvKernArgs ka) { ka.A.obs_packed = h->env_obs_packed; return ka; }
 
+static const uint32_t *eval7_table(int device);   // the table-driven evaluator's rank-mask table, one per device (defined with the judger entry points)
+
 extern "C" {
 
 int pk_abi_version(void) { return PK_ABI_VERSION; }
@@ -461,6 +484,7 @@ int pk_create(pk_handle **out, int device, int num_tables, int num_players, cons
         h->env_tpb = h->tpb;
         if (const char *pk = getenv("PK_ENV_TPB")) { int v = atoi(pk); if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) h->env_tpb = v; }
     }
+    if (const char *pk = getenv("PK_ROLLOUT_TAB")) { int v = atoi(pk); if (v >= 0) h->tab_min_steps = v; }
     if (const char *pk = getenv("PK_PARK")) { int v = atoi(pk); if (v >= 1 && v <= 64) h->park = v; }
     if (const char *pk = getenv("PK_ENDK")) { int v = atoi(pk); if (v >= 1 && v <= 64) h->endk = v; }
     if (const char *pk = getenv("PK_COALESCE")) { int v = atoi(pk); if (v >= 0 && v <= (1 << 20)) h->coalesce = v; }
@@ -525,6 +549,7 @@ int pk_create(pk_handle **out, int device, int num_tables, int num_players, cons
     S.big_blind = big_blind; S.small_blind = small_blind;
     S.key0 = (uint32_t)seed; S.key1 = (uint32_t)(seed >> 32);
     S.table_id_base = table_id_base; S.T = num_tables;
+    S.evtab = num_players <= 6 ? eval7_table(device) : nullptr;   // k_rollout_tab stages it in LDS (NULL -- out of memory -- : k_rollout is used)
 
     // Game.__init__ (game.py:242-264): every seat ACTIVE, dealer cursor = config dealer, credits 0, ranks NONE.
     {

@@ -21,6 +21,8 @@ enum : int { PS_FOLDED = 0, PS_ACTIVE = 1, PS_CALLED = 2, PS_ALL_IN = 3, PS_BROK
 constexpr uint32_t STREAM_DECK = 0x4445434Bu, STREAM_ACTION = 0x41435432u;  // 'DECK', 'ACT2' (RNG spec: DESIGN.md section 3)
 constexpr uint32_t NONE_V = (uint32_t)HR_NONE << 20;  // ranking value (rank<<20 | kickers) of judger's (NONE, [])
 
+constexpr int EVAL7_TAB_WORDS = 8192;   // entries of the table-driven evaluator's rank-mask table (eval7_tab_entry): 32 KB
+
 // ---------------------------------------------------------------------------------------------- HBM layout
 // Structure-of-arrays, seat-major: element (seat p, table t) of a per-seat array lives at [p*T + t], so the 64 lanes
 // of a wave (64 consecutive tables) touch 64 consecutive 8-byte (or 4-byte) words per load: fully coalesced.
@@ -44,6 +46,7 @@ struct State {
     unsigned long long *counters;                // [waves][PK_NUM_COUNTERS]: one slot per wavefront, no atomics (4 096
                                                  // contended atomicAdds per launch cost ~46 us); summed by k_sum_counters
     unsigned long long *prof;                    // [PF_SLOTS], diagnostic build only
+    const uint32_t *evtab;                       // [EVAL7_TAB_WORDS] the table of eval7_tab (per device; k_rollout_tab stages it in LDS), or NULL
     double start_credits[PK_MAX_PLAYERS];
     double big_blind, small_blind;
     uint32_t key0, key1, table_id_base;
@@ -424,7 +427,6 @@ __device__ inline uint32_t eval7_tab_entry(uint32_t m) {
     const uint32_t len = (uint32_t)__popc(run), top = run ? (uint32_t)(31 - __clz((int)run)) : 0u;
     return k5 | (st << 20) | (len << 24) | (top << 28);
 }
-constexpr int EVAL7_TAB_WORDS = 8192;
 
 // lo = card bytes 0..3, hi = card bytes 4..6 (byte 7 ignored) of 7 DISTINCT cards; T = the table above (LDS).
 // Candidates are encoded stronger = larger -- c' = 10 - HandRanking in bits 24..27, then (shift of the tail lookup)/4
@@ -637,6 +639,7 @@ struct Prof {
 
 template <int N>
 struct Lds {  // per workgroup (= one wavefront); ~10 KB at N = 10
+    static constexpr bool TAB = false;   // (LdsTab: the showdown hands are ranked by the table-driven evaluator)
     uint32_t item[64 * N + 64][2];  // [0] = community cards 0..3 (bytes); [1] = card4 | hole0<<6 | hole1<<12 | dest<<18
                                // (the last 64 entries: one scratch slot per lane for the writes of seats not in the showdown)
     uint32_t res[64 * N];      // dest = lane*N + seat -> HandRanking<<20 | kickers
@@ -649,6 +652,23 @@ struct Lds {  // per workgroup (= one wavefront); ~10 KB at N = 10
     uint32_t lone[(5 + 2 * N + 3) / 4];              // the deck words of a wave's ONE arriving table (end_block<false>), read by byte
     uint32_t stock[PK_STOCK][(5 + 2 * N + 3) / 4];   // decks dealt ahead for ONE table of the wave (end_block<false>: a lone dealing table's step may roll on)
 };
+
+// The same for k_rollout_tab (round 6): the workgroup also holds the 32 KB rank-mask table of eval7_tab, and the showdown hands are ranked by
+// that evaluator (~110 instructions + 6 LDS lookups against eval7_distinct's ~230).  A CU's 160 KB of LDS hold FOUR such workgroups -- one wave
+// per SIMD, what 65 536 tables need -- only if each stays within 40 960 bytes (measured: 40 864 bytes run at full rate, 42 912 at half,
+// profiles/r06_lds_pad.txt), i.e. 8 192 bytes beside the table: up to six seats, with the rankings returned THROUGH the queue slots (no `res`),
+// ONE dummy slot for the writes of seats not in the showdown, and without the single-table arrays (the kernel runs end_block<true>).
+template <int N>
+struct LdsTab {
+    static constexpr bool TAB = true;
+    uint32_t item[64 * N + 1][2];      // [0] = community cards 0..3 (bytes); [1] = card4 | hole0<<6 | hole1<<12; [0] is overwritten by the hand's ranking
+    uint32_t act[8][64];
+    uint32_t show[N][64];
+    Fresh fresh;
+    alignas(16) uint8_t nth[128][8];
+    alignas(16) uint32_t evtab[EVAL7_TAB_WORDS];
+};
+static_assert(sizeof(LdsTab<6>) <= 40960, "four one-wave workgroups of k_rollout_tab<6> must fit a CU's 160 KB of LDS");
 
 struct ActionRng {  // one Philox block serves EIGHT consecutive steps of a table: 16-bit draws (RNG spec)
     uint64_t idx = ~0ull;
@@ -785,6 +805,17 @@ __device__ __forceinline__ int pick_action(const Hot &S, ActionRng &rng, uint32_
 // policy nibble of seat p in a per-seat policy word (PokerGameEnv's agents list, envs/game_env.py:13-18)
 __device__ __forceinline__ int seat_policy(uint64_t seatpol, int p) { return (int)((seatpol >> (4 * p)) & 15); }
 
+// The showdown queue's synchronisation points.  Every table kernel's workgroup is ONE wavefront (PK_TABLE_BLOCK = 64), and a wave's LDS instructions
+// execute in issue order: a write followed by a read of the same location -- also by another lane of that wave -- needs program order, not a barrier.
+// Rounds 1-5 wrote __syncthreads() here: the compiler drops its s_barrier for a one-wave workgroup but keeps its fences -- a full s_waitcnt (every
+// LDS and global access drained) and no scheduling across it.  Round 6: a compiler-only barrier (no memory operation moves across it, nothing is
+// emitted; the reads' own s_waitcnt is placed at their first use): k_rollout_tab<6> 30.84 -> 31.13 G on one box (profiles/r06_tab_variants.txt).
+// -DPK_HEAVY_SYNC brings the old form back.  NOT valid for workgroups of several waves (there are none among the table kernels: static_assert below).
+#if defined(PK_HOST_SIM) || defined(PK_HEAVY_SYNC)
+#define PK_QSYNC() __syncthreads()
+#else
+#define PK_QSYNC() __builtin_amdgcn_wave_barrier()
+#endif
 template <int N>
 struct Table {
     static constexpr int K = 5 + 2 * N;      // cards ever read (game.py:278,388-395)
@@ -1023,7 +1054,8 @@ struct Table {
     }
 
     // Rankings of the last showdown (game.py:488-489) -> State::show; every kernel that runs end_block calls this last.
-    __device__ __forceinline__ void store_show(uint32_t *show, int T, int t, const Lds<N> &lds) const {
+    template <typename LDS>
+    __device__ __forceinline__ void store_show(uint32_t *show, int T, int t, const LDS &lds) const {
         if (showed) {
             const int lane = threadIdx.x & (PK_WAVE - 1);
             const auto g_show = as_global(show);
@@ -1031,7 +1063,8 @@ struct Table {
         }
     }
     // Workgroup copy of the fresh-table constants; call once, from wave-uniform control flow, before the first end_block.
-    __device__ __forceinline__ static void stage_fresh(Lds<N> &lds, const Fresh *src) {
+    template <typename LDS>
+    __device__ __forceinline__ static void stage_fresh(LDS &lds, const Fresh *src) {
         const int lane = threadIdx.x & (PK_WAVE - 1);
         constexpr int words = (int)(sizeof(Fresh) / 4);
         const auto s32 = as_global(reinterpret_cast<const uint32_t *>(src));
@@ -1155,8 +1188,10 @@ struct Table {
     // table's decks four at a time.  For the kernels whose launches end in a tail of single tables: k_step / k_rollout_single (+7 %: a
     // step that rolls hand after hand), k_env_step / k_env_reset (+1 %); NOT the bounded asynchronous env launches (-3 %: their
     // end_blocks serve one or two tables that rarely deal twice within a launch) -- profiles/r05_ab_lone.txt.
-    template <bool ONE_PASS = true, bool LONE = !ONE_PASS>
-    __device__ __forceinline__ void end_block(const Hot &S, int t, uint32_t table_id, Lds<N> &lds, bool auto_reset) {
+    template <bool ONE_PASS = true, bool LONE = !ONE_PASS, typename LDS = Lds<N>>
+    __device__ __forceinline__ void end_block(const Hot &S, int t, uint32_t table_id, LDS &lds, bool auto_reset) {
+        constexpr bool TAB = LDS::TAB;      // (LdsTab: rank the showdown hands with the table-driven evaluator; the rankings come back through the queue slots)
+        static_assert(!TAB || (ONE_PASS && !LONE), "the table evaluator's LDS layout has no single-table arrays");
         static_assert(!(ONE_PASS && LONE), "the lone-table paths belong to the kernels that run the whole side-pot loop per call");
         const bool e = lstate == LS_END;
         const bool resumed = ONE_PASS && lstate == LS_POT;
@@ -1237,23 +1272,32 @@ struct Table {
         if (lone) {
         } else if (total) {  // wave-uniform
             PK_FOR(p, N)                                                           // hand = deck[:5] + hole cards (:394-395)
-                const uint32_t slot = ((showdown >> p) & 1) ? my_base[p] : (uint32_t)(64 * N + lane);   // no branch per seat
+                const uint32_t slot = ((showdown >> p) & 1) ? my_base[p] : (uint32_t)(64 * N + (TAB ? 0 : lane));   // no branch per seat (TAB: ONE dummy slot)
                 lds.item[slot][0] = cards[0];
-                lds.item[slot][1] = card(4) | (card(5 + 2 * p) << 6) | (card(6 + 2 * p) << 12) | ((uint32_t)(lane * N + p) << 18);
+                lds.item[slot][1] = card(4) | (card(5 + 2 * p) << 6) | (card(6 + 2 * p) << 12) | (TAB ? 0u : ((uint32_t)(lane * N + p) << 18));
              PK_END
-            __syncthreads();
+            PK_QSYNC();
             for (uint32_t base = 0; base < total; base += PK_WAVE) {
                 PK_PROF(prof.count(PF_N_EVALPASS);)
                 uint32_t i = base + lane;
                 if (i < total) {
                     uint32_t w0 = lds.item[i][0], w1 = lds.item[i][1];
-                    uint32_t h[7] = {w0 & 0xff, (w0 >> 8) & 0xff, (w0 >> 16) & 0xff, w0 >> 24, w1 & 0x3f, (w1 >> 6) & 0x3f, (w1 >> 12) & 0x3f};
-                    lds.res[w1 >> 18] = eval7_distinct(h);
+                    if constexpr (TAB) {
+                        // the hand's suit-lane bit set straight from the packed words (a 64-bit shift takes its amount modulo 64: no masks needed
+                        // beyond the ones C wants), then eval7_tab's lookups in the workgroup's copy of the table
+                        const uint64_t bits = (4ull << (w0 & 63)) | (4ull << ((w0 >> 8) & 63)) | (4ull << ((w0 >> 16) & 63)) | (4ull << ((w0 >> 24) & 63)) |
+                                              (4ull << (w1 & 63)) | (4ull << ((w1 >> 6) & 63)) | (4ull << ((w1 >> 12) & 63));
+                        lds.item[i][0] = eval7_tab_back(eval7_tab_front_bits(bits, lds.evtab), lds.evtab);
+                    } else {
+                        uint32_t h[7] = {w0 & 0xff, (w0 >> 8) & 0xff, (w0 >> 16) & 0xff, w0 >> 24, w1 & 0x3f, (w1 >> 6) & 0x3f, (w1 >> 12) & 0x3f};
+                        lds.res[w1 >> 18] = eval7_distinct(h);
+                    }
                 }
             }
-            __syncthreads();
-            if (sd) { PK_FOR(p, N) pot_hv[p] = ((showdown >> p) & 1) ? lds.res[lane * N + p] : NONE_V; PK_END }
-            __syncthreads();  // the queue is reused by the next end_block of this wave
+            PK_QSYNC();
+            if constexpr (TAB) { if (sd) { PK_FOR(p, N) pot_hv[p] = ((showdown >> p) & 1) ? lds.item[my_base[p]][0] : NONE_V; PK_END } }
+            else if (sd) { PK_FOR(p, N) pot_hv[p] = ((showdown >> p) & 1) ? lds.res[lane * N + p] : NONE_V; PK_END }
+            PK_QSYNC();  // the queue is reused by the next end_block of this wave
             evals += __popc(showdown);
         } else if (sd) {
             PK_FOR(p, N) pot_hv[p] = NONE_V; PK_END                                // potential winners, none of them CALLED / ALL_IN
@@ -1379,7 +1423,8 @@ struct Table {
     }
 
     // Runs the machine until every lane of the wave is DONE.  Must be called from wave-uniform control flow.
-    __device__ __forceinline__ void run(const Hot &S, int t, uint32_t table_id, Lds<N> &lds, bool auto_reset) {
+    template <typename LDS>
+    __device__ __forceinline__ void run(const Hot &S, int t, uint32_t table_id, LDS &lds, bool auto_reset) {
         PK_PROF(prof.lap(PF_ACTION);)
         for (;;) {
             cursor();

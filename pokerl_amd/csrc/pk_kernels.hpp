@@ -12,6 +12,7 @@ using namespace pk;
 // SIMD (256 CUs x 4), so occupancy cannot hide anything and the register budget is the whole 512-entry file:
 // __launch_bounds__(64) lets the compiler keep a table's full state in VGPRs instead of spilling to scratch.
 #define PK_TABLE_BLOCK 64
+static_assert(PK_TABLE_BLOCK == PK_WAVE, "one wavefront per workgroup: what PK_QSYNC (pk_device.hpp) and every wave-level ballot of the step machine assume");
 
 template <typename ST>
 __device__ __forceinline__ void wave_add_counters(const ST &S, uint32_t steps, uint32_t hands, uint32_t evals, uint32_t games) {
@@ -170,13 +171,29 @@ struct StepKernArgs { const State *Sp; Hot H; const int32_t *actions; uint8_t *f
 #ifndef PK_STEP_ROLLING
 #define PK_STEP_ROLLING 16   // hands rolled inside one Game.step from which a bounded launch carries that step to its end (as PK_ENV_ROLLING)
 #endif
-template <int N, bool ONE_PASS, int POLICY, int PASSES = 0, bool BOUNDED = false>
+// TAB (k_rollout_tab, up to six seats): the showdown hands are ranked by the table-driven evaluator, whose 32 KB table the wave stages in its LDS.
+template <int N, bool ONE_PASS, int POLICY, int PASSES = 0, bool BOUNDED = false, bool TAB = false>
 __device__ __forceinline__ void rollout_body(const State *__restrict__ Sp, const Hot &H, int K, int auto_reset, int park, int slack, int clear_terr,
                                              const int32_t *actions = nullptr, const StepKernArgs *ext = nullptr) {
     // Array bases by pointer (loaded only where the table is loaded / stored), loop scalars by value: see pk::Hot.
     constexpr int policy = POLICY;
     const auto &S = *as_global(Sp);
-    __shared__ Lds<N> lds;
+    using LDS = std::conditional_t<TAB, LdsTab<N>, Lds<N>>;
+    __shared__ LDS lds;
+    if constexpr (TAB) {     // the workgroup's copy of the evaluator's table: 32 x (16-byte load + 16-byte LDS write) per lane, eight loads in flight
+        static_assert(ONE_PASS && POLICY != PK_POLICY_EXTERNAL, "k_rollout_tab is a fused-rollout kernel");
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const auto g_tab = (PK_GLOBAL const u32x4 *)as_global(S.evtab);
+        const int lane0 = threadIdx.x & (PK_WAVE - 1);
+#pragma unroll 1
+        for (int i = lane0; i < EVAL7_TAB_WORDS / 4; i += 8 * PK_WAVE) {
+            u32x4 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = g_tab[i + j * PK_WAVE];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) reinterpret_cast<u32x4 *>(lds.evtab)[i + j * PK_WAVE] = v[j];
+        }
+    }
     const int t = blockIdx.x * H.tpb + threadIdx.x;
     const bool live = (int)threadIdx.x < H.tpb && t < S.T;
     const uint32_t table_id = H.table_id_base + (uint32_t)t;
@@ -336,6 +353,12 @@ __device__ __forceinline__ void rollout_body(const State *__restrict__ Sp, const
 template <int N>
 __global__ void __launch_bounds__(PK_TABLE_BLOCK, PK_WAVES_PER_SIMD_N(N)) PK_ROLLOUT_ATTR k_rollout(const State *__restrict__ Sp, Hot H, int K, int auto_reset, int park, int slack, int clear_terr) {
     rollout_body<N, true, PK_POLICY_RANDOM>(Sp, H, K, auto_reset, park, slack, clear_terr);
+}
+// ... with the showdown hands ranked by the table-driven evaluator (rollout_body<..., TAB>): up to six seats, batches of at most one wave per SIMD
+// (40 752 bytes of LDS per wave: a second wave per SIMD would not fit the CU), launches long enough to pay for staging the table (pk_api.hip).
+template <int N>
+__global__ void __launch_bounds__(PK_TABLE_BLOCK, PK_WAVES_PER_SIMD_N(N)) PK_ROLLOUT_ATTR k_rollout_tab(const State *__restrict__ Sp, Hot H, int K, int auto_reset, int park, int slack, int clear_terr) {
+    rollout_body<N, true, PK_POLICY_RANDOM, 0, false, true>(Sp, H, K, auto_reset, park, slack, clear_terr);
 }
 template <int N>
 __global__ void __launch_bounds__(PK_TABLE_BLOCK, PK_WAVES_PER_SIMD_N(N)) PK_ROLLOUT_ATTR k_rollout_allin(const State *__restrict__ Sp, Hot H, int K, int auto_reset, int park, int slack, int clear_terr) {
@@ -1125,5 +1148,8 @@ __global__ void k_eval7_prefix(int a, int b, int fast, uint32_t count, uint32_t 
 #define PK_TABLE_KERNELS_LE10(X, N)                                          \
     X(N, k_rollout_occ3, PK_ROLLOUT_SIG)                                     \
     X(N, k_rollout_occ3_allin, PK_ROLLOUT_SIG)
+// ... and up to six (the table evaluator's LDS layout: LdsTab)
+#define PK_TABLE_KERNELS_LE6(X, N)                                           \
+    X(N, k_rollout_tab, PK_ROLLOUT_SIG)
 #define PK_INSTANTIATE_KERNEL(N, name, sig) template __global__ void name<N> sig;
 #define PK_DECLARE_KERNEL(N, name, sig) extern template __global__ void name<N> sig;

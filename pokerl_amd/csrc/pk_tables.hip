@@ -13,3 +13,6 @@ PK_TABLE_KERNELS(PK_INSTANTIATE_KERNEL, PK_SEATS)
 #if PK_SEATS <= 10
 PK_TABLE_KERNELS_LE10(PK_INSTANTIATE_KERNEL, PK_SEATS)
 #endif
+#if PK_SEATS <= 6
+PK_TABLE_KERNELS_LE6(PK_INSTANTIATE_KERNEL, PK_SEATS)
+#endif

@@ -414,6 +414,27 @@ def test_both_rollout_kernels_vs_oracle(HB, O, monkeypatch, occ3):
         h.g.close()
 
 
+@pytest.mark.parametrize("tab", ["0", "1"])
+def test_rollout_with_the_table_evaluator_vs_oracle(HB, O, monkeypatch, tab):
+    """k_rollout_tab (round 6: up to six seats, batches of at most one wave per SIMD, launches of >= 16 steps -- the showdown hands ranked by the
+    table-driven evaluator out of the wave's own LDS copy of the table, rankings returned through the queue slots) against k_rollout
+    (PK_ROLLOUT_TAB=0: never) and the oracle: every state byte incl. the rankings of the last showdown, full-width ragged waves, per-seat stacks,
+    deferred / split launches, launches below and above the step threshold, all seat counts the kernel exists for; the all-in agents (every hand a
+    showdown) take k_rollout_allin either way."""
+    monkeypatch.setenv("PK_ROLLOUT_TAB", tab)
+    for N, T, policy, K, stacks in [(6, 65536, 0, 96, 100), (6, 65536 - 37, 0, 64, [50, 100, 20, 100, 80, 100]), (2, 65536, 0, 80, 100), (3, 40000, 0, 90, 100),
+                                    (4, 5000, 0, 150, [3, 100, 5, 40]), (5, 1500, 0, 300, 100), (6, 8192, 1, 100, 100), (6, 70000, 0, 40, 100)]:
+        o = O.OracleGame(T, N, stacks, seed=4400 + N)
+        h = HB(T, N, stacks, seed=4400 + N)
+        o.reset(); h.reset()
+        for k in (K // 3, 7, K - K // 3 - 7):                        # (a 7-step launch in between: below the kernel's threshold)
+            h.g.rollout(k, policy, True, True, counters=False)
+        co, _ = o.rollout(K, policy, True)
+        assert co.tolist() == h.rollout(0, policy, True).tolist(), (N, T, tab)
+        assert_same(o.snapshot(), h.snapshot(), "N=%d T=%d PK_ROLLOUT_TAB=%s" % (N, T, tab))
+        h.g.close()
+
+
 def test_hand_cap_rule(HB, O):
     """start_credits = 0: every seat is re-dealt all-in with no chips for ever -- the reference's Game.step would never
     return (docs/history.md section 2).  step() reports PK_TERR_HAND_CAP; a rollout with auto_reset treats it as a finished game."""
@@ -948,7 +969,7 @@ def test_bench_json_contract():
     assert c["n_gpus"] == 1 and c["steps"] == 256 and c["warmup"] == 64 and c["higher_is_better"] is True
     assert c["scaling"] == "weak" and c["vs_baseline"] is None and c["dtype"] == "f64" and c["data"] == "synthetic"
     assert "workload" in c["config"] and "model" not in c["config"] and "BASELINE configs[2]" in c["config"]["workload"]
-    assert c["config"]["kernel"].startswith("k_rollout<6>") and "dist" not in c
+    assert c["config"]["kernel"].startswith("k_rollout_tab<6>") and "dist" not in c      # (256-step launches: the table-evaluator variant)
     assert abs(c["value"] - 65536 * 256 / (c["ms_per_step"] * 256 / 1e3)) / c["value"] < 1e-3     # (five significant digits in the line)
     crf = c["roofline"]
     assert crf["bound"] == "valu-issue" and crf["unit"] == "wave-instr/s" and 0.0 < crf["frac"] <= 0.5 and crf["traffic"] > 0

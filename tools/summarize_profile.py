@@ -41,7 +41,8 @@ durs = sorted((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in row
 n_l, n_s, line = bench_line(os.path.join(src, "trace.log"))
 waves = int(rows[0]["Grid_Size_X"]) // int(rows[0]["Workgroup_Size_X"])
 summary = {
-    "tag": tag, "kernel": rows[0]["Kernel_Name"], "launches_total": len(durs),
+    "tag": tag, "kernel": max(set(r["Kernel_Name"] for r in rows), key=lambda k: sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows if r["Kernel_Name"] == k)),
+    "kernels_matched": sorted(set(r["Kernel_Name"] for r in rows)), "launches_total": len(durs),
     "avg_launch_ms": sum(durs) / len(durs) / 1e6, "min_launch_ms": durs[0] / 1e6, "max_launch_ms": durs[-1] / 1e6,
     "median_launch_ms": durs[len(durs) // 2] / 1e6,
     "vgpr": int(rows[0]["VGPR_Count"]), "agpr": int(rows[0]["Accum_VGPR_Count"]), "sgpr": int(rows[0]["SGPR_Count"]),
