@@ -612,8 +612,11 @@ def kernel_short(w, players):
     occ3 = (players == 6 and w["n_local"] > 131072) or (players == 7 and w["n_local"] >= 262144) or (players == 8 and w["n_local"] >= 524288)
     name = {"random": "k_rollout_occ3" if occ3 else "k_rollout", "allin": "k_rollout_occ3_allin" if occ3 else "k_rollout_allin"}[w["policy"]]
     tab_min = int(os.environ.get("PK_ROLLOUT_TAB", "16"))     # pk_api.hip launch_rollout: the table-evaluator variant, where it applies
-    if w["policy"] == "random" and players <= 6 and w["n_local"] <= 65536 and tab_min > 0 and w["stats"]["min"] >= tab_min:
-        name = "k_rollout_tab"
+    if w["n_local"] <= 65536 and tab_min > 0 and w["stats"]["min"] >= tab_min and not occ3:
+        if w["policy"] == "random" and players <= 6:
+            name = "k_rollout_tab"
+        elif w["policy"] == "allin" and players <= 10:
+            name = "k_rollout_allin_tab"
     return "%s<%d> fused, %.0f steps/launch" % (name, players, w["kern_steps"])
 
 

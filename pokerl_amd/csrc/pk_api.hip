@@ -222,8 +222,9 @@ static int launch_rollout(pk_handle *h, int k_steps, int policy, int auto_reset,
     else if (!h->occ3) {
         // k_rollout_tab: the showdown hands ranked by the table-driven evaluator -- where its 40 KB of LDS per wave cost no occupancy (at most one
         // wave per SIMD: 1 024 workgroups) and the launch is long enough to pay for staging the table (~1.5 us); knob PK_ROLLOUT_TAB (min steps, 0 = off)
-        if (policy == PK_POLICY_RANDOM && h->N <= 6 && h->S.evtab && h->tab_min_steps > 0 && k_steps >= h->tab_min_steps && table_grid(h) <= 1024)
-            DISPATCH_N_LE6(h, k_rollout_tab, table_grid(h), ROLLOUT_ARGS);
+        const bool tab_ok = h->S.evtab && h->tab_min_steps > 0 && k_steps >= h->tab_min_steps && table_grid(h) <= 1024;
+        if (policy == PK_POLICY_RANDOM && h->N <= 6 && tab_ok) DISPATCH_N_LE6(h, k_rollout_tab, table_grid(h), ROLLOUT_ARGS);
+        else if (policy == PK_POLICY_ALLIN && h->N <= 10 && tab_ok) DISPATCH_N_LE10(h, k_rollout_allin_tab, table_grid(h), ROLLOUT_ARGS);   // (no action ring in LDS: up to ten seats)
         else if (policy == PK_POLICY_RANDOM) DISPATCH_N(h, k_rollout, table_grid(h), ROLLOUT_ARGS);
         else DISPATCH_N(h, k_rollout_allin, table_grid(h), ROLLOUT_ARGS);
     } else {
@@ -549,7 +550,7 @@ int pk_create(pk_handle **out, int device, int num_tables, int num_players, cons
     S.big_blind = big_blind; S.small_blind = small_blind;
     S.key0 = (uint32_t)seed; S.key1 = (uint32_t)(seed >> 32);
     S.table_id_base = table_id_base; S.T = num_tables;
-    S.evtab = num_players <= 6 ? eval7_table(device) : nullptr;   // k_rollout_tab stages it in LDS (NULL -- out of memory -- : k_rollout is used)
+    S.evtab = num_players <= 10 ? eval7_table(device) : nullptr;   // k_rollout_tab / k_rollout_allin_tab stage it in LDS (NULL -- out of memory -- : k_rollout(_allin) is used)
 
     // Game.__init__ (game.py:242-264): every seat ACTIVE, dealer cursor = config dealer, credits 0, ranks NONE.
     {

@@ -658,8 +658,12 @@ struct Lds {  // per workgroup (= one wavefront); ~10 KB at N = 10
 // per SIMD, what 65 536 tables need -- only if each stays within 40 960 bytes (measured: 40 864 bytes run at full rate, 42 912 at half,
 // profiles/r06_lds_pad.txt), i.e. 8 192 bytes beside the table: up to six seats, with the rankings returned THROUGH the queue slots (no `res`),
 // ONE dummy slot for the writes of seats not in the showdown, and without the single-table arrays (the kernel runs end_block<true>).
+// RING: the in-kernel agent draws (random agents: the action ring and the k-th-valid-action table); without them -- the all-in agents, whose
+// every hand is a showdown: BASELINE configs[4] -- the budget holds up to ten seats.
+template <int N, bool RING>
+struct LdsTab;
 template <int N>
-struct LdsTab {
+struct LdsTab<N, true> {
     static constexpr bool TAB = true;
     uint32_t item[64 * N + 1][2];      // [0] = community cards 0..3 (bytes); [1] = card4 | hole0<<6 | hole1<<12; [0] is overwritten by the hand's ranking
     uint32_t act[8][64];
@@ -668,7 +672,17 @@ struct LdsTab {
     alignas(16) uint8_t nth[128][8];
     alignas(16) uint32_t evtab[EVAL7_TAB_WORDS];
 };
-static_assert(sizeof(LdsTab<6>) <= 40960, "four one-wave workgroups of k_rollout_tab<6> must fit a CU's 160 KB of LDS");
+template <int N>
+struct LdsTab<N, false> {
+    static constexpr bool TAB = true;
+    uint32_t item[64 * N + 1][2];
+    uint32_t show[N][64];
+    Fresh fresh;
+    alignas(16) uint32_t evtab[EVAL7_TAB_WORDS];
+};
+#define PK_TAB_LDS_BUDGET 40960        // a quarter of a CU's 160 KB
+static_assert(sizeof(LdsTab<6, true>) <= PK_TAB_LDS_BUDGET && sizeof(LdsTab<10, false>) <= PK_TAB_LDS_BUDGET,
+              "four one-wave workgroups of k_rollout_tab<6> / k_rollout_allin_tab<10> must fit a CU's 160 KB of LDS");
 
 struct ActionRng {  // one Philox block serves EIGHT consecutive steps of a table: 16-bit draws (RNG spec)
     uint64_t idx = ~0ull;

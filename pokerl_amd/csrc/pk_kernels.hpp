@@ -178,7 +178,7 @@ __device__ __forceinline__ void rollout_body(const State *__restrict__ Sp, const
     // Array bases by pointer (loaded only where the table is loaded / stored), loop scalars by value: see pk::Hot.
     constexpr int policy = POLICY;
     const auto &S = *as_global(Sp);
-    using LDS = std::conditional_t<TAB, LdsTab<N>, Lds<N>>;
+    using LDS = std::conditional_t<TAB, LdsTab<N, POLICY == PK_POLICY_RANDOM>, Lds<N>>;
     __shared__ LDS lds;
     if constexpr (TAB) {     // the workgroup's copy of the evaluator's table: 32 x (16-byte load + 16-byte LDS write) per lane, eight loads in flight
         static_assert(ONE_PASS && POLICY != PK_POLICY_EXTERNAL, "k_rollout_tab is a fused-rollout kernel");
@@ -200,7 +200,7 @@ __device__ __forceinline__ void rollout_body(const State *__restrict__ Sp, const
     Table<N> tb;
     uint32_t owed = 0;
     Table<N>::stage_fresh(lds, H.fresh);
-    stage_nth(lds);
+    if constexpr (!TAB || POLICY == PK_POLICY_RANDOM) stage_nth(lds);      // (the table variant of the all-in agents has no such table: LdsTab<N, false>)
     constexpr bool EXTERNAL = POLICY == PK_POLICY_EXTERNAL;
     constexpr bool PAY = PASSES != 1;        // the single-step kernels (k_step, k_rollout_single) move the payoffs only where a hand ended
     if (live) { tb.template load<PAY>(S, t); tb.hands_this_step = (int)as_global(S.mid)[t]; owed = as_global(S.owed)[t] + (uint32_t)K; } else tb.blank();
@@ -257,18 +257,20 @@ __device__ __forceinline__ void rollout_body(const State *__restrict__ Sp, const
         // conditionally executed blocks), and parks a full s_waitcnt right behind the first LDS read of every betting
         // pass: the action ring's latency was exposed three passes out of four.
         if (policy == PK_POLICY_RANDOM) __builtin_amdgcn_s_waitcnt(0);   // (the all-in kernel has no LDS read in its passes)
-        if (policy == PK_POLICY_RANDOM) ring.ensure(lds, H, table_id, tb.step_serial, alive && owed > 0, NPASS);   // wave-uniform
+        if constexpr (policy == PK_POLICY_RANDOM) ring.ensure(lds, H, table_id, tb.step_serial, alive && owed > 0, NPASS);   // wave-uniform
 #pragma unroll
         for (int pass = 0; pass < NPASS; ++pass) {
             const bool go = alive && tb.lstate == LS_DONE && owed > 0;
             uint32_t word = 0;
-            if (policy == PK_POLICY_RANDOM) word = ActionRing::peek(lds, tb.step_serial);
+            if constexpr (policy == PK_POLICY_RANDOM) word = ActionRing::peek(lds, tb.step_serial);
             if (go) {
                 uint32_t mask = tb.valid_mask(high_bet);
-                tb.begin_step(H, EXTERNAL ? ext_action
-                               : policy == PK_POLICY_ALLIN ? (int)MV_ALL_IN
-                               : policy == PK_POLICY_CALL ? call_action(mask)
-                                                          : action_from_draw_lds(lds, ActionRing::half_of(word, tb.step_serial), mask), high_bet);
+                int act;
+                if constexpr (EXTERNAL) act = ext_action;
+                else if constexpr (policy == PK_POLICY_ALLIN) act = (int)MV_ALL_IN;
+                else if constexpr (policy == PK_POLICY_CALL) act = call_action(mask);
+                else act = action_from_draw_lds(lds, ActionRing::half_of(word, tb.step_serial), mask);
+                tb.begin_step(H, act, high_bet);
             }
             PK_PROF(tb.prof.lap(PF_ACTION);)
             tb.scan_first();      // every lane in LS_SCAN: the steps just begun and the ones end_block carried into a new hand
@@ -359,6 +361,10 @@ __global__ void __launch_bounds__(PK_TABLE_BLOCK, PK_WAVES_PER_SIMD_N(N)) PK_ROL
 template <int N>
 __global__ void __launch_bounds__(PK_TABLE_BLOCK, PK_WAVES_PER_SIMD_N(N)) PK_ROLLOUT_ATTR k_rollout_tab(const State *__restrict__ Sp, Hot H, int K, int auto_reset, int park, int slack, int clear_terr) {
     rollout_body<N, true, PK_POLICY_RANDOM, 0, false, true>(Sp, H, K, auto_reset, park, slack, clear_terr);
+}
+template <int N>     // ... the all-in agents (every hand a showdown: BASELINE configs[4]) with the table evaluator: no action ring in LDS, up to ten seats
+__global__ void __launch_bounds__(PK_TABLE_BLOCK, PK_WAVES_PER_SIMD_N(N)) PK_ROLLOUT_ATTR k_rollout_allin_tab(const State *__restrict__ Sp, Hot H, int K, int auto_reset, int park, int slack, int clear_terr) {
+    rollout_body<N, true, PK_POLICY_ALLIN, 0, false, true>(Sp, H, K, auto_reset, park, slack, clear_terr);
 }
 template <int N>
 __global__ void __launch_bounds__(PK_TABLE_BLOCK, PK_WAVES_PER_SIMD_N(N)) PK_ROLLOUT_ATTR k_rollout_allin(const State *__restrict__ Sp, Hot H, int K, int auto_reset, int park, int slack, int clear_terr) {
@@ -1147,7 +1153,8 @@ __global__ void k_eval7_prefix(int a, int b, int fast, uint32_t count, uint32_t 
 // ... and the ones that exist up to ten seats only (the 168-register variants: beyond ten seats they would spill)
 #define PK_TABLE_KERNELS_LE10(X, N)                                          \
     X(N, k_rollout_occ3, PK_ROLLOUT_SIG)                                     \
-    X(N, k_rollout_occ3_allin, PK_ROLLOUT_SIG)
+    X(N, k_rollout_occ3_allin, PK_ROLLOUT_SIG)                               \
+    X(N, k_rollout_allin_tab, PK_ROLLOUT_SIG)
 // ... and up to six (the table evaluator's LDS layout: LdsTab)
 #define PK_TABLE_KERNELS_LE6(X, N)                                           \
     X(N, k_rollout_tab, PK_ROLLOUT_SIG)

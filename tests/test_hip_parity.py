@@ -420,10 +420,11 @@ def test_rollout_with_the_table_evaluator_vs_oracle(HB, O, monkeypatch, tab):
     table-driven evaluator out of the wave's own LDS copy of the table, rankings returned through the queue slots) against k_rollout
     (PK_ROLLOUT_TAB=0: never) and the oracle: every state byte incl. the rankings of the last showdown, full-width ragged waves, per-seat stacks,
     deferred / split launches, launches below and above the step threshold, all seat counts the kernel exists for; the all-in agents (every hand a
-    showdown) take k_rollout_allin either way."""
+    showdown: BASELINE configs[4]) take k_rollout_allin_tab up to ten seats (no action ring in LDS, so the table fits beside a wider queue)."""
     monkeypatch.setenv("PK_ROLLOUT_TAB", tab)
     for N, T, policy, K, stacks in [(6, 65536, 0, 96, 100), (6, 65536 - 37, 0, 64, [50, 100, 20, 100, 80, 100]), (2, 65536, 0, 80, 100), (3, 40000, 0, 90, 100),
-                                    (4, 5000, 0, 150, [3, 100, 5, 40]), (5, 1500, 0, 300, 100), (6, 8192, 1, 100, 100), (6, 70000, 0, 40, 100)]:
+                                    (4, 5000, 0, 150, [3, 100, 5, 40]), (5, 1500, 0, 300, 100), (6, 8192, 1, 100, 100), (6, 70000, 0, 40, 100),
+                                    (9, 65536, 1, 40, 100), (10, 20000, 1, 60, 100), (7, 3000, 1, 80, [5, 100, 30, 100, 100, 2, 60]), (2, 65536, 1, 50, 100)]:
         o = O.OracleGame(T, N, stacks, seed=4400 + N)
         h = HB(T, N, stacks, seed=4400 + N)
         o.reset(); h.reset()

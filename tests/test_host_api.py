@@ -39,9 +39,11 @@ def test_no_table_kernel_uses_scratch():
     import kernel_meta
     ks = kernel_meta.kernels(_lib.LIB_PATH)
     table_kernels = [k for k in ks if re.match(r"k_(reset|make_fresh|pick|rollout|step|env_)", k)]
-    assert len(table_kernels) == 15 * 13 + 9 * 2 + 5, len(table_kernels)    # 13 kernels x seats 2..16 + the two occ3 variants x seats 2..10 + k_rollout_tab x seats 2..6
-    # k_rollout_tab's one-wave workgroups must fit a CU four at a time (160 KB of LDS: 40 960 bytes each), or 65 536 tables run at half rate
-    assert all(0 < ks["k_rollout_tab<%d>" % n]["lds"] <= 40960 for n in range(2, 7)), {n: ks["k_rollout_tab<%d>" % n]["lds"] for n in range(2, 7)}
+    # 13 kernels x seats 2..16 + the two occ3 variants and k_rollout_allin_tab x seats 2..10 + k_rollout_tab x seats 2..6
+    assert len(table_kernels) == 15 * 13 + 9 * 3 + 5, len(table_kernels)
+    # the table-evaluator variants' one-wave workgroups must fit a CU four at a time (160 KB of LDS: 40 960 bytes each), or 65 536 tables run at half rate
+    tab = {k: d["lds"] for k, d in ks.items() if k.startswith(("k_rollout_tab<", "k_rollout_allin_tab<"))}
+    assert len(tab) == 5 + 9 and all(32768 < v <= 40960 for v in tab.values()), tab
     for base in ("k_step", "k_step_async", "k_rollout", "k_env_step_async"):
         assert all("%s<%d>" % (base, n) in ks for n in build.SEATS), base
     bad = {k: d["private_segment"] for k, d in ks.items() if d["private_segment"] != 0 and k not in SCRATCH_ALLOWED}
