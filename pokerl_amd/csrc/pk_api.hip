@@ -415,7 +415,8 @@ static EnvKernArgs env_args(const pk_handle *h, const int32_t *actions_d, int se
 // pk_set_env_obs_packed: pk_env_step_fused_d / _async_d / _multi_d write the compact row of every table they deliver
 static inline EnvKernArgs with_packed(const pk_handle *h, EnvKernArgs ka) { ka.A.obs_packed = h->env_obs_packed; return ka; }
 
-static const uint32_t *eval7_table(int device);   // the table-driven evaluator's rank-mask table, one per device (defined with the judger entry points)
+// the table-driven evaluator's rank-mask table, one per device (defined with the judger entry points); built on `stream` the first time
+static const uint32_t *eval7_table(int device, hipStream_t stream = nullptr);
 
 extern "C" {
 
@@ -550,7 +551,10 @@ int pk_create(pk_handle **out, int device, int num_tables, int num_players, cons
     S.big_blind = big_blind; S.small_blind = small_blind;
     S.key0 = (uint32_t)seed; S.key1 = (uint32_t)(seed >> 32);
     S.table_id_base = table_id_base; S.T = num_tables;
-    S.evtab = num_players <= 10 ? eval7_table(device) : nullptr;   // k_rollout_tab / k_rollout_allin_tab stage it in LDS (NULL -- out of memory -- : k_rollout(_allin) is used)
+    // k_rollout_tab / k_rollout_allin_tab stage it in LDS (NULL -- out of memory -- : k_rollout(_allin) is used).  Built on the HANDLE's stream: the legacy
+    // default stream, once brought to life, takes one of the four normal-priority hardware queues for the rest of the process -- four env handles then
+    // share three (measured in round 6's first bench refresh: 3.6 -> 2.5 G env.step/s with four handles; docs/history.md section 5 has the mechanism)
+    S.evtab = num_players <= 10 ? eval7_table(device, h->stream) : nullptr;
 
     // Game.__init__ (game.py:242-264): every seat ACTIVE, dealer cursor = config dealer, credits 0, ranks NONE.
     {
@@ -1401,7 +1405,6 @@ static void *scratch(int device, size_t bytes) {  // caller holds g_scratch_mu a
     return s.p;
 }
 
-static const uint32_t *eval7_table(int device);
 // pk_eval_hands(_d)'s launch: the table path (k_eval_hands_tab); the register evaluator if the table could not be allocated or
 // env PK_EVAL_HANDS_TAB=0 (A/B knob).  tab: eval7_table(device), fetched by the caller BEFORE it takes g_scratch_mu.
 static void launch_eval_hands(const uint32_t *tab, const uint8_t *cards_d, const uint8_t *ncards_d, size_t m, uint8_t *rank_d, uint32_t *kick_d,
@@ -1489,15 +1492,15 @@ int pk_compare_rankings(int device, const uint8_t *rank, const uint32_t *kick, i
 
 // The 32 KB table of the table-driven evaluator (eval7_tab), one per device, built on first use.
 static uint32_t *g_eval_tab[PK_MAX_DEVICES];
-static const uint32_t *eval7_table(int device) {   // the device is current
+static const uint32_t *eval7_table(int device, hipStream_t stream) {   // the device is current
     if (device < 0 || device >= PK_MAX_DEVICES) return nullptr;
     std::lock_guard<std::mutex> lock(g_scratch_mu);
     if (g_eval_tab[device] && !dev_alloc_alive(g_eval_tab[device], EVAL7_TAB_WORDS * 4 + PK_ODD_BYTES)) g_eval_tab[device] = nullptr;   // (the device was reset: build it again)
     if (!g_eval_tab[device]) {
         uint32_t *p = nullptr;
         if (hipMalloc((void **)&p, EVAL7_TAB_WORDS * 4 + PK_ODD_BYTES) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-        hipLaunchKernelGGL(k_make_eval7_tab, dim3(EVAL7_TAB_WORDS / 256), dim3(256), 0, 0, p);
-        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(0) != hipSuccess) { (void)hipFree(p); return nullptr; }
+        hipLaunchKernelGGL(k_make_eval7_tab, dim3(EVAL7_TAB_WORDS / 256), dim3(256), 0, stream, p);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) { (void)hipFree(p); return nullptr; }
         g_eval_tab[device] = p;
     }
     return g_eval_tab[device];

@@ -40,6 +40,8 @@ rows = [r for r in csv.DictReader(open(trace)) if kname in r["Kernel_Name"]]
 durs = sorted((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in rows)
 n_l, n_s, line = bench_line(os.path.join(src, "trace.log"))
 waves = int(rows[0]["Grid_Size_X"]) // int(rows[0]["Workgroup_Size_X"])
+_dom = max(set(r["Kernel_Name"] for r in rows), key=lambda k: sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows if r["Kernel_Name"] == k))
+rows = [r for r in rows if r["Kernel_Name"] == _dom] + [r for r in rows if r["Kernel_Name"] != _dom]     # registers / LDS below: of the kernel the time goes to
 summary = {
     "tag": tag, "kernel": max(set(r["Kernel_Name"] for r in rows), key=lambda k: sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows if r["Kernel_Name"] == k)),
     "kernels_matched": sorted(set(r["Kernel_Name"] for r in rows)), "launches_total": len(durs),
