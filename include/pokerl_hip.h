@@ -243,6 +243,11 @@ int pk_pick_actions_d(pk_handle *h, int policy, int32_t *actions_d);
  * tables remember what they still owe; the next pk_rollout picks that up, and every other entry point (getters,
  * pk_step, pk_reset, pk_sync, pk_record_event, ...) first completes it (pk_flush), so no caller can observe a table
  * that has made fewer than the requested steps.  Results do not depend on how the steps were split over launches. */
+/* Kernel choice (internal, bit-identical results either way): for random agents up to six seats and all-in agents up to ten, batches of at most one
+ * wave per SIMD (<= 65 536 tables) and launches of >= 16 steps run the variant that ranks the showdown hands with the table-driven evaluator out of
+ * each wave's own 32 KB LDS copy of the table (+2 ... 14 %).  That variant takes ALL of a CU's LDS (four 40 KB workgroups): two handles that roll out
+ * CONCURRENTLY on one GPU then run one after the other instead of side by side -- env PK_ROLLOUT_TAB=0 switches the variant off for such a process
+ * (PK_ROLLOUT_TAB=<n>: minimum steps per launch, default 16). */
 int pk_rollout(pk_handle *h, int k_steps, int policy, int auto_reset, int fused, uint64_t *counters);
 /* Asynchronous fused pk_rollout calls (counters == NULL, auto_reset != 0) are also COALESCED on the host: while the two
  * most recent launches are still running, a call only adds its steps to a host-side count, which is launched as ONE kernel
