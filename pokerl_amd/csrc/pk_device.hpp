@@ -664,7 +664,7 @@ template <int N, bool RING>
 struct LdsTab;
 template <int N>
 struct LdsTab<N, true> {
-    static constexpr bool TAB = true;
+    static constexpr bool TAB = true, PAIRS = false;   // (PAIRS: two hands per lane per evaluation round -- end_block; the random agents' queues rarely hold > 64 hands: -0.6 % there)
     uint32_t item[64 * N + 1][2];      // [0] = community cards 0..3 (bytes); [1] = card4 | hole0<<6 | hole1<<12; [0] is overwritten by the hand's ranking
     uint32_t act[8][64];
     uint32_t show[N][64];
@@ -674,7 +674,7 @@ struct LdsTab<N, true> {
 };
 template <int N>
 struct LdsTab<N, false> {
-    static constexpr bool TAB = true;
+    static constexpr bool TAB = true, PAIRS = true;    // (all-in agents: ~290 hands per call at nine seats: +5 %)
     uint32_t item[64 * N + 1][2];
     uint32_t show[N][64];
     Fresh fresh;
@@ -1291,7 +1291,29 @@ struct Table {
                 lds.item[slot][1] = card(4) | (card(5 + 2 * p) << 6) | (card(6 + 2 * p) << 12) | (TAB ? 0u : ((uint32_t)(lane * N + p) << 18));
              PK_END
             PK_QSYNC();
-            for (uint32_t base = 0; base < total; base += PK_WAVE) {
+            uint32_t base0 = 0;
+            if constexpr (TAB) {
+                // More than 64 hands in the queue (the all-in agents: ~290 per call at nine seats): TWO hands per lane per round, branch-free, so that
+                // the ten lookups of a pair are in flight together and one hand's arithmetic fills the other's LDS waits -- at one wave per SIMD each
+                // of the three dependent LDS round trips of an evaluation is otherwise exposed.  A lane without a (second) hand evaluates the dummy
+                // slot.  The remainder (and the usual case of the random agents, <= 64 hands) takes the single-hand loop below.
+                if constexpr (LDS::PAIRS) {
+                    auto bits_of = [](uint32_t w0, uint32_t w1) {
+                        return (4ull << (w0 & 63)) | (4ull << ((w0 >> 8) & 63)) | (4ull << ((w0 >> 16) & 63)) | (4ull << ((w0 >> 24) & 63)) |
+                               (4ull << (w1 & 63)) | (4ull << ((w1 >> 6) & 63)) | (4ull << ((w1 >> 12) & 63));
+                    };
+                    for (; base0 + PK_WAVE < total; base0 += 2 * PK_WAVE) {
+                        PK_PROF(prof.count(PF_N_EVALPASS, 2);)
+                        const uint32_t ia = base0 + lane, ib0 = ia + PK_WAVE;
+                        const uint32_t ib = ib0 < total ? ib0 : (uint32_t)(64 * N);          // (ia < total: the loop condition)
+                        const uint32_t a0 = lds.item[ia][0], a1 = lds.item[ia][1], b0 = lds.item[ib][0], b1 = lds.item[ib][1];
+                        const Eval7Front fa = eval7_tab_front_bits(bits_of(a0, a1), lds.evtab), fb = eval7_tab_front_bits(bits_of(b0, b1), lds.evtab);
+                        const uint32_t va = eval7_tab_back(fa, lds.evtab), vb = eval7_tab_back(fb, lds.evtab);
+                        lds.item[ia][0] = va; lds.item[ib][0] = vb;
+                    }
+                }
+            }
+            for (uint32_t base = base0; base < total; base += PK_WAVE) {
                 PK_PROF(prof.count(PF_N_EVALPASS);)
                 uint32_t i = base + lane;
                 if (i < total) {
