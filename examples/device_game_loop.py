@@ -61,10 +61,9 @@ for s in range(steps):
 game.sync()
 te = terr.download(np.uint8, T)
 assert not (te[ready.download(np.uint8, T) != 0] & L.TERR_INVALID_ACTION).any()      # the picks were valid for every table that took one
-# A drain is a full step call: it would step the ready tables AGAIN with whatever `actions` holds.  "No step" is spelled as an invalid action (-1):
-# those tables come back untouched with TERR_INVALID_ACTION (by design, not an error); the tables in flight ignore their action and finish.
-actions.upload(np.full(T, -1, np.int32))
-game.step_async_d(actions, flags, terr, ready, max_hands=0, auto_reset=True)   # drain: every table ready
+# A drain with an actions buffer is a full step call: it would step the ready tables AGAIN with whatever the buffer holds.  actions = None (or -1 for
+# a table) means "no step": those tables come back untouched with TERR_INVALID_ACTION (by design, not an error); the tables in flight finish.
+game.step_async_d(None, flags, terr, ready, max_hands=0, auto_reset=True)      # drain only (actions None): every table ready, nobody stepped
 game.sync()
 assert (ready.download(np.uint8, T) != 0).all() and not (terr.download(np.uint8, T) & ~np.uint8(L.TERR_INVALID_ACTION | L.TERR_HAND_CAP)).any()
 dt = time.perf_counter() - t0

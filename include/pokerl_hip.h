@@ -163,8 +163,8 @@ int pk_step_auto_d(pk_handle *h, const int32_t *actions_d, uint8_t *flags_d, uin
  * steps are in flight (PK_E_INVALID_ARG).  A step that has already rolled 16 hands is carried to its end whatever the budget.
  * A DRAIN (max_hands <= 0) IS A FULL STEP CALL: besides finishing what is in flight it steps every idle (ready) table with actions_d[t], like any other
  * call.  To drain WITHOUT stepping, fill actions_d with an invalid action (-1): those tables come back untouched with PK_TERR_INVALID_ACTION in terr_d[t]
- * (the error byte of a table that was merely passed over -- not an error of the call).  Draining with the buffer the previous launch consumed steps the
- * ready tables a second time with stale actions. */
+ * (the error byte of a table that was merely passed over -- not an error of the call) -- or pass actions_d == NULL, which only a drain accepts and which
+ * means the same "no action for anybody".  Draining with the buffer the previous launch consumed steps the ready tables a second time with stale actions. */
 int pk_step_async_d(pk_handle *h, const int32_t *actions_d, uint8_t *flags_d, uint8_t *terr_d, uint8_t *ready_d, int max_hands, int auto_reset);
 
 /* Game.get_valid_actions(player), pokerl/game.py:339-383: out[T][7] one-hot bytes.  player < 0: each table's active
@@ -194,9 +194,10 @@ int pk_get_hand_ranks(pk_handle *h, uint8_t *rank, uint32_t *kick);
 
 /* pokerl.judger.eval_hand (pokerl/judger.py:7-99) on M hands.  cards[M][7] Card.value bytes (unused slots ignored),
  * ncards[M] in 0..7 (NULL = all 7).  rank[M], kick[M] (packed kickers, judger.py:101-109), nkick[M] (may be NULL).
- * The FIRST call per device (of this or any other judger entry point that uses the table path) builds a 32 KB table: one hipMalloc, one small
- * kernel on the legacy default stream and a hipStreamSynchronize(0) -- a one-off host block and an implicit sync with blocking streams, not legal
- * inside a stream capture: make one warm-up call (any m >= 1) before capturing or timing.
+ * The FIRST call per device that needs the evaluator's 32 KB table builds it (unless a handle of up to ten seats exists on the device: pk_create has
+ * built it): one hipMalloc, one small kernel and one hipStreamSynchronize -- on the stream the call was given (pk_eval_hands_d) or on the legacy default
+ * stream (the host-buffer entry points, which run there anyway).  A one-off host block, not legal inside a stream capture: make one warm-up call
+ * (any m >= 1) before capturing or timing.
  * Multiset semantics: duplicate cards are legal, as in the reference's own tests (those hands, hands of fewer than three cards and
  * hands with a byte that is no card -- suit > 3 or rank nibble > 12 -- take the reference's sort-and-scan; 3..7 DISTINCT cards a
  * table-driven evaluator that equals it on every subset of the deck: tools/host_sim `evalntab`, GPU digest fast = 4). */

@@ -721,7 +721,8 @@ int pk_step_auto_d(pk_handle *h, const int32_t *actions_d, uint8_t *flags_d, uin
     return launch_step(h, actions_d, flags_d, terr_d, 1);
 }
 int pk_step_async_d(pk_handle *h, const int32_t *actions_d, uint8_t *flags_d, uint8_t *terr_d, uint8_t *ready_d, int max_hands, int auto_reset) {
-    if (!h || !actions_d || !flags_d || !ready_d) return h ? h->fail(PK_E_INVALID_ARG, "pk_step_async_d: NULL buffer") : PK_E_INVALID_ARG;
+    if (!h || !flags_d || !ready_d) return h ? h->fail(PK_E_INVALID_ARG, "pk_step_async_d: NULL buffer") : PK_E_INVALID_ARG;
+    if (!actions_d && max_hands > 0) return h->fail(PK_E_INVALID_ARG, "pk_step_async_d: actions_d may be NULL only for a drain (max_hands <= 0): finish what is in flight, step nothing");
     ON_DEVICE(h);
     if (h->step_pending) {
         if ((auto_reset ? 1 : 0) != h->step_auto)   // steps in flight keep the reset rule they were started with
@@ -1430,7 +1431,7 @@ int pk_eval_hands_d(int device, const uint8_t *cards_d, const uint8_t *ncards_d,
     DeviceGuard guard(device);
     if (!guard.ok) { g_err = "hipSetDevice failed"; return PK_E_HIP; }
     if (m == 0) return PK_OK;
-    launch_eval_hands(eval7_table(device), cards_d, ncards_d, m, rank_d, kick_d, nkick_d, (hipStream_t)stream);
+    launch_eval_hands(eval7_table(device, (hipStream_t)stream), cards_d, ncards_d, m, rank_d, kick_d, nkick_d, (hipStream_t)stream);   // (a first call builds the table on the CALLER's stream)
     if (hipGetLastError() != hipSuccess) { g_err = "pk_eval_hands_d: launch failed"; return PK_E_HIP; }
     return PK_OK;
 }

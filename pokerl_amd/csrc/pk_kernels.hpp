@@ -213,7 +213,8 @@ __device__ __forceinline__ void rollout_body(const State *__restrict__ Sp, const
     static_assert(!BOUNDED || POLICY == PK_POLICY_EXTERNAL, "bounded launches are pk_step_async_d's");
     if (EXTERNAL) {                                                                // game.py:648-651
         const uint32_t vm = tb.valid_mask(high_bet);
-        ext_action = live ? as_global(actions)[t] : -1;
+        if constexpr (BOUNDED) ext_action = (live && actions) ? as_global(actions)[t] : -1;    // (actions == NULL: a drain that steps nothing, pk_step_async_d)
+        else ext_action = live ? as_global(actions)[t] : -1;
         const bool carried = BOUNDED && live && tb.stepped;                        // a step of an earlier launch is in flight: its action was taken then
         ext_ok = carried || (live && ext_action >= 0 && ext_action < PK_NUM_MOVES && ((vm >> ext_action) & 1));
         owed = ext_ok ? 1u : 0u;                                                   // (the host has flushed: nothing was owed)

@@ -125,7 +125,9 @@ class VecGame:
         """`Game.step` as a bounded launch (pk_step_async_d): tables whose step has returned get ready_d[t] = 1 and their flags_d /
         terr_d; a table whose step rolls on through further hands (game.py:607-611) stays in flight on the device, ready_d[t] = 0,
         and the next call carries on with it, ignoring actions_d[t].  max_hands <= 0 drains (every table ready); until then every
-        other method that reads or changes tables raises (PK_E_BUSY).  Per table the steps, flags and RNG draws are the synchronous ones."""
+        other method that reads or changes tables raises (PK_E_BUSY).  Per table the steps, flags and RNG draws are the synchronous ones.
+        A drain is a full step call -- idle tables are stepped with actions_d[t] -- unless actions_d is None (drain only: nobody steps, idle
+        tables come back untouched with TERR_INVALID_ACTION in terr_d)."""
         L.check(self._lib.pk_step_async_d(self._h, self._dptr(actions_d), self._dptr(flags_d), self._dptr(terr_d), self._dptr(ready_d),
                                           int(max_hands), int(bool(auto_reset))), self._h)
 

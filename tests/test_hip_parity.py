@@ -624,9 +624,16 @@ def test_async_game_step(HB, O):
             badrow = mask & ((fl != exp_f) | (te != want_e))
             assert not badrow.any(), (where, what, [(int(t), int(exp_f[t]), int(fl[t]), int(want_e[t]), int(te[t])) for t in np.nonzero(badrow)[0][:6]], int(badrow.sum()))
 
-        def drain():                                                     # finish what is in flight; idle tables: "no step" (an invalid action)
-            act.upload(np.full(T, -1, np.int32))
-            g.step_async_d(act, flags, terr, ready, max_hands=0, auto_reset=auto); g.sync()
+        drains = [0]
+
+        def drain():                                                     # finish what is in flight; idle tables: "no step" -- an invalid action (-1), or
+            drains[0] += 1                                               # no actions buffer at all (NULL: only a drain takes that), alternately
+            if drains[0] % 2:
+                act.upload(np.full(T, -1, np.int32))
+                g.step_async_d(act, flags, terr, ready, max_hands=0, auto_reset=auto)
+            else:
+                g.step_async_d(None, flags, terr, ready, max_hands=0, auto_reset=auto)
+            g.sync()
             assert (ready.download(np.uint8, T) != 0).all(), where
             fin = ~idle
             check(fin, "drain")
@@ -676,6 +683,7 @@ def test_async_game_step(HB, O):
         assert lib.pk_rollout(g._h, 5, 0, 1, 1, None) == L.PK_E_BUSY and lib.pk_env_reset_d(g._h, None, 0) == L.PK_E_BUSY
         assert lib.pk_env_step_async_d(g._h, None, 0, 0, 1, 4, act.ptr, flags.ptr, flags.ptr, terr.ptr, None, ready.ptr) == L.PK_E_BUSY
         assert lib.pk_step_async_d(g._h, act.ptr, flags.ptr, terr.ptr, ready.ptr, 1, 0 if auto else 1) == L.PK_E_INVALID_ARG
+        assert lib.pk_step_async_d(g._h, None, flags.ptr, terr.ptr, ready.ptr, 1, 1 if auto else 0) == L.PK_E_INVALID_ARG      # NULL actions: a drain only
         assert lib.pk_pick_actions_d(g._h, 0, act.ptr) == L.PK_OK and lib.pk_sync(g._h) == L.PK_OK
         act.upload(np.full(T, -1, np.int32))
         g.step_async_d(act, flags, terr, ready, max_hands=0, auto_reset=auto); g.sync()
