@@ -26,7 +26,7 @@ obs = DeviceBuffer(T * (17 + 3 * N) * 8)                       # dense StateView
 L.check(L.lib().pk_get_obs_d(game._h, -1, obs.ptr), game._h)   # the rows of the freshly reset tables (one launch, once) ...
 game.set_step_obs(obs, None)                                   # ... from now on every step_d / step_async_d writes `game.active_state` itself
                                                                #     (pk_set_step_obs: from the step kernel's registers, no launch of its own)
-for _ in range(300):                                           # warm-up: the first launches of a process load code objects and ramp the clock
+for _ in range(4000):                                          # warm-up (~0.1 s): the first launches of a process load code objects and ramp the clock
     game.pick_actions_d(actions, pokerl_amd.Policy.RANDOM)
     game.step_d(actions, flags, terr, auto_reset=True)
 game.sync()
